@@ -1,0 +1,96 @@
+"""ctypes binding of libclmgs_hip.so (C ABI declared in include/clmgs.h).
+
+The library is the product: if it is missing, or if a tensor handed to an
+operator is not a contiguous CUDA(HIP) tensor of the declared dtype, we raise --
+there is deliberately no eager/PyTorch fallback path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclmgs_hip.so")
+
+_vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/clmgs.h one to one
+SIGNATURES = {
+    "clmgs_version": (_i, []),
+    "clmgs_last_error": (ctypes.c_char_p, []),
+    "clmgs_projection_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "clmgs_projection_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_sh_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "clmgs_sh_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "clmgs_isect_count_temp_bytes": (_sz, [_i]),
+    "clmgs_isect_count": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
+    "clmgs_isect_sort_temp_bytes": (_sz, [_i64]),
+    "clmgs_isect_emit_sort": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
+    "clmgs_isect_offsets": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
+    "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_ssim_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_ssim_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "clmgs_rows_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i]),
+    "clmgs_rows_scatter_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i]),
+    "clmgs_scatter_to_bit": (_i, [_vp, _vp, _i, _vp, _i64, _i]),
+    "clmgs_extract_ffs": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "clmgs_pair_overlap_count": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
+    "clmgs_set_signal": (_i, [_vp, _vp, _i, ctypes.c_int32]),
+    "clmgs_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _f, _f, _f, _i, _i, _f, _i]),
+    "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _f, _f, _f, _i, _i, _f, _i, _vp, _i]),
+    "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
+    "clmgs_pinned_alloc": (_vp, [_sz]),
+    "clmgs_pinned_free": (_i, [_vp]),
+}
+
+_lib = None
+
+
+class ClmgsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ClmgsError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C clm_gs_amd/csrc).  clm_gs_amd has no CPU/eager fallback."
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError = ABI drift, also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().clmgs_last_error()
+        raise ClmgsError(f"libclmgs_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=None, allow_none=False, allow_host=False):
+    """Raw pointer of a contiguous device tensor (or pinned host tensor if allowed)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise ClmgsError("required tensor is None")
+    if dtype is not None and t.dtype != dtype:
+        raise ClmgsError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ClmgsError("tensor must be contiguous")
+    if not t.is_cuda:
+        if not (allow_host and (t.is_pinned() or getattr(t, "_clmgs_pinned", False))):
+            raise ClmgsError("tensor must live on the GPU (no CPU fallback in clm_gs_amd)")
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,199 @@
+"""clm_kernels operator surface used by the CLM-GS engines, on gfx950.
+
+Same names and argument meaning as the reference's call sites
+(strategies/base_engine.py:5,93; strategies/clm_offload/engine.py:14-20,152-153,
+200-204,227-232,499-505,622-636,709-716,789-825; optimizer.py:3,76-88).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, stream
+
+F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
+
+
+# ------------------------------------------------------------------- fused SSIM
+class _FusedSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        L = _lib.lib()
+        img1, img2 = img1.contiguous(), img2.contiguous()
+        B, CH, H, W = img1.shape
+        need = img1.requires_grad
+        ssim_sum = torch.zeros((1,), dtype=F32, device=img1.device)
+        maps = [torch.empty_like(img1) for _ in range(3)] if need else [None, None, None]
+        check(L.clmgs_ssim_fwd(stream(), B, CH, H, W, dptr(img1, F32), dptr(img2, F32),
+                               dptr(ssim_sum), dptr(maps[0], F32, True), dptr(maps[1], F32, True),
+                               dptr(maps[2], F32, True)))
+        ctx.shape = (B, CH, H, W)
+        if need:
+            ctx.save_for_backward(img1, img2, *maps)
+        return (ssim_sum / float(img1.numel())).reshape(())
+
+    @staticmethod
+    def backward(ctx, v):
+        L = _lib.lib()
+        img1, img2, m0, m1, m2 = ctx.saved_tensors
+        B, CH, H, W = ctx.shape
+        v_img1 = torch.empty_like(img1)
+        v = v.reshape(1).to(F32).contiguous()
+        check(L.clmgs_ssim_bwd(stream(), B, CH, H, W, dptr(img1), dptr(img2), dptr(v, F32),
+                               1.0 / float(img1.numel()), dptr(m0), dptr(m1), dptr(m2),
+                               dptr(v_img1)))
+        return v_img1, None
+
+
+def fused_ssim(img1, img2):
+    """Mean SSIM of [B,CH,H,W] images (11x11, sigma 1.5, zero padded), differentiable in img1."""
+    return _FusedSSIM.apply(img1, img2)
+
+
+# ------------------------------------------------------------- SH row movement
+def _idx64(t):
+    return 1 if t is not None and t.dtype == I64 else 0
+
+
+def _rows(fn, dst, src, dst_idx, src_idx, grid):
+    L = _lib.lib()
+    n = (dst_idx if dst_idx is not None else src_idx).numel() if (dst_idx is not None or src_idx is not None) else dst.shape[0]
+    if dst_idx is not None and src_idx is not None and dst_idx.dtype != src_idx.dtype:
+        src_idx = src_idx.to(dst_idx.dtype)
+    is64 = _idx64(dst_idx if dst_idx is not None else src_idx)
+    cols = src.shape[-1]
+    check(getattr(L, fn)(stream(), dptr(dst, F32, allow_host=True), dptr(src, F32, allow_host=True),
+                         dptr(dst_idx, None, True), dptr(src_idx, None, True), is64, int(n),
+                         int(cols), int(grid)))
+
+
+def send_shs2gpu_stream(shs, parameters, filter_idx, grid_size=0, block_size=256):
+    """shs[i] = parameters[filter[i]]  (parameters may be pinned host memory)."""
+    _rows("clmgs_rows_gather", shs, parameters, None, filter_idx, grid_size)
+
+
+def send_shs2gpu_stream_retention(shs_next, parameters, shs_retent, host_indices_to_param,
+                                  rtnt_indices_to_param, param_indices_from_host,
+                                  param_indices_from_rtnt, grid_size=0, block_size=256,
+                                  grid_size_D=0, block_size_D=256):
+    """shs_next[param_indices_from_host[i]] = parameters[host_indices_to_param[i]] and
+    shs_next[param_indices_from_rtnt[j]] = shs_retent[rtnt_indices_to_param[j]]."""
+    if host_indices_to_param.numel():
+        _rows("clmgs_rows_gather", shs_next, parameters, param_indices_from_host,
+              host_indices_to_param, grid_size)
+    if rtnt_indices_to_param.numel():
+        _rows("clmgs_rows_gather", shs_next, shs_retent, param_indices_from_rtnt,
+              rtnt_indices_to_param, grid_size_D)
+
+
+def send_shs2cpu_grad_buffer_stream(shs_grad, grad_buffer, filter_idx, accum=True, grid_size=0,
+                                    block_size=256):
+    """grad_buffer[filter[i]] (+)= shs_grad[i]."""
+    _rows("clmgs_rows_scatter_add" if accum else "clmgs_rows_gather", grad_buffer, shs_grad,
+          filter_idx, None, grid_size)
+
+
+def send_shs2cpu_grad_buffer_stream_retention(shs_grad, grad_buffer, shs_grad_next,
+                                              host_indices_from_grad, rtnt_indices_from_grad,
+                                              grad_indices_to_host, grad_indices_to_rtnt,
+                                              accum=True, grid_size=0, block_size=256,
+                                              grid_size_D=0, block_size_D=256):
+    """grad_buffer[host_indices_from_grad[i]] += shs_grad[grad_indices_to_host[i]] and
+    shs_grad_next[rtnt_indices_from_grad[j]] = shs_grad[grad_indices_to_rtnt[j]]."""
+    if host_indices_from_grad.numel():
+        _rows("clmgs_rows_scatter_add" if accum else "clmgs_rows_gather", grad_buffer, shs_grad,
+              host_indices_from_grad, grad_indices_to_host, grid_size)
+    if rtnt_indices_from_grad.numel():
+        _rows("clmgs_rows_gather", shs_grad_next, shs_grad, rtnt_indices_from_grad,
+              grad_indices_to_rtnt, grid_size_D)
+
+
+@torch.no_grad()
+def spherical_harmonics_bwd_inplace(degrees_to_use, dirs, coeffs, v_coeffs, v_colors):
+    """SH backward that ACCUMULATES into the persistent v_coeffs[n,48] buffer and returns
+    v_dirs (clm_offload/engine.py:709-716)."""
+    L = _lib.lib()
+    n = dirs.numel() // 3
+    d2, c2, vc = dirs.contiguous(), coeffs.contiguous(), v_colors.contiguous()
+    v_dirs = torch.empty_like(d2)
+    check(L.clmgs_sh_bwd(stream(), n, int(degrees_to_use), dptr(d2, F32), dptr(c2, F32), None,
+                         dptr(vc, F32), dptr(v_coeffs, F32), 1, dptr(v_dirs)))
+    return v_dirs
+
+
+# ------------------------------------------------------------------- bitmaps
+def scatter_to_bit(bitmap, filter_idx, bit):
+    L = _lib.lib()
+    check(L.clmgs_scatter_to_bit(stream(), dptr(bitmap), bitmap.element_size(),
+                                 dptr(filter_idx.contiguous(), I64), filter_idx.numel(), int(bit)))
+
+
+def extract_ffs(bitmap, ffs):
+    L = _lib.lib()
+    check(L.clmgs_extract_ffs(stream(), dptr(bitmap), bitmap.element_size(), bitmap.numel(),
+                              dptr(ffs, U8)))
+
+
+def compute_cnt_h(bitmap, tmp_buffer, grid_size=64, block_size=256):
+    """Reference contract (clm_offload/engine.py:227-233): fill tmp_buffer[bsz-1, T] with
+    partial counts whose row sums are cnt_d[i] = #(F_i & F_{i+1}).  Here the full count lands
+    in column 0 and the remaining columns are zero."""
+    L = _lib.lib()
+    bsz = tmp_buffer.shape[0] + 1
+    cnt = torch.zeros((bsz - 1,), dtype=I32, device=bitmap.device)
+    check(L.clmgs_pair_overlap_count(stream(), dptr(bitmap), bitmap.element_size(), bitmap.numel(),
+                                     bsz, dptr(cnt)))
+    tmp_buffer.zero_()
+    tmp_buffer[:, 0] = cnt
+    return cnt
+
+
+def pair_overlap_count(bitmap, bsz):
+    L = _lib.lib()
+    cnt = torch.zeros((bsz - 1,), dtype=I32, device=bitmap.device)
+    check(L.clmgs_pair_overlap_count(stream(), dptr(bitmap), bitmap.element_size(), bitmap.numel(),
+                                     int(bsz), dptr(cnt)))
+    return cnt
+
+
+def set_signal(signal_tensor_pinned, idx, value):
+    L = _lib.lib()
+    check(L.clmgs_set_signal(stream(), ctypes.c_void_p(signal_tensor_pinned.data_ptr()), int(idx),
+                             int(value)))
+
+
+# ----------------------------------------------------------------------- Adam
+def selective_adam_update(param, grad, exp_avg, exp_avg_sq, visibility, lr, beta1, beta2, eps, N, M):
+    """Adam on rows where visibility is True, no bias correction (optimizer.py:76-88)."""
+    L = _lib.lib()
+    col_lr = torch.full((M,), float(lr), dtype=F32, device=param.device)
+    vis = visibility.contiguous().view(U8)
+    check(L.clmgs_adam_rows(stream(), dptr(param, F32), dptr(grad, F32), dptr(exp_avg, F32),
+                            dptr(exp_avg_sq, F32), None, 0, dptr(vis, U8), int(N), int(M),
+                            dptr(col_lr), float(beta1), float(beta2), float(eps), 1, 0, 1.0, 0))
+
+
+def adam_rows(p, g, m, v, rows, col_lr, beta1, beta2, eps, step, bias_correction=True,
+              grad_scale=1.0, zero_grad=False, mask=None):
+    """Row-sparse Adam with per-column learning rate on device tensors [*, cols]."""
+    L = _lib.lib()
+    n_rows = rows.numel() if rows is not None else p.shape[0]
+    cols = p.shape[-1] if p.dim() > 1 else 1
+    check(L.clmgs_adam_rows(stream(), dptr(p, F32), dptr(g, F32), dptr(m, F32), dptr(v, F32),
+                            dptr(rows, None, True), _idx64(rows),
+                            dptr(mask.view(U8) if mask is not None else None, U8, True),
+                            int(n_rows), int(cols), dptr(col_lr, F32), float(beta1), float(beta2),
+                            float(eps), int(step), int(bool(bias_correction)), float(grad_scale),
+                            int(bool(zero_grad))))
+
+
+def densify_stats(filter_idx, v_means2d, radii, width, height, max_radii2D, xyz_gradient_accum,
+                  denom, only_visible=True):
+    """Fused form of gsplat_add_densification_stats[_exact_filter]
+    (clm_offload/gaussian_model.py:833-851, no_offload/gaussian_model.py:767-783)."""
+    L = _lib.lib()
+    n = radii.numel()
+    check(L.clmgs_densify_stats(stream(), n, dptr(filter_idx, I64, True),
+                                dptr(v_means2d.contiguous(), F32), dptr(radii.contiguous(), I32),
+                                int(bool(only_visible)), float(width) * 0.5, float(height) * 0.5, dptr(max_radii2D, F32),
+                                dptr(xyz_gradient_accum, F32), dptr(denom, F32)))

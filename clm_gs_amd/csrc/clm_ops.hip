@@ -1,0 +1,292 @@
+// CLM offload data movers, visibility bitmaps, row-sparse Adam and densification
+// statistics (gfx950).  Replaces the clm_kernels entry points used at
+// strategies/clm_offload/engine.py:152-153,200-204,227-232,499-505,622-636,789-825
+// and optimizer.py:76-88; stats: strategies/clm_offload/gaussian_model.py:833-851.
+//
+// All of these are HBM- (or host-link-) bound row/byte movers: a 48-float row is
+// 12 lanes x 16 B, so 64 lanes move 5 1/3 rows per instruction fully coalesced.
+#include "common.h"
+
+namespace clmgs {
+
+template <typename IdxT>
+__device__ __forceinline__ int64_t row_of(const void* idx, int64_t i) {
+  return idx ? (int64_t)reinterpret_cast<const IdxT*>(idx)[i] : i;
+}
+
+// cols % 4 == 0 fast path: one float4 per lane.
+template <typename IdxT, bool ADD>
+__global__ void __launch_bounds__(256)
+rows_move_f4_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                    const void* __restrict__ dst_idx, const void* __restrict__ src_idx,
+                    int64_t n_rows, int f4_per_row) {
+  const int64_t total = n_rows * f4_per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / f4_per_row;
+    const int k = (int)(i - r * f4_per_row);
+    const int64_t sr = row_of<IdxT>(src_idx, r), dr = row_of<IdxT>(dst_idx, r);
+    const float4 v = reinterpret_cast<const float4*>(src)[sr * f4_per_row + k];
+    float4* d = reinterpret_cast<float4*>(dst) + dr * f4_per_row + k;
+    if (ADD) {
+      float4 o = *d;
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      *d = o;
+    } else {
+      *d = v;
+    }
+  }
+}
+
+template <typename IdxT, bool ADD>
+__global__ void __launch_bounds__(256)
+rows_move_f1_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                    const void* __restrict__ dst_idx, const void* __restrict__ src_idx,
+                    int64_t n_rows, int cols) {
+  const int64_t total = n_rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int k = (int)(i - r * cols);
+    const int64_t sr = row_of<IdxT>(src_idx, r), dr = row_of<IdxT>(dst_idx, r);
+    const float v = src[sr * cols + k];
+    if (ADD) dst[dr * cols + k] += v; else dst[dr * cols + k] = v;
+  }
+}
+
+template <bool ADD>
+static int rows_move(void* stream, float* dst, const float* src, const void* dst_idx,
+                     const void* src_idx, int idx_is_64, int64_t n_rows, int cols,
+                     int grid_blocks) {
+  CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0);
+  if (n_rows == 0) return 0;
+  CLMGS_CHECK_ARG(dst && src);
+  hipStream_t s = (hipStream_t)stream;
+  const bool f4 = (cols % 4 == 0) && (((uintptr_t)dst | (uintptr_t)src) % 16 == 0);
+  const int64_t total = f4 ? n_rows * (cols / 4) : n_rows * cols;
+  int grid = grid_blocks > 0 ? grid_blocks : min(ceil_div(total, 256), 256 * 8);
+  if (f4) {
+    if (idx_is_64)
+      hipLaunchKernelGGL((rows_move_f4_kernel<int64_t, ADD>), dim3(grid), dim3(256), 0, s, dst, src,
+                         dst_idx, src_idx, n_rows, cols / 4);
+    else
+      hipLaunchKernelGGL((rows_move_f4_kernel<int32_t, ADD>), dim3(grid), dim3(256), 0, s, dst, src,
+                         dst_idx, src_idx, n_rows, cols / 4);
+  } else {
+    if (idx_is_64)
+      hipLaunchKernelGGL((rows_move_f1_kernel<int64_t, ADD>), dim3(grid), dim3(256), 0, s, dst, src,
+                         dst_idx, src_idx, n_rows, cols);
+    else
+      hipLaunchKernelGGL((rows_move_f1_kernel<int32_t, ADD>), dim3(grid), dim3(256), 0, s, dst, src,
+                         dst_idx, src_idx, n_rows, cols);
+  }
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ bitmaps
+template <typename T>
+__global__ void scatter_to_bit_kernel(T* __restrict__ bitmap, const int64_t* __restrict__ filter,
+                                      int64_t n, int bit) {
+  using U = typename std::make_unsigned<T>::type;
+  const U m = (U)((U)1 << bit);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // ids inside one filter are unique -> plain RMW, no atomics needed
+    U* p = reinterpret_cast<U*>(bitmap) + filter[i];
+    *p = (U)(*p | m);
+  }
+}
+
+template <typename T>
+__global__ void extract_ffs_kernel(const T* __restrict__ bitmap, int64_t N, uint8_t* __restrict__ ffs) {
+  using U = typename std::make_unsigned<T>::type;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = (unsigned long long)(U)bitmap[i];
+    ffs[i] = (uint8_t)(v ? (__ffsll((long long)v)) : 0);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+pair_overlap_kernel(const T* __restrict__ bitmap, int64_t N, int bsz, int32_t* __restrict__ cnt) {
+  using U = typename std::make_unsigned<T>::type;
+  __shared__ int sh[64];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = (unsigned long long)(U)bitmap[i];
+    // micro-batch m lives in bit (bsz-1-m); adjacent pairs = v & (v << 1)
+    unsigned long long both = v & (v << 1);
+    while (both) {
+      const int b = __ffsll((long long)both) - 1;  // bit of micro-batch m, m+1 in bit b-1
+      both &= both - 1;
+      atomicAdd(&sh[bsz - 1 - b], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bsz - 1; i += blockDim.x)
+    if (sh[i]) atomicAdd(&cnt[i], sh[i]);
+}
+
+__global__ void set_signal_kernel(int32_t* signal, int idx, int32_t value) {
+  __threadfence_system();
+  __hip_atomic_store(signal + idx, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// --------------------------------------------------------------------- Adam
+template <typename IdxT>
+__global__ void __launch_bounds__(256)
+adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, const void* __restrict__ rows,
+                 const uint8_t* __restrict__ mask, int64_t n_rows, int cols,
+                 const float* __restrict__ col_lr, float beta1, float beta2, float eps,
+                 float inv_bc1, float inv_sqrt_bc2, float grad_scale, int zero_grad) {
+  const int64_t total = n_rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int k = (int)(i - r * cols);
+    const int64_t row = row_of<IdxT>(rows, r);
+    if (mask && !mask[row]) continue;
+    const int64_t o = row * cols + k;
+    const float gg = g[o] * grad_scale;
+    const float mm = beta1 * m[o] + (1.f - beta1) * gg;
+    const float vv = beta2 * v[o] + (1.f - beta2) * gg * gg;
+    m[o] = mm; v[o] = vv;
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    p[o] -= (col_lr[k] * inv_bc1) * (mm / denom);
+    if (zero_grad) g[o] = 0.f;
+  }
+}
+
+// ------------------------------------------------------- densification stats
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int64_t n, const int64_t* __restrict__ filter,
+                     const float* __restrict__ v_means2d, const int32_t* __restrict__ radii,
+                     int only_visible, float half_w, float half_h, float* __restrict__ max_radii2D,
+                     float* __restrict__ accum, float* __restrict__ denom) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = radii[i];
+    if (only_visible && r <= 0) continue;
+    const int64_t g = filter ? filter[i] : i;
+    const float gx = v_means2d[2 * i] * half_w, gy = v_means2d[2 * i + 1] * half_h;
+    max_radii2D[g] = fmaxf(max_radii2D[g], (float)r);
+    accum[g] += sqrtf(gx * gx + gy * gy);
+    denom[g] += 1.f;
+  }
+}
+
+}  // namespace clmgs
+
+using namespace clmgs;
+
+extern "C" int clmgs_rows_gather(void* stream, float* dst, const float* src, const void* dst_idx,
+                                 const void* src_idx, int idx_is_64, int64_t n_rows, int cols,
+                                 int grid_blocks) {
+  return rows_move<false>(stream, dst, src, dst_idx, src_idx, idx_is_64, n_rows, cols, grid_blocks);
+}
+
+extern "C" int clmgs_rows_scatter_add(void* stream, float* dst, const float* src,
+                                      const void* dst_idx, const void* src_idx, int idx_is_64,
+                                      int64_t n_rows, int cols, int grid_blocks) {
+  return rows_move<true>(stream, dst, src, dst_idx, src_idx, idx_is_64, n_rows, cols, grid_blocks);
+}
+
+#define DISPATCH_ELEM(bytes, CALL)                    \
+  switch (bytes) {                                    \
+    case 1: { typedef int8_t T; CALL; } break;        \
+    case 2: { typedef int16_t T; CALL; } break;       \
+    case 4: { typedef int32_t T; CALL; } break;       \
+    case 8: { typedef int64_t T; CALL; } break;       \
+    default: clmgs::set_error("bitmap elem_bytes must be 1,2,4,8"); return CLMGS_EINVAL; \
+  }
+
+extern "C" int clmgs_scatter_to_bit(void* stream, void* bitmap, int elem_bytes,
+                                    const int64_t* filter, int64_t n, int bit) {
+  CLMGS_CHECK_ARG(n >= 0 && bit >= 0 && bit < elem_bytes * 8);
+  if (n == 0) return 0;
+  CLMGS_CHECK_ARG(bitmap && filter);
+  const int grid = min(ceil_div(n, 256), 256 * 8);
+  DISPATCH_ELEM(elem_bytes, hipLaunchKernelGGL(scatter_to_bit_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (T*)bitmap, filter, n, bit));
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_extract_ffs(void* stream, const void* bitmap, int elem_bytes, int64_t N,
+                                 uint8_t* ffs) {
+  CLMGS_CHECK_ARG(N >= 0);
+  if (N == 0) return 0;
+  CLMGS_CHECK_ARG(bitmap && ffs);
+  const int grid = min(ceil_div(N, 256), 256 * 8);
+  DISPATCH_ELEM(elem_bytes, hipLaunchKernelGGL(extract_ffs_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)bitmap, N, ffs));
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_pair_overlap_count(void* stream, const void* bitmap, int elem_bytes,
+                                        int64_t N, int bsz, int32_t* cnt) {
+  CLMGS_CHECK_ARG(N >= 0 && bsz >= 2 && bsz <= elem_bytes * 8 && cnt);
+  if (N == 0) return 0;
+  CLMGS_CHECK_ARG(bitmap);
+  const int grid = min(ceil_div(N, 256), 256 * 4);
+  DISPATCH_ELEM(elem_bytes, hipLaunchKernelGGL(pair_overlap_kernel<T>, dim3(grid), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)bitmap, N, bsz, cnt));
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_set_signal(void* stream, int32_t* signal_pinned, int idx, int32_t value) {
+  CLMGS_CHECK_ARG(signal_pinned && idx >= 0);
+  hipLaunchKernelGGL(set_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, signal_pinned,
+                     idx, value);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v,
+                               const void* rows, int idx_is_64, const uint8_t* mask,
+                               int64_t n_rows, int cols, const float* col_lr, float beta1,
+                               float beta2, float eps, int step, int bias_correction,
+                               float grad_scale, int zero_grad) {
+  CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && step >= 1);
+  if (n_rows == 0) return 0;
+  CLMGS_CHECK_ARG(p && g && m && v && col_lr);
+  float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+  if (bias_correction) {
+    inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  }
+  const int grid = min(ceil_div(n_rows * cols, 256), 256 * 8);
+  if (idx_is_64)
+    hipLaunchKernelGGL(adam_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                       g, m, v, rows, mask, n_rows, cols, col_lr, beta1, beta2, eps, inv_bc1,
+                       inv_sqrt_bc2, grad_scale, zero_grad);
+  else
+    hipLaunchKernelGGL(adam_rows_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                       g, m, v, rows, mask, n_rows, cols, col_lr, beta1, beta2, eps, inv_bc1,
+                       inv_sqrt_bc2, grad_scale, zero_grad);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_densify_stats(void* stream, int64_t n, const int64_t* filter,
+                                   const float* v_means2d, const int32_t* radii,
+                                   int only_visible, float half_w, float half_h,
+                                   float* max_radii2D, float* xyz_gradient_accum,
+                                   float* denom) {
+  CLMGS_CHECK_ARG(n >= 0);
+  if (n == 0) return 0;
+  CLMGS_CHECK_ARG(v_means2d && radii && max_radii2D && xyz_gradient_accum && denom);
+  const int grid = min(ceil_div(n, 256), 256 * 8);
+  hipLaunchKernelGGL(densify_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, filter,
+                     v_means2d, radii, only_visible, half_w, half_h, max_radii2D,
+                     xyz_gradient_accum, denom);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}

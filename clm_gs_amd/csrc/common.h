@@ -1,0 +1,85 @@
+// Shared helpers for the gfx950 kernels of libclmgs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/clmgs.h"
+
+namespace clmgs {
+
+void set_error(const char* fmt, ...);
+
+#define CLMGS_CHECK_ARG(cond)                                                       \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      clmgs::set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond);   \
+      return CLMGS_EINVAL;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define CLMGS_HIP(expr)                                                             \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      clmgs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                \
+                       hipGetErrorString(_e));                                      \
+      return (int)_e;                                                               \
+    }                                                                               \
+  } while (0)
+
+#define CLMGS_LAUNCH_CHECK() CLMGS_HIP(hipGetLastError())
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed,
+// speed only).  Remap so each XCD's L2 sees one contiguous range of work items.
+// Bijective for any n (MI355X guide, "XCD swizzle must be bijective").
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+  const unsigned X = 8;
+  unsigned xcd = b % X, slot = b / X;
+  unsigned q = n / X, r = n % X;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+// ------------------------------------------------------------- wave64 sum
+// DPP butterfly inside rows of 16, then row broadcasts (gfx9 DPP row_bcast).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int iv = __float_as_int(v);
+  int r = __builtin_amdgcn_update_dpp(0, iv, CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(r);
+}
+
+// Every lane ends up with ... only lane 63 is guaranteed to hold the full sum.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111>(v);  // row_shr:1
+  v = dpp_add<0x112>(v);  // row_shr:2
+  v = dpp_add<0x114>(v);  // row_shr:4
+  v = dpp_add<0x118>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  {
+    int iv = __float_as_int(v);
+    int r = __builtin_amdgcn_update_dpp(0, iv, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+    v += __int_as_float(r);
+  }
+  {
+    int iv = __float_as_int(v);
+    int r = __builtin_amdgcn_update_dpp(0, iv, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+    v += __int_as_float(r);
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = wave_sum_to_lane63(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace clmgs

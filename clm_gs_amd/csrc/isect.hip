@@ -1,0 +1,184 @@
+// Tile binning: per-Gaussian tile counts, (tile | depth) keys, stable radix sort,
+// per-tile start offsets (gfx950).  Replaces gsplat.isect_tiles and
+// gsplat.isect_offset_encode (strategies/base_engine.py:175-186,
+// strategies/no_offload/engine.py:75-84, strategies/clm_offload/engine.py:89-100).
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace clmgs {
+
+struct TileBox { int x0, y0, x1, y1; };
+
+__device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, float tile_size,
+                                            int tile_w, int tile_h) {
+  const float tr = radius / tile_size, tx = mx / tile_size, ty = my / tile_size;
+  TileBox b;
+  b.x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tile_w);
+  b.y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)tile_h);
+  b.x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tile_w);
+  b.y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)tile_h);
+  return b;
+}
+
+__global__ void __launch_bounds__(256)
+isect_count_kernel(int64_t CN, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+                   float tile_size, int tile_w, int tile_h, int32_t* __restrict__ tiles_per_gauss,
+                   int64_t* __restrict__ cum) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < CN;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int cnt = 0;
+    const int r = radii[i];
+    if (r > 0) {
+      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * i);
+      const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+      cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
+    }
+    tiles_per_gauss[i] = cnt;
+    cum[i] = cnt;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+isect_emit_kernel(int64_t CN, int N, const float* __restrict__ means2d,
+                  const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                  const int64_t* __restrict__ cum, float tile_size, int tile_w, int tile_h,
+                  int tile_bits, int64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < CN;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = radii[i];
+    if (r <= 0) continue;
+    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * i);
+    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+    int64_t cur = (i == 0) ? 0 : cum[i - 1];
+    const int64_t cam = i / N;
+    const int64_t depth_bits = (int64_t)(uint32_t)__float_as_int(depths[i]);
+    const int64_t cam_part = cam << tile_bits;
+    for (int ty = b.y0; ty < b.y1; ++ty) {
+      for (int tx = b.x0; tx < b.x1; ++tx) {
+        const int64_t tile = (int64_t)ty * tile_w + tx;
+        keys[cur] = ((cam_part | tile) << 32) | depth_bits;
+        vals[cur] = (int32_t)i;
+        ++cur;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+isect_offsets_kernel(int64_t n_isects, const int64_t* __restrict__ isect_ids, int n_tiles_total,
+                     int n_tiles, int tile_bits, int32_t* __restrict__ offsets) {
+  const int64_t mask = ((int64_t)1 << tile_bits) - 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_isects;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = isect_ids[i] >> 32;
+    const int cur = (int)((k >> tile_bits) * n_tiles + (k & mask));
+    if (i == 0) {
+      for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+    } else {
+      const int64_t kp = isect_ids[i - 1] >> 32;
+      const int prev = (int)((kp >> tile_bits) * n_tiles + (kp & mask));
+      for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+    }
+    if (i == n_isects - 1) {
+      for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
+    }
+  }
+}
+
+static inline int ilog2_floor(unsigned v) { int r = 0; while (v >>= 1) ++r; return r; }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace clmgs
+
+using namespace clmgs;
+
+extern "C" size_t clmgs_isect_count_temp_bytes(int CN) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (int64_t*)nullptr, (int64_t*)nullptr, CN);
+  return align_up(bytes, 256) + 256;
+}
+
+extern "C" int clmgs_isect_count(void* stream, int C, int N, const float* means2d,
+                                 const int32_t* radii, int tile_size, int tile_width,
+                                 int tile_height, int32_t* tiles_per_gauss, int64_t* cum,
+                                 void* temp, size_t temp_bytes) {
+  CLMGS_CHECK_ARG(C >= 1 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
+  const int64_t CN = (int64_t)C * N;
+  if (CN == 0) return 0;
+  CLMGS_CHECK_ARG(CN < ((int64_t)1 << 31));
+  CLMGS_CHECK_ARG(means2d && radii && tiles_per_gauss && cum && temp);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(isect_count_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256), 0, s,
+                     CN, means2d, radii, (float)tile_size, tile_width, tile_height,
+                     tiles_per_gauss, cum);
+  CLMGS_LAUNCH_CHECK();
+  size_t need = 0;
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, cum, cum, (int)CN, s);
+  CLMGS_CHECK_ARG(temp_bytes >= need);
+  CLMGS_HIP(hipcub::DeviceScan::InclusiveSum(temp, need, cum, cum, (int)CN, s));
+  return 0;
+}
+
+static size_t sort_scratch_bytes(int64_t n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (int64_t*)nullptr, (int64_t*)nullptr,
+                                     (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)n, 0, 64);
+  return bytes;
+}
+
+extern "C" size_t clmgs_isect_sort_temp_bytes(int64_t n_isects) {
+  if (n_isects <= 0) return 256;
+  return align_up((size_t)n_isects * 8, 256) + align_up((size_t)n_isects * 4, 256) +
+         align_up(sort_scratch_bytes(n_isects), 256) + 256;
+}
+
+extern "C" int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isects,
+                                     const float* means2d, const int32_t* radii,
+                                     const float* depths, const int64_t* cum, int tile_size,
+                                     int tile_width, int tile_height, int64_t* isect_ids,
+                                     int32_t* flatten_ids, void* temp, size_t temp_bytes) {
+  CLMGS_CHECK_ARG(C >= 1 && N >= 0 && n_isects >= 0);
+  if (n_isects == 0) return 0;
+  CLMGS_CHECK_ARG(n_isects < ((int64_t)1 << 31));
+  CLMGS_CHECK_ARG(means2d && radii && depths && cum && isect_ids && flatten_ids && temp);
+  CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect_sort_temp_bytes(n_isects));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t CN = (int64_t)C * N;
+  const int n_tiles = tile_width * tile_height;
+  const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
+  const int cam_bits = ilog2_floor((unsigned)C) + 1;
+  char* base = (char*)temp;
+  int64_t* keys_in = (int64_t*)base;
+  base += align_up((size_t)n_isects * 8, 256);
+  int32_t* vals_in = (int32_t*)base;
+  base += align_up((size_t)n_isects * 4, 256);
+  size_t scratch = sort_scratch_bytes(n_isects);
+  hipLaunchKernelGGL(isect_emit_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256), 0, s,
+                     CN, N, means2d, radii, depths, cum, (float)tile_size, tile_width,
+                     tile_height, tile_bits, keys_in, vals_in);
+  CLMGS_LAUNCH_CHECK();
+  CLMGS_HIP(hipcub::DeviceRadixSort::SortPairs(base, scratch, keys_in, isect_ids, vals_in,
+                                               flatten_ids, (unsigned)n_isects, 0,
+                                               32 + tile_bits + cam_bits, s));
+  return 0;
+}
+
+extern "C" int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids,
+                                   int C, int tile_width, int tile_height, int32_t* offsets) {
+  CLMGS_CHECK_ARG(C >= 1 && tile_width > 0 && tile_height > 0 && offsets && n_isects >= 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int n_tiles = tile_width * tile_height;
+  if (n_isects == 0) {
+    CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)C * n_tiles, s));
+    return 0;
+  }
+  CLMGS_CHECK_ARG(isect_ids);
+  const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
+  hipLaunchKernelGGL(isect_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)),
+                     dim3(256), 0, s, n_isects, isect_ids, C * n_tiles, n_tiles, tile_bits,
+                     offsets);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,341 @@
+// Per-tile front-to-back alpha blending and its VJP (gfx950).
+// Replaces gsplat.rasterize_to_pixels forward + autograd backward
+// (strategies/base_engine.py:192-203, strategies/no_offload/engine.py:86-97,
+// strategies/clm_offload/engine.py:106-117; arithmetic: SURVEY.md A5/A6).
+//
+// CDNA4 mapping -- NOT the 16x16-threads-per-tile CUDA shape:
+//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels
+//     (column lane&15, rows (lane>>4) + 4k).  A tile's Gaussian record is read
+//     from LDS once per wave and reused for 4 pixels per lane, so LDS traffic per
+//     pixel-Gaussian pair is 1/4 of a thread-per-pixel kernel, there is no
+//     multi-wave barrier, and the 4 independent pixels give the exp/fma chain ILP;
+//   * the tile's depth-sorted list is staged 64 records at a time: lane l gathers
+//     record l (id -> mean, conic, opacity, colour) and parks it in LDS;
+//   * backward: each lane first sums its 4 pixels' contributions, then one DPP
+//     wave reduction per Gaussian (row_shr + row_bcast) and ONE set of float
+//     atomics per (Gaussian, tile), issued 64 Gaussians at a time by 64 lanes;
+//   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous
+//     stripe of tiles, so neighbouring tiles' shared Gaussians hit in L2.
+#include "common.h"
+#include "gs_math.h"
+
+namespace clmgs {
+
+constexpr int TILE = 16;
+constexpr int PPL = 4;        // pixels per lane
+constexpr float ALPHA_MIN = 1.f / 255.f;
+constexpr float T_EPS = 1e-4f;
+
+struct TileLds {
+  float4 a[64];   // x, y, opacity, conic.a
+  float4 b[64];   // conic.b, conic.c, r, g
+  float c[64];    // b
+  int id[64];     // Gaussian id (cam*N + g)
+};
+
+__device__ __forceinline__ void tile_range(const int32_t* __restrict__ offsets, int tile,
+                                           int n_tiles_total, int64_t n_isects, int& s, int& e) {
+  s = offsets[tile];
+  e = (tile == n_tiles_total - 1) ? (int)n_isects : offsets[tile + 1];
+}
+
+__global__ void __launch_bounds__(64)
+rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ means2d,
+                     const float* __restrict__ conics, const float* __restrict__ colors,
+                     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+                     int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
+                     const int32_t* __restrict__ flatten_ids, float* __restrict__ render_colors,
+                     float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+  __shared__ TileLds sm;
+  const int n_tiles = tile_w * tile_h;
+  const int n_tiles_total = C * n_tiles;
+  const int tile = (int)xcd_remap(blockIdx.x, (unsigned)n_tiles_total);
+  const int cam = tile / n_tiles;
+  const int t_in = tile - cam * n_tiles;
+  const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int j = tx * TILE + (lane & 15);
+  const int i0 = ty * TILE + (lane >> 4);
+  const float px = (float)j + 0.5f;
+
+  float T[PPL], cr[PPL], cg[PPL], cb[PPL], py[PPL];
+  int last[PPL];
+  bool alive[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = i0 + 4 * k;
+    py[k] = (float)i + 0.5f;
+    T[k] = 1.f; cr[k] = cg[k] = cb[k] = 0.f; last[k] = 0;
+    alive[k] = (i < H) && (j < W);
+  }
+
+  int rs, re;
+  tile_range(offsets, tile, n_tiles_total, n_isects, rs, re);
+
+  for (int bs = rs; bs < re; bs += 64) {
+    bool any_alive = false;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) any_alive |= alive[k];
+    if (!__any(any_alive)) break;
+    __syncthreads();
+    const int idx = bs + lane;
+    if (idx < re) {
+      const int g = flatten_ids[idx];
+      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+      const float* cn = conics + 3 * (size_t)g;
+      const float* cl = colors + 3 * (size_t)g;
+      sm.a[lane] = make_float4(m.x, m.y, opacities[g], cn[0]);
+      sm.b[lane] = make_float4(cn[1], cn[2], cl[0], cl[1]);
+      sm.c[lane] = cl[2];
+    }
+    __syncthreads();
+    const int bn = min(64, re - bs);
+    for (int t = 0; t < bn; ++t) {
+      const float4 A = sm.a[t];
+      const float4 B = sm.b[t];
+      float alpha[PPL];
+      bool valid[PPL];
+      bool any_valid = false;
+      const float dx = A.x - px;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float dy = A.y - py[k];
+        const float sigma = 0.5f * (A.w * dx * dx + B.y * dy * dy) + B.x * dx * dy;
+        alpha[k] = fminf(0.999f, A.z * __expf(-sigma));
+        valid[k] = alive[k] && (sigma >= 0.f) && (alpha[k] >= ALPHA_MIN);
+        any_valid |= valid[k];
+      }
+      if (!__any(any_valid)) continue;
+      const float blue = sm.c[t];
+      bool still = false;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float next_T = T[k] * (1.f - alpha[k]);
+        const bool term = valid[k] && (next_T <= T_EPS);
+        const bool acc = valid[k] && !term;
+        const float vis = acc ? alpha[k] * T[k] : 0.f;
+        cr[k] += B.z * vis; cg[k] += B.w * vis; cb[k] += blue * vis;
+        T[k] = acc ? next_T : T[k];
+        last[k] = acc ? (bs + t) : last[k];
+        alive[k] = alive[k] && !term;
+        still |= alive[k];
+      }
+      if (!__any(still)) break;
+    }
+  }
+
+  float bgr = 0.f, bgg = 0.f, bgb = 0.f;
+  if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = i0 + 4 * k;
+    if (i < H && j < W) {
+      const size_t pix = ((size_t)cam * H + i) * W + j;
+      render_colors[3 * pix] = cr[k] + T[k] * bgr;
+      render_colors[3 * pix + 1] = cg[k] + T[k] * bgg;
+      render_colors[3 * pix + 2] = cb[k] + T[k] * bgb;
+      render_alphas[pix] = 1.f - T[k];
+      last_ids[pix] = last[k];
+    }
+  }
+}
+
+struct TileLdsBwd {
+  float4 a[64];
+  float4 b[64];
+  float c[64];
+  int id[64];
+  float acc[64][9];  // reduced per-Gaussian gradient of this tile
+};
+
+__global__ void __launch_bounds__(64)
+rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ means2d,
+                     const float* __restrict__ conics, const float* __restrict__ colors,
+                     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+                     int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
+                     const int32_t* __restrict__ flatten_ids,
+                     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+                     const float* __restrict__ v_render_colors,
+                     const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d,
+                     float* __restrict__ v_conics, float* __restrict__ v_colors,
+                     float* __restrict__ v_opacities) {
+  __shared__ TileLdsBwd sm;
+  const int n_tiles = tile_w * tile_h;
+  const int n_tiles_total = C * n_tiles;
+  const int tile = (int)xcd_remap(blockIdx.x, (unsigned)n_tiles_total);
+  const int cam = tile / n_tiles;
+  const int t_in = tile - cam * n_tiles;
+  const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
+  const int lane = threadIdx.x;
+  const int j = tx * TILE + (lane & 15);
+  const int i0 = ty * TILE + (lane >> 4);
+  const float px = (float)j + 0.5f;
+
+  int rs, re;
+  tile_range(offsets, tile, n_tiles_total, n_isects, rs, re);
+  if (re <= rs) return;
+
+  float T[PPL], Tf[PPL], py[PPL], vr[PPL], vg[PPL], vb[PPL], va[PPL];
+  float br[PPL], bg_[PPL], bb[PPL];  // running sum of colour behind the current Gaussian
+  int bin[PPL];
+  bool inside[PPL];
+  int max_bin = -1;
+  float bgr = 0.f, bgg = 0.f, bgb = 0.f;
+  if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = i0 + 4 * k;
+    py[k] = (float)i + 0.5f;
+    inside[k] = (i < H) && (j < W);
+    br[k] = bg_[k] = bb[k] = 0.f;
+    if (inside[k]) {
+      const size_t pix = ((size_t)cam * H + i) * W + j;
+      Tf[k] = 1.f - render_alphas[pix];
+      bin[k] = last_ids[pix];
+      vr[k] = v_render_colors[3 * pix]; vg[k] = v_render_colors[3 * pix + 1]; vb[k] = v_render_colors[3 * pix + 2];
+      va[k] = v_render_alphas ? v_render_alphas[pix] : 0.f;
+      // d(out)/d(T_final) through the background term folds into the alpha cotangent
+      va[k] -= (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]);
+      max_bin = max(max_bin, bin[k]);
+    } else {
+      Tf[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = va[k] = 0.f;
+    }
+    T[k] = Tf[k];
+  }
+  max_bin = wave_max_i32(max_bin);
+  const int hi = min(re - 1, max_bin);  // nothing behind the deepest contributor matters
+
+  for (int bh = hi; bh >= rs; bh -= 64) {
+    __syncthreads();
+    const int idx = bh - lane;
+    if (idx >= rs) {
+      const int g = flatten_ids[idx];
+      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+      const float* cn = conics + 3 * (size_t)g;
+      const float* cl = colors + 3 * (size_t)g;
+      sm.a[lane] = make_float4(m.x, m.y, opacities[g], cn[0]);
+      sm.b[lane] = make_float4(cn[1], cn[2], cl[0], cl[1]);
+      sm.c[lane] = cl[2];
+      sm.id[lane] = g;
+    }
+    __syncthreads();
+    const int bn = min(64, bh - rs + 1);
+    unsigned long long touched = 0ull;
+    for (int t = 0; t < bn; ++t) {
+      const int gi = bh - t;
+      const float4 A = sm.a[t];
+      const float4 B = sm.b[t];
+      const float dx = A.x - px;
+      float alpha[PPL], gex[PPL], dy[PPL];
+      bool valid[PPL];
+      bool any_valid = false;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        dy[k] = A.y - py[k];
+        const float sigma = 0.5f * (A.w * dx * dx + B.y * dy[k] * dy[k]) + B.x * dx * dy[k];
+        gex[k] = __expf(-sigma);
+        alpha[k] = fminf(0.999f, A.z * gex[k]);
+        valid[k] = inside[k] && (gi <= bin[k]) && (sigma >= 0.f) && (alpha[k] >= ALPHA_MIN);
+        any_valid |= valid[k];
+      }
+      if (!__any(any_valid)) continue;
+      const float blue = sm.c[t];
+      float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_x = 0.f,
+            g_y = 0.f, g_o = 0.f;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        if (valid[k]) {
+          const float ra = 1.f / (1.f - alpha[k]);
+          T[k] *= ra;
+          const float fac = alpha[k] * T[k];
+          g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
+          float v_alpha = (B.z * T[k] - br[k] * ra) * vr[k] + (B.w * T[k] - bg_[k] * ra) * vg[k] +
+                          (blue * T[k] - bb[k] * ra) * vb[k];
+          v_alpha += Tf[k] * ra * va[k];
+          if (A.z * gex[k] <= 0.999f) {
+            const float v_sigma = -A.z * gex[k] * v_alpha;
+            g_ca += 0.5f * v_sigma * dx * dx;
+            g_cb += v_sigma * dx * dy[k];
+            g_cc += 0.5f * v_sigma * dy[k] * dy[k];
+            g_x += v_sigma * (A.w * dx + B.x * dy[k]);
+            g_y += v_sigma * (B.x * dx + B.y * dy[k]);
+            g_o += gex[k] * v_alpha;
+          }
+          br[k] += B.z * fac; bg_[k] += B.w * fac; bb[k] += blue * fac;
+        }
+      }
+      g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+      g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+      g_x = wave_sum_to_lane63(g_x); g_y = wave_sum_to_lane63(g_y); g_o = wave_sum_to_lane63(g_o);
+      if (lane == 63) {
+        float* a = sm.acc[t];
+        a[0] = g_x; a[1] = g_y; a[2] = g_ca; a[3] = g_cb; a[4] = g_cc;
+        a[5] = g_r; a[6] = g_g; a[7] = g_b; a[8] = g_o;
+      }
+      touched |= (1ull << t);
+    }
+    __syncthreads();
+    if ((touched >> lane) & 1ull) {
+      const size_t g = (size_t)sm.id[lane];
+      const float* a = sm.acc[lane];
+      atomicAdd(v_means2d + 2 * g, a[0]);
+      atomicAdd(v_means2d + 2 * g + 1, a[1]);
+      atomicAdd(v_conics + 3 * g, a[2]);
+      atomicAdd(v_conics + 3 * g + 1, a[3]);
+      atomicAdd(v_conics + 3 * g + 2, a[4]);
+      atomicAdd(v_colors + 3 * g, a[5]);
+      atomicAdd(v_colors + 3 * g + 1, a[6]);
+      atomicAdd(v_colors + 3 * g + 2, a[7]);
+      atomicAdd(v_opacities + g, a[8]);
+    }
+  }
+}
+
+}  // namespace clmgs
+
+using namespace clmgs;
+
+extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
+                                   const float* means2d, const float* conics, const float* colors,
+                                   const float* opacities, const float* backgrounds, int width,
+                                   int height, int tile_size, int tile_width, int tile_height,
+                                   const int32_t* offsets, const int32_t* flatten_ids,
+                                   float* render_colors, float* render_alphas, int32_t* last_ids) {
+  CLMGS_CHECK_ARG(tile_size == TILE);
+  CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
+                  tile_height * TILE >= height);
+  CLMGS_CHECK_ARG(offsets && render_colors && render_alphas && last_ids);
+  CLMGS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids));
+  const int n_blocks = C * tile_width * tile_height;
+  hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, C, N,
+                     n_isects, means2d, conics, colors, opacities, backgrounds, width, height,
+                     tile_width, tile_height, offsets, flatten_ids, render_colors, render_alphas,
+                     last_ids);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
+                                   const float* means2d, const float* conics, const float* colors,
+                                   const float* opacities, const float* backgrounds, int width,
+                                   int height, int tile_size, int tile_width, int tile_height,
+                                   const int32_t* offsets, const int32_t* flatten_ids,
+                                   const float* render_alphas, const int32_t* last_ids,
+                                   const float* v_render_colors, const float* v_render_alphas,
+                                   float* v_means2d, float* v_conics, float* v_colors,
+                                   float* v_opacities) {
+  CLMGS_CHECK_ARG(tile_size == TILE);
+  CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
+                  tile_height * TILE >= height);
+  if (n_isects == 0) return 0;
+  CLMGS_CHECK_ARG(means2d && conics && colors && opacities && offsets && flatten_ids &&
+                  render_alphas && last_ids && v_render_colors && v_means2d && v_conics &&
+                  v_colors && v_opacities);
+  const int n_blocks = C * tile_width * tile_height;
+  hipLaunchKernelGGL(rasterize_bwd_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, C, N,
+                     n_isects, means2d, conics, colors, opacities, backgrounds, width, height,
+                     tile_width, tile_height, offsets, flatten_ids, render_alphas, last_ids,
+                     v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}

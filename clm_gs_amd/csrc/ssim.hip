@@ -1,0 +1,178 @@
+// Fused SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward + VJP wrt img1.
+// Replaces clm_kernels.fused_ssim (strategies/base_engine.py:5,93); definition pinned
+// by utils/loss_utils.py:26-85.
+//
+// One 256-thread block produces a 16x16 output tile of one channel: the 26x26
+// halo of both images is staged in LDS once, the window is applied separably
+// (horizontal pass into LDS, vertical pass out of it).
+#include "common.h"
+
+namespace clmgs {
+
+constexpr int ST = 16;          // output tile edge
+constexpr int SR = 5;           // window radius
+constexpr int SH_ = ST + 2 * SR;  // halo edge = 26
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+
+__constant__ float c_win[11] = {
+    0.0010283801f, 0.0075987582f, 0.0360007721f, 0.1093606895f, 0.2130055377f, 0.2660117249f,
+    0.2130055377f, 0.1093606895f, 0.0360007721f, 0.0075987582f, 0.0010283801f};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
+                float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12) {
+  __shared__ float sx[SH_][SH_ + 1];
+  __shared__ float sy[SH_][SH_ + 1];
+  __shared__ float hz[5][SH_][ST + 1];
+  __shared__ float red[4];
+  const int plane = blockIdx.z;  // b*CH + ch
+  const size_t base = (size_t)plane * H * W;
+  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < SH_ * SH_; i += 256) {
+    const int r = i / SH_, c = i - r * SH_;
+    const int y = y0 + r - SR, x = x0 + c - SR;
+    float a = 0.f, b = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      a = img1[base + (size_t)y * W + x];
+      b = img2[base + (size_t)y * W + x];
+    }
+    sx[r][c] = a; sy[r][c] = b;
+  }
+  __syncthreads();
+  for (int i = tid; i < SH_ * ST; i += 256) {
+    const int r = i / ST, c = i - r * ST;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = c_win[k], a = sx[r][c + k], b = sy[r][c + k];
+      s0 += w * a; s1 += w * b; s2 += w * a * a; s3 += w * b * b; s4 += w * a * b;
+    }
+    hz[0][r][c] = s0; hz[1][r][c] = s1; hz[2][r][c] = s2; hz[3][r][c] = s3; hz[4][r][c] = s4;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = c_win[k];
+    mu1 += w * hz[0][ty + k][tx]; mu2 += w * hz[1][ty + k][tx];
+    e11 += w * hz[2][ty + k][tx]; e22 += w * hz[3][ty + k][tx]; e12 += w * hz[4][ty + k][tx];
+  }
+  const int y = y0 + ty, x = x0 + tx;
+  float val = 0.f;
+  if (y < H && x < W) {
+    const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = e11 - mu1sq, s2 = e22 - mu2sq, s12 = e12 - mu12;
+    const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
+    const float D = mu1sq + mu2sq + SSIM_C1, E = s1 + s2 + SSIM_C2;
+    const float iDE = 1.f / (D * E);
+    val = A * B * iDE;
+    if (dm_dmu1) {
+      const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 / D;  // at fixed sigma
+      const float d_s1 = -val / E;
+      const float d_s12 = 2.f * A * iDE;
+      const size_t o = base + (size_t)y * W + x;
+      // fold d(sigma)/d(mu1) in: sigma1_sq = E[xx] - mu1^2, sigma12 = E[xy] - mu1 mu2
+      dm_dmu1[o] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+      dm_dsigma1_sq[o] = d_s1;
+      dm_dsigma12[o] = d_s12;
+    }
+  }
+  const float tot = block_sum_256(val, red);
+  if (tid == 0) atomicAdd(ssim_sum, tot);
+}
+
+__global__ void __launch_bounds__(256)
+ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                const float* __restrict__ v_mean, float inv_numel,
+                const float* __restrict__ dm_dmu1,
+                const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
+                float* __restrict__ v_img1) {
+  __shared__ float sm[3][SH_][SH_ + 1];
+  __shared__ float hz[3][SH_][ST + 1];
+  const int plane = blockIdx.z;
+  const size_t base = (size_t)plane * H * W;
+  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+  const int tid = threadIdx.x;
+  const float scale = v_mean[0] * inv_numel;
+  for (int i = tid; i < SH_ * SH_; i += 256) {
+    const int r = i / SH_, c = i - r * SH_;
+    const int y = y0 + r - SR, x = x0 + c - SR;
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const size_t o = base + (size_t)y * W + x;
+      a = dm_dmu1[o]; b = dm_dsigma1_sq[o]; d = dm_dsigma12[o];
+    }
+    sm[0][r][c] = a; sm[1][r][c] = b; sm[2][r][c] = d;
+  }
+  __syncthreads();
+  for (int i = tid; i < SH_ * ST; i += 256) {
+    const int r = i / ST, c = i - r * ST;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = c_win[k];
+      s0 += w * sm[0][r][c + k]; s1 += w * sm[1][r][c + k]; s2 += w * sm[2][r][c + k];
+    }
+    hz[0][r][c] = s0; hz[1][r][c] = s1; hz[2][r][c] = s2;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = c_win[k];
+    g0 += w * hz[0][ty + k][tx]; g1 += w * hz[1][ty + k][tx]; g2 += w * hz[2][ty + k][tx];
+  }
+  const int y = y0 + ty, x = x0 + tx;
+  if (y < H && x < W) {
+    const size_t o = base + (size_t)y * W + x;
+    v_img1[o] = scale * (g0 + 2.f * img1[o] * g1 + img2[o] * g2);
+  }
+}
+
+}  // namespace clmgs
+
+using namespace clmgs;
+
+extern "C" int clmgs_ssim_fwd(void* stream, int B, int CH, int H, int W, const float* img1,
+                              const float* img2, float* ssim_sum, float* dm_dmu1,
+                              float* dm_dsigma1_sq, float* dm_dsigma12) {
+  CLMGS_CHECK_ARG(B >= 1 && CH >= 1 && H >= 1 && W >= 1 && img1 && img2 && ssim_sum);
+  CLMGS_CHECK_ARG((dm_dmu1 && dm_dsigma1_sq && dm_dsigma12) ||
+                  (!dm_dmu1 && !dm_dsigma1_sq && !dm_dsigma12));
+  CLMGS_CHECK_ARG((int64_t)B * CH <= 65535);
+  dim3 grid(ceil_div(W, ST), ceil_div(H, ST), B * CH);
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2,
+                     ssim_sum, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_ssim_bwd(void* stream, int B, int CH, int H, int W, const float* img1,
+                              const float* img2, const float* v_mean, float inv_numel,
+                              const float* dm_dmu1,
+                              const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                              float* v_img1) {
+  CLMGS_CHECK_ARG(B >= 1 && CH >= 1 && H >= 1 && W >= 1 && img1 && img2 && v_mean && dm_dmu1 &&
+                  dm_dsigma1_sq && dm_dsigma12 && v_img1);
+  CLMGS_CHECK_ARG((int64_t)B * CH <= 65535);
+  dim3 grid(ceil_div(W, ST), ceil_div(H, ST), B * CH);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2,
+                     v_mean, inv_numel, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, v_img1);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}

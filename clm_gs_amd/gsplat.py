@@ -1,0 +1,256 @@
+"""The five gsplat operators the CLM-GS engines import
+(strategies/base_engine.py:6-12, strategies/no_offload/engine.py:4-10,
+strategies/clm_offload/engine.py:7-13), with the same names, argument meaning
+and return shapes, served by the gfx950 kernels of libclmgs_hip.so.
+
+Differentiable operators are ``torch.autograd.Function``s whose forward and
+backward call the C ABI; there is no eager fallback.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, stream
+
+F32, I32, I64 = torch.float32, torch.int32, torch.int64
+
+
+# --------------------------------------------------------------------- projection
+class _Projection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip):
+        L = _lib.lib()
+        means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+        viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty((C, N), dtype=I32, device=dev)
+        means2d = torch.empty((C, N, 2), dtype=F32, device=dev)
+        depths = torch.empty((C, N), dtype=F32, device=dev)
+        conics = torch.empty((C, N, 3), dtype=F32, device=dev)
+        check(L.clmgs_projection_fwd(
+            stream(), C, N, dptr(means, F32), dptr(quats, F32), dptr(scales, F32),
+            dptr(viewmats, F32), dptr(Ks, F32), int(width), int(height), float(eps2d),
+            float(near_plane), float(far_plane), float(radius_clip), dptr(radii), dptr(means2d),
+            dptr(depths), dptr(conics)))
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
+        ctx.cfg = (int(width), int(height), float(eps2d))
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics):
+        L = _lib.lib()
+        means, quats, scales, viewmats, Ks, radii = ctx.saved_tensors
+        width, height, eps2d = ctx.cfg
+        C, N = radii.shape
+        dev = means.device
+        if v_means2d is None:
+            v_means2d = torch.zeros((C, N, 2), dtype=F32, device=dev)
+        if v_conics is None:
+            v_conics = torch.zeros((C, N, 3), dtype=F32, device=dev)
+        v_means2d, v_conics = v_means2d.contiguous(), v_conics.contiguous()
+        v_depths = v_depths.contiguous() if v_depths is not None else None
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        check(L.clmgs_projection_bwd(
+            stream(), C, N, dptr(means), dptr(quats), dptr(scales), dptr(viewmats), dptr(Ks),
+            width, height, eps2d, dptr(radii), dptr(v_means2d, F32), dptr(v_depths, F32, True),
+            dptr(v_conics, F32), dptr(v_means), dptr(v_quats), dptr(v_scales)))
+        return v_means, v_quats, v_scales, None, None, None, None, None, None, None, None
+
+
+def fully_fused_projection(means, covars, quats, scales, viewmats, Ks, width, height, eps2d=0.3,
+                           near_plane=0.01, far_plane=1e10, radius_clip=0.0, packed=False,
+                           sparse_grad=False, calc_compensations=False):
+    """EWA projection of N Gaussians into C cameras.
+
+    Unpacked -> (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], None).
+    Packed (no grad; strategies/base_engine.py:36-47 uses it under no_grad only)
+    -> (camera_ids, gaussian_ids, radii, means2d, depths, conics, None), ordered
+    by (camera, gaussian).
+    """
+    if covars is not None:
+        raise NotImplementedError("the CLM-GS engines always pass covars=None")
+    if calc_compensations:
+        raise NotImplementedError("compensations are never requested by the CLM-GS engines")
+    if not packed:
+        radii, means2d, depths, conics = _Projection.apply(
+            means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+            radius_clip)
+        return radii, means2d, depths, conics, None
+    with torch.no_grad():
+        radii, means2d, depths, conics = _Projection.apply(
+            means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+            radius_clip)
+        camera_ids, gaussian_ids = torch.nonzero(radii > 0, as_tuple=True)
+        return (camera_ids, gaussian_ids, radii[camera_ids, gaussian_ids],
+                means2d[camera_ids, gaussian_ids], depths[camera_ids, gaussian_ids],
+                conics[camera_ids, gaussian_ids], None)
+
+
+def visibility_radii(means, quats, scales, viewmats, Ks, width, height, eps2d=0.3,
+                     near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+    """radii[C,N] only: the cull of fully_fused_projection without writing the 24 B of
+    per-pair outputs (what calculate_filters, strategies/base_engine.py:18-76, needs)."""
+    L = _lib.lib()
+    means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+    viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+    C, N = viewmats.shape[0], means.shape[0]
+    radii = torch.empty((C, N), dtype=I32, device=means.device)
+    check(L.clmgs_projection_fwd(
+        stream(), C, N, dptr(means, F32), dptr(quats, F32), dptr(scales, F32), dptr(viewmats, F32),
+        dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+        float(radius_clip), dptr(radii), None, None, None))
+    return radii
+
+
+# ------------------------------------------------------------ spherical harmonics
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, coeffs, masks):
+        L = _lib.lib()
+        lead = dirs.shape[:-1]
+        n = dirs.numel() // 3
+        assert coeffs.shape[-2:] == (16, 3) or coeffs.shape[-1] == 48, coeffs.shape
+        d2, c2 = dirs.contiguous(), coeffs.contiguous()
+        m2 = masks.contiguous().view(torch.uint8) if masks is not None else None
+        colors = torch.empty(lead + (3,), dtype=F32, device=dirs.device)
+        check(L.clmgs_sh_fwd(stream(), n, int(degree), dptr(d2, F32), dptr(c2, F32),
+                             dptr(m2, torch.uint8, True), dptr(colors)))
+        ctx.save_for_backward(d2, c2, m2)
+        ctx.degree = int(degree)
+        ctx.n = n
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        L = _lib.lib()
+        d2, c2, m2 = ctx.saved_tensors
+        v_colors = v_colors.contiguous()
+        v_coeffs = torch.empty_like(c2) if ctx.needs_input_grad[2] else None
+        v_dirs = torch.empty_like(d2) if ctx.needs_input_grad[1] else None
+        if v_coeffs is None:  # kernel always produces v_coeffs; give it scratch
+            v_coeffs_buf = torch.empty_like(c2)
+        else:
+            v_coeffs_buf = v_coeffs
+        check(L.clmgs_sh_bwd(stream(), ctx.n, ctx.degree, dptr(d2), dptr(c2),
+                             dptr(m2, torch.uint8, True), dptr(v_colors, F32), dptr(v_coeffs_buf),
+                             0, dptr(v_dirs, F32, True)))
+        return None, v_dirs, v_coeffs, None
+
+
+def spherical_harmonics(degrees_to_use, dirs, coeffs, masks=None):
+    """colors[...,3] from dirs[...,3] (normalised inside) and coeffs[...,16,3]; rows with
+    masks == False produce 0 and receive 0 gradient."""
+    return _SphericalHarmonics.apply(degrees_to_use, dirs, coeffs, masks)
+
+
+# ------------------------------------------------------------------- tile binning
+@torch.no_grad()
+def isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True,
+                packed=False, n_cameras=None, camera_ids=None, gaussian_ids=None):
+    """-> (tiles_per_gauss[C,N] i32, isect_ids[I] i64 sorted, flatten_ids[I] i32)."""
+    if packed or not sort:
+        raise NotImplementedError("the CLM-GS engines call isect_tiles(packed=False, sort=True)")
+    L = _lib.lib()
+    C, N = radii.shape
+    dev = radii.device
+    means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    tiles_per_gauss = torch.empty((C, N), dtype=I32, device=dev)
+    cum = torch.empty((C * N,), dtype=I64, device=dev)
+    if C * N == 0:
+        return tiles_per_gauss, torch.empty(0, dtype=I64, device=dev), torch.empty(0, dtype=I32, device=dev)
+    tb = L.clmgs_isect_count_temp_bytes(C * N)
+    temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    check(L.clmgs_isect_count(stream(), C, N, dptr(means2d, F32), dptr(radii, I32), int(tile_size),
+                              int(tile_width), int(tile_height), dptr(tiles_per_gauss), dptr(cum),
+                              dptr(temp), tb))
+    n_isects = int(cum[-1].item())  # data-dependent size: the one host sync of the front end
+    isect_ids = torch.empty((n_isects,), dtype=I64, device=dev)
+    flatten_ids = torch.empty((n_isects,), dtype=I32, device=dev)
+    if n_isects:
+        sb = L.clmgs_isect_sort_temp_bytes(n_isects)
+        temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
+        check(L.clmgs_isect_emit_sort(stream(), C, N, n_isects, dptr(means2d), dptr(radii),
+                                      dptr(depths, F32), dptr(cum), int(tile_size),
+                                      int(tile_width), int(tile_height), dptr(isect_ids),
+                                      dptr(flatten_ids), dptr(temp2), sb))
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids, n_cameras, tile_width, tile_height):
+    """offsets[C, tile_height, tile_width] i32 = first sorted index of each tile."""
+    L = _lib.lib()
+    offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=I32, device=isect_ids.device)
+    check(L.clmgs_isect_offsets(stream(), isect_ids.numel(), dptr(isect_ids.contiguous(), I64),
+                                int(n_cameras), int(tile_width), int(tile_height), dptr(offsets)))
+    return offsets
+
+
+# ---------------------------------------------------------------------- rasterize
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
+                isect_offsets, flatten_ids):
+        L = _lib.lib()
+        C, N = opacities.shape
+        dev = means2d.device
+        means2d, conics, colors, opacities = (t.contiguous() for t in (means2d, conics, colors, opacities))
+        bg = backgrounds.contiguous() if backgrounds is not None else None
+        offsets = isect_offsets.contiguous()
+        fids = flatten_ids.contiguous()
+        th, tw = offsets.shape[1:]
+        out = torch.empty((C, height, width, 3), dtype=F32, device=dev)
+        alphas = torch.empty((C, height, width, 1), dtype=F32, device=dev)
+        last_ids = torch.empty((C, height, width), dtype=I32, device=dev)
+        n_isects = fids.numel()
+        check(L.clmgs_rasterize_fwd(
+            stream(), C, N, n_isects, dptr(means2d, F32), dptr(conics, F32), dptr(colors, F32),
+            dptr(opacities, F32), dptr(bg, F32, True), int(width), int(height), int(tile_size), tw,
+            th, dptr(offsets, I32), dptr(fids, I32), dptr(out), dptr(alphas), dptr(last_ids)))
+        ctx.save_for_backward(means2d, conics, colors, opacities, bg, offsets, fids, alphas, last_ids)
+        ctx.cfg = (int(width), int(height), int(tile_size))
+        return out, alphas
+
+    @staticmethod
+    def backward(ctx, v_out, v_alphas):
+        L = _lib.lib()
+        means2d, conics, colors, opacities, bg, offsets, fids, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size = ctx.cfg
+        C, N = opacities.shape
+        th, tw = offsets.shape[1:]
+        v_out = v_out.contiguous()
+        v_alphas = v_alphas.contiguous() if v_alphas is not None else None
+        v_means2d = torch.zeros_like(means2d)
+        v_conics = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacities = torch.zeros_like(opacities)
+        check(L.clmgs_rasterize_bwd(
+            stream(), C, N, fids.numel(), dptr(means2d), dptr(conics), dptr(colors),
+            dptr(opacities), dptr(bg, F32, True), width, height, tile_size, tw, th, dptr(offsets),
+            dptr(fids), dptr(alphas), dptr(last_ids), dptr(v_out, F32), dptr(v_alphas, F32, True),
+            dptr(v_means2d), dptr(v_conics), dptr(v_colors), dptr(v_opacities)))
+        return v_means2d, v_conics, v_colors, v_opacities, None, None, None, None, None, None
+
+
+def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_height, tile_size,
+                        isect_offsets, flatten_ids, backgrounds=None, masks=None, packed=False,
+                        absgrad=False):
+    """-> (render_colors[C,H,W,3], render_alphas[C,H,W,1]).  backgrounds: None, [3] or [C,3]
+    (the reference passes both shapes: no_offload/engine.py:96 vs base_engine.py:189-191)."""
+    if packed or absgrad or masks is not None:
+        raise NotImplementedError("packed/absgrad/masks are not used by the CLM-GS engines")
+    if colors.shape[-1] != 3:
+        raise NotImplementedError("3 colour channels only")
+    C = opacities.shape[0]
+    if backgrounds is not None:
+        backgrounds = backgrounds.reshape(-1, 3).to(F32)
+        if backgrounds.shape[0] != C:
+            backgrounds = backgrounds.expand(C, 3)
+    return _Rasterize.apply(means2d, conics, colors, opacities, backgrounds, int(image_width),
+                            int(image_height), int(tile_size), isect_offsets, flatten_ids)

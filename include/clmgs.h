@@ -1,0 +1,177 @@
+/* clmgs.h -- C ABI of libclmgs_hip.so, the MI355X (gfx950) replacement for the
+ * native operators the CLM-GS engines call.
+ *
+ * Conventions:
+ *   - plain C types; every buffer is CALLER-ALLOCATED (device memory unless the
+ *     name says host/pinned) and passed as raw pointer + extents;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return 0 on success, non-zero = hipError_t or a CLMGS_E* code; the message
+ *     is available (thread-local) from clmgs_last_error();
+ *   - no allocation inside, except explicit temp-storage queries: calling a
+ *     `*_temp_bytes` function tells the caller how much scratch to pass;
+ *   - re-entrant from two host threads on different streams (render thread and
+ *     optimizer thread); nothing here holds the Python GIL.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (file:line under the reference tree).  The kernels themselves are absent
+ * from the reference (empty submodules), see oracle/gs_oracle.py's header.
+ */
+#ifndef CLMGS_H
+#define CLMGS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLMGS_EINVAL 10001
+#define CLMGS_ENOMEM 10002
+
+int clmgs_version(void);
+const char* clmgs_last_error(void);
+
+/* ---- gsplat.fully_fused_projection  (strategies/base_engine.py:36-47,139-151;
+ *      strategies/no_offload/engine.py:49-60; strategies/clm_offload/engine.py:51-63)
+ * means[N,3] quats[N,4] scales[N,3] viewmats[C,4,4] Ks[C,3,3] ->
+ * radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3].
+ * Any of means2d/depths/conics may be NULL (visibility-only pass). */
+int clmgs_projection_fwd(void* stream, int C, int N, const float* means, const float* quats,
+                         const float* scales, const float* viewmats, const float* Ks, int width,
+                         int height, float eps2d, float near_plane, float far_plane,
+                         float radius_clip, int32_t* radii, float* means2d, float* depths,
+                         float* conics);
+/* VJP of the above.  v_means[N,3], v_quats[N,4], v_scales[N,3] are overwritten
+ * with the sum over the C cameras. */
+int clmgs_projection_bwd(void* stream, int C, int N, const float* means, const float* quats,
+                         const float* scales, const float* viewmats, const float* Ks, int width,
+                         int height, float eps2d, const int32_t* radii, const float* v_means2d,
+                         const float* v_depths, const float* v_conics, float* v_means,
+                         float* v_quats, float* v_scales);
+
+/* ---- gsplat.spherical_harmonics  (base_engine.py:161-163; no_offload/engine.py:67-69;
+ *      clm_offload/engine.py:73-76)
+ * dirs[n,3] (un-normalised), coeffs[n,16,3], masks[n] u8 or NULL -> colors[n,3]. */
+int clmgs_sh_fwd(void* stream, int n, int degree, const float* dirs, const float* coeffs,
+                 const uint8_t* masks, float* colors);
+/* v_coeffs[n,16,3]: accumulate != 0 adds into the buffer (this is
+ * clm_kernels.spherical_harmonics_bwd_inplace, clm_offload/engine.py:709-716),
+ * else overwrites (rows beyond the active degree = 0).  v_dirs[n,3] may be NULL. */
+int clmgs_sh_bwd(void* stream, int n, int degree, const float* dirs, const float* coeffs,
+                 const uint8_t* masks, const float* v_colors, float* v_coeffs, int accumulate,
+                 float* v_dirs);
+
+/* ---- gsplat.isect_tiles / isect_offset_encode  (base_engine.py:175-186)
+ * Phase 1: tiles_per_gauss[C*N] i32 and its inclusive prefix sum cum[C*N] i64.
+ * The caller reads cum[C*N-1] (= I) and allocates isect buffers. */
+size_t clmgs_isect_count_temp_bytes(int CN);
+int clmgs_isect_count(void* stream, int C, int N, const float* means2d, const int32_t* radii,
+                      int tile_size, int tile_width, int tile_height, int32_t* tiles_per_gauss,
+                      int64_t* cum, void* temp, size_t temp_bytes);
+/* Phase 2: emit + sort.  isect_ids[I] i64 = (cam << tile_bits | tile) << 32 | depth bits,
+ * flatten_ids[I] i32 = cam*N + gaussian, both sorted by key (stable). */
+size_t clmgs_isect_sort_temp_bytes(int64_t n_isects);
+int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isects, const float* means2d,
+                          const int32_t* radii, const float* depths, const int64_t* cum,
+                          int tile_size, int tile_width, int tile_height, int64_t* isect_ids,
+                          int32_t* flatten_ids, void* temp, size_t temp_bytes);
+/* offsets[C*tile_h*tile_w] i32 = first sorted index of each (cam,tile). */
+int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids, int C,
+                        int tile_width, int tile_height, int32_t* offsets);
+
+/* ---- gsplat.rasterize_to_pixels  (base_engine.py:192-203)
+ * means2d[C*N,2] conics[C*N,3] colors[C*N,3] opacities[C*N], backgrounds[C,3] or NULL ->
+ * render_colors[C,H,W,3], render_alphas[C,H,W], last_ids[C,H,W] i32.  tile_size must be 16. */
+int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects, const float* means2d,
+                        const float* conics, const float* colors, const float* opacities,
+                        const float* backgrounds, int width, int height, int tile_size,
+                        int tile_width, int tile_height, const int32_t* offsets,
+                        const int32_t* flatten_ids, float* render_colors, float* render_alphas,
+                        int32_t* last_ids);
+/* v_means2d[C*N,2] v_conics[C*N,3] v_colors[C*N,3] v_opacities[C*N] must be ZEROED by the
+ * caller; the kernel accumulates with float atomics. */
+int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const float* means2d,
+                        const float* conics, const float* colors, const float* opacities,
+                        const float* backgrounds, int width, int height, int tile_size,
+                        int tile_width, int tile_height, const int32_t* offsets,
+                        const int32_t* flatten_ids, const float* render_alphas,
+                        const int32_t* last_ids, const float* v_render_colors,
+                        const float* v_render_alphas, float* v_means2d, float* v_conics,
+                        float* v_colors, float* v_opacities);
+
+/* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
+ * img1,img2 [B,CH,H,W].  fwd writes the per-pixel SSIM map sum into ssim_sum[1] (caller
+ * zeroes it; mean = sum / (B*CH*H*W)) and, when the three dm_* maps are non-NULL, the
+ * partial derivatives needed by bwd.  bwd writes v_img1 = v_mean[0] * inv_numel * dSSIM_sum/dimg1
+ * (v_mean is a DEVICE scalar: the upstream cotangent never visits the host). */
+int clmgs_ssim_fwd(void* stream, int B, int CH, int H, int W, const float* img1,
+                   const float* img2, float* ssim_sum, float* dm_dmu1, float* dm_dsigma1_sq,
+                   float* dm_dsigma12);
+int clmgs_ssim_bwd(void* stream, int B, int CH, int H, int W, const float* img1,
+                   const float* img2, const float* v_mean, float inv_numel, const float* dm_dmu1,
+                   const float* dm_dsigma1_sq, const float* dm_dsigma12, float* v_img1);
+
+/* ---- clm_kernels row movers  (clm_offload/engine.py:499-505, 622-636, 789-802, 815-822)
+ * dst/src may be device memory or pinned (mapped) host memory.
+ * gather:      dst[dst_idx ? dst_idx[i] : i] = src[src_idx ? src_idx[i] : i]
+ * scatter_add: dst[dst_idx ? dst_idx[i] : i] += src[src_idx ? src_idx[i] : i]
+ * Index arrays are i32 or i64 (idx_is_64). cols floats per row; grid_blocks = 0 -> auto. */
+int clmgs_rows_gather(void* stream, float* dst, const float* src, const void* dst_idx,
+                      const void* src_idx, int idx_is_64, int64_t n_rows, int cols,
+                      int grid_blocks);
+int clmgs_rows_scatter_add(void* stream, float* dst, const float* src, const void* dst_idx,
+                           const void* src_idx, int idx_is_64, int64_t n_rows, int cols,
+                           int grid_blocks);
+
+/* ---- clm_kernels bitmap helpers  (clm_offload/engine.py:152-153, 200-204, 227-232)
+ * bitmap elements are elem_bytes in {1,2,4,8}. */
+int clmgs_scatter_to_bit(void* stream, void* bitmap, int elem_bytes, const int64_t* filter,
+                         int64_t n, int bit);
+int clmgs_extract_ffs(void* stream, const void* bitmap, int elem_bytes, int64_t N, uint8_t* ffs);
+/* cnt[bsz-1] i32 (caller zeroes): cnt[i] = #{g : bit(bsz-1-i) & bit(bsz-2-i)} i.e. the
+ * number of Gaussians visible in both micro-batch i and i+1. */
+int clmgs_pair_overlap_count(void* stream, const void* bitmap, int elem_bytes, int64_t N,
+                             int bsz, int32_t* cnt);
+/* clm_kernels.set_signal (clm_offload/engine.py:807,825): stream-ordered write of `value`
+ * to pinned host flag signal[idx], visible to a polling host thread. */
+int clmgs_set_signal(void* stream, int32_t* signal_pinned, int idx, int32_t value);
+
+/* ---- Adam  (optimizer.py:6-184; clm_offload/gaussian_model.py:161-211)
+ * Row-wise Adam over p,g,m,v [*, cols] with per-column learning rate col_lr[cols] (device).
+ * rows: i32/i64 row list or NULL (all n_rows rows in order); mask: u8[n_rows] or NULL
+ * (rows with mask==0 are skipped; this is clm_kernels.selective_adam_update).
+ * g is multiplied by grad_scale; bias_correction uses the 1-based `step`;
+ * zero_grad != 0 clears consumed gradient rows. */
+int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const void* rows,
+                    int idx_is_64, const uint8_t* mask, int64_t n_rows, int cols,
+                    const float* col_lr, float beta1, float beta2, float eps, int step,
+                    int bias_correction, float grad_scale, int zero_grad);
+/* Host (OpenMP) variant on pinned/pageable host memory: cpu_adam.FusedCPUAdam row group
+ * update (clm_offload/engine.py:316-328).  If signal != NULL, busy-waits until
+ * *signal != 0 before touching the rows. */
+int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, const int32_t* rows,
+                         int64_t n_rows, int cols, const float* col_lr, float beta1, float beta2,
+                         float eps, int step, int bias_correction, float grad_scale,
+                         int zero_grad, const volatile int32_t* signal, int n_threads);
+
+/* ---- densification statistics  (clm_offload/gaussian_model.py:833-851;
+ *      no_offload/gaussian_model.py:767-783; densification.py:59-147)
+ * For i < n (only rows with radii[i] > 0 when only_visible != 0): g = filter ? filter[i] : i;
+ * max_radii2D[g] = max(., radii[i]); accum[g] += |v_means2d[i] * (W/2, H/2)|; denom[g] += 1. */
+int clmgs_densify_stats(void* stream, int64_t n, const int64_t* filter, const float* v_means2d,
+                        const int32_t* radii, int only_visible, float half_w, float half_h,
+                        float* max_radii2D,
+                        float* xyz_gradient_accum, float* denom);
+
+/* ---- fast_tsp.find_tour  (clm_offload/engine.py:179): open-tour heuristic on an n x n
+ * integer distance matrix (greedy nearest neighbour + 2-opt until no improvement). */
+int clmgs_tsp_tour(int n, const int64_t* dist, int32_t* tour);
+
+/* ---- pinned host memory  (numba.cuda.pinned_array at clm_offload/gaussian_model.py:34-44) */
+void* clmgs_pinned_alloc(size_t bytes);
+int clmgs_pinned_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLMGS_H */

@@ -1,0 +1,361 @@
+"""-m gpu: every HIP operator (through the C ABI) against the CPU oracle.
+
+Tolerances (fp32 path): forward images PSNR >= 60 dB and max-abs <= 2e-4;
+gradients relative-L2 <= 2e-4 against autograd of the oracle run in float64
+(float atomics make the summation order nondeterministic); integer outputs
+(radii, tile counts, isect ids, offsets, last ids, filters) bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import gs_oracle as O
+from tests.scenes import psnr, rel_l2, small_scene
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-4
+
+
+def _to(dev, *ts):
+    return [t.to(dev) for t in ts]
+
+
+def test_library_is_native(dev):
+    from clm_gs_amd import _lib
+    assert _lib.lib().clmgs_version() >= 100
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_projection_fwd_bwd(dev, C):
+    from clm_gs_amd import gsplat as G
+    s = small_scene(n=6000, width=200, height=120, seed=1, spread=3.0, depth=5.0)
+    vms = torch.stack([s["viewmat"]] * C)
+    for c in range(C):
+        vms[c, 0, 3] += 0.4 * c
+    Ks = torch.stack([s["K"]] * C)
+    m, q, sc = [t.clone().double().requires_grad_() for t in (s["means"], s["quats"], s["scales"])]
+    r0, m0, d0, c0, _ = O.fully_fused_projection(m, None, q, sc, vms.double(), Ks.double(), 200, 120)
+    md, qd, sd = [t.clone().to(dev).requires_grad_() for t in (s["means"], s["quats"], s["scales"])]
+    r1, m1, d1, c1, _ = G.fully_fused_projection(md, None, qd, sd, vms.to(dev), Ks.to(dev), 200, 120)
+    assert torch.equal(r1.cpu(), r0), "radii must be bit-exact"
+    assert (r0 > 0).sum() > 1000
+    ok = r0 > 0
+    assert (m1.cpu() - m0.float())[ok].abs().max() < 2e-3
+    assert rel_l2(d1.cpu()[ok], d0[ok]) < 1e-6
+    assert rel_l2(c1.cpu()[ok], c0[ok]) < 1e-5
+    assert m1.cpu()[~ok].abs().max() == 0 and c1.cpu()[~ok].abs().max() == 0
+    g = torch.Generator().manual_seed(5)
+    vm, vd, vc = torch.randn(m0.shape, generator=g), torch.randn(d0.shape, generator=g), torch.randn(c0.shape, generator=g)
+    ((m0 * vm.double()).sum() + (d0 * vd.double()).sum() + (c0 * vc.double()).sum()).backward()
+    ((m1 * vm.to(dev)).sum() + (d1 * vd.to(dev)).sum() + (c1 * vc.to(dev)).sum()).backward()
+    assert rel_l2(md.grad.cpu(), m.grad) < GRAD_TOL
+    assert rel_l2(qd.grad.cpu(), q.grad) < GRAD_TOL
+    assert rel_l2(sd.grad.cpu(), sc.grad) < GRAD_TOL
+
+
+def test_projection_packed_matches_oracle(dev):
+    from clm_gs_amd import gsplat as G
+    s = small_scene(n=3000, width=96, height=64, seed=2, spread=4.0)
+    vms = torch.stack([s["viewmat"], s["viewmat"]])
+    vms[1, 0, 3] -= 1.0
+    Ks = torch.stack([s["K"]] * 2)
+    ref = O.fully_fused_projection(s["means"], None, s["quats"], s["scales"], vms, Ks, 96, 64, packed=True)
+    out = G.fully_fused_projection(*_to(dev, s["means"]), None, *_to(dev, s["quats"], s["scales"], vms, Ks), 96, 64, packed=True)
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1])
+    assert torch.equal(out[2].cpu(), ref[2])
+    rad = G.visibility_radii(*_to(dev, s["means"], s["quats"], s["scales"], vms, Ks), 96, 64)
+    cam, gid = torch.nonzero(rad > 0, as_tuple=True)
+    assert torch.equal(cam.cpu(), ref[0]) and torch.equal(gid.cpu(), ref[1])
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+@pytest.mark.parametrize("masked", [False, True])
+def test_sh_fwd_bwd(dev, deg, masked):
+    from clm_gs_amd import gsplat as G
+    g = torch.Generator().manual_seed(10 + deg)
+    n = 1337
+    dirs = torch.randn(1, n, 3, generator=g) * 3
+    coeffs = torch.randn(1, n, 16, 3, generator=g)
+    masks = (torch.rand(1, n, generator=g) > 0.3) if masked else None
+    d0, c0 = dirs.double().requires_grad_(), coeffs.double().requires_grad_()
+    col0 = O.spherical_harmonics(deg, d0, c0, masks)
+    d1, c1 = dirs.to(dev).requires_grad_(), coeffs.to(dev).requires_grad_()
+    col1 = G.spherical_harmonics(deg, d1, c1, masks.to(dev) if masked else None)
+    assert (col1.cpu() - col0.float()).abs().max() < 1e-5
+    v = torch.randn(col0.shape, generator=g)
+    (col0 * v.double()).sum().backward()
+    (col1 * v.to(dev)).sum().backward()
+    assert rel_l2(c1.grad.cpu(), c0.grad) < 1e-5
+    if deg > 0:
+        assert rel_l2(d1.grad.cpu(), d0.grad) < 1e-4
+    else:
+        assert d1.grad.abs().max() == 0
+
+
+def test_sh_bwd_inplace_accumulates(dev):
+    from clm_gs_amd import clm_kernels as K
+    g = torch.Generator().manual_seed(3)
+    n, deg = 700, 2
+    dirs = torch.randn(1, n, 3, generator=g)
+    coeffs = torch.randn(1, n, 16, 3, generator=g)
+    vcol = torch.randn(1, n, 3, generator=g)
+    prior = torch.randn(n, 48, generator=g)
+    d0, c0 = dirs.double().requires_grad_(), coeffs.double().requires_grad_()
+    (O.spherical_harmonics(deg, d0, c0) * vcol.double()).sum().backward()
+    buf = prior.clone().to(dev)
+    v_dirs = K.spherical_harmonics_bwd_inplace(deg, dirs.to(dev), coeffs.to(dev), buf, vcol.to(dev))
+    want = prior.double() + c0.grad.reshape(n, 48)
+    assert rel_l2(buf.cpu(), want) < 1e-5
+    assert rel_l2(v_dirs.cpu(), d0.grad) < 1e-4
+
+
+def _project_cpu(s):
+    return O.fully_fused_projection(s["means"], None, s["quats"], s["scales"], s["viewmat"][None], s["K"][None], s["width"], s["height"])
+
+
+@pytest.mark.parametrize("wh", [(64, 48), (70, 37), (16, 16)])
+def test_isect_bit_exact(dev, wh):
+    from clm_gs_amd import gsplat as G
+    w, h = wh
+    s = small_scene(n=500, width=w, height=h, seed=4)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    t0, i0, f0 = O.isect_tiles(m2, radii, d, 16, tw, th)
+    t1, i1, f1 = G.isect_tiles(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th)
+    assert torch.equal(t1.cpu(), t0)
+    assert torch.equal(i1.cpu(), i0)
+    assert torch.equal(f1.cpu(), f0)
+    o0 = O.isect_offset_encode(i0, 1, tw, th)
+    o1 = G.isect_offset_encode(i1, 1, tw, th)
+    assert torch.equal(o1.cpu(), o0)
+
+
+def test_isect_empty(dev):
+    from clm_gs_amd import gsplat as G
+    n = 10
+    radii = torch.zeros(1, n, dtype=torch.int32, device=dev)
+    m2 = torch.zeros(1, n, 2, device=dev)
+    d = torch.zeros(1, n, device=dev)
+    t, i, f = G.isect_tiles(m2, radii, d, 16, 4, 3)
+    assert i.numel() == 0 and f.numel() == 0 and t.sum() == 0
+    off = G.isect_offset_encode(i, 1, 4, 3)
+    assert off.shape == (1, 3, 4) and off.abs().sum() == 0
+
+
+@pytest.mark.parametrize("bg", [None, (0.2, 0.5, 0.9)])
+@pytest.mark.parametrize("wh", [(64, 48), (70, 37)])
+def test_rasterize_fwd_bwd(dev, bg, wh):
+    from clm_gs_amd import gsplat as G
+    w, h = wh
+    s = small_scene(n=600, width=w, height=h, seed=6, log_scale=-1.2)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    _, ids, fids = O.isect_tiles(m2, radii, d, 16, tw, th)
+    off = O.isect_offset_encode(ids, 1, tw, th)
+    g = torch.Generator().manual_seed(9)
+    colors = torch.rand(1, 600, 3, generator=g)
+    opac = s["opac"].reshape(1, -1)
+    bgt = torch.tensor([bg]) if bg is not None else None
+    a = [t.clone().double().requires_grad_() for t in (m2, cn, colors, opac)]
+    img0, al0, last0 = O.rasterize_to_pixels(*a, w, h, 16, off, fids, backgrounds=bgt.double() if bg else None, return_last_ids=True)
+    b = [t.clone().to(dev).requires_grad_() for t in (m2, cn, colors, opac)]
+    img1, al1 = G.rasterize_to_pixels(*b, w, h, 16, off.to(dev), fids.to(dev), backgrounds=bgt.to(dev) if bg else None)
+    assert img1.shape == (1, h, w, 3) and al1.shape == (1, h, w, 1)
+    assert psnr(img1.cpu(), img0) > 60
+    assert (img1.cpu() - img0.float()).abs().max() < 2e-4
+    assert (al1.cpu() - al0.float()).abs().max() < 2e-4
+    vi, va = torch.randn(img0.shape, generator=g), torch.randn(al0.shape, generator=g)
+    ((img0 * vi.double()).sum() + (al0 * va.double()).sum()).backward()
+    ((img1 * vi.to(dev)).sum() + (al1 * va.to(dev)).sum()).backward()
+    for name, x, y in zip(("means2d", "conics", "colors", "opacities"), b, a):
+        assert rel_l2(x.grad.cpu(), y.grad) < GRAD_TOL, name
+
+
+def test_rasterize_last_ids_and_saturation(dev):
+    """Opaque stack: exercises the T <= 1e-4 early stop and last_ids."""
+    from clm_gs_amd import _lib, gsplat as G
+    w, h = 48, 32
+    s = small_scene(n=900, width=w, height=h, seed=7, spread=0.6, log_scale=-0.6)
+    s["opac"] = torch.full_like(s["opac"], 0.97)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    _, ids, fids = O.isect_tiles(m2, radii, d, 16, tw, th)
+    off = O.isect_offset_encode(ids, 1, tw, th)
+    colors = torch.rand(1, 900, 3, generator=torch.Generator().manual_seed(1))
+    opac = s["opac"].reshape(1, -1)
+    img0, al0, last0 = O.rasterize_to_pixels(m2, cn, colors, opac, w, h, 16, off, fids, return_last_ids=True)
+    assert (al0 > 0.9998).float().mean() > 0.3, "scene must saturate many pixels"
+    # call the C ABI directly to also see last_ids
+    L = _lib.lib()
+    from clm_gs_amd._lib import dptr, stream, check
+    t = [x.to(dev).contiguous() for x in (m2, cn, colors, opac, off, fids)]
+    out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
+    last = torch.empty(1, h, w, dtype=torch.int32, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, 900, fids.numel(), dptr(t[0]), dptr(t[1]), dptr(t[2]), dptr(t[3]), None,
+                                w, h, 16, tw, th, dptr(t[4]), dptr(t[5]), dptr(out), dptr(al), dptr(last)))
+    assert psnr(out.cpu(), img0) > 60
+    mism = (last.cpu() != last0).float().mean().item()
+    assert mism < 0.01, f"last_ids mismatch fraction {mism} (threshold ties only)"
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (37, 70), (11, 9)])
+def test_fused_ssim(dev, hw):
+    from clm_gs_amd import clm_kernels as K
+    h, w = hw
+    g = torch.Generator().manual_seed(11)
+    a, b = torch.rand(1, 3, h, w, generator=g), torch.rand(1, 3, h, w, generator=g)
+    a0 = a.double().requires_grad_()
+    s0 = O.fused_ssim(a0, b.double())
+    a1 = a.to(dev).requires_grad_()
+    s1 = K.fused_ssim(a1, b.to(dev))
+    assert abs(s1.item() - s0.item()) < 1e-5
+    (s0 * -0.2).backward()
+    (s1 * -0.2).backward()
+    assert rel_l2(a1.grad.cpu(), a0.grad) < 1e-4
+
+
+def test_end_to_end_one_camera(dev):
+    """strategies/no_offload/engine.py:15-101 composition: loss and all input grads."""
+    from clm_gs_amd import clm_kernels as K, gsplat as G
+    s = small_scene(n=800, width=80, height=56, seed=12)
+    w, h = s["width"], s["height"]
+    p0 = [t.clone().double().requires_grad_() for t in (s["means"], s["opac"], s["scales"], s["quats"], s["shs"])]
+    img0, _, _, _ = O.render_one_camera(*p0, 3, s["viewmat"].double(), s["K"].double(), w, h)
+    l0 = O.training_loss(img0, s["gt"])
+    l0.backward()
+    p1 = [t.clone().to(dev).requires_grad_() for t in (s["means"], s["opac"], s["scales"], s["quats"], s["shs"])]
+    means, opac, scales, quats, shs = p1
+    vm, Kd = s["viewmat"].to(dev), s["K"].to(dev)
+    radii, m2, d, cn, _ = G.fully_fused_projection(means, None, quats, scales, vm[None], Kd[None], w, h)
+    dirs = means[None] - torch.inverse(vm[None])[:, None, :3, 3]
+    col = torch.clamp_min(G.spherical_harmonics(3, dirs, shs[None], masks=radii > 0) + 0.5, 0.0)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    _, ids, fids = G.isect_tiles(m2, radii, d, 16, tw, th)
+    off = G.isect_offset_encode(ids, 1, tw, th)
+    img, _ = G.rasterize_to_pixels(m2, cn, col, opac.squeeze(1)[None], w, h, 16, off, fids)
+    img1 = img[0].permute(2, 0, 1).contiguous()
+    assert psnr(img1.cpu(), img0) > 60
+    gt = torch.clamp(s["gt"].to(dev).float() / 255.0, 0, 1)
+    l1 = 0.8 * (img1 - gt).abs().mean() + 0.2 * (1 - K.fused_ssim(img1[None], gt[None]))
+    l1.backward()
+    assert abs(l1.item() - l0.item()) < 1e-5
+    for name, x, y in zip(("means", "opac", "scales", "quats", "shs"), p1, p0):
+        assert rel_l2(x.grad.cpu(), y.grad) < 5e-4, name
+
+
+def test_row_movers_and_bitmaps(dev):
+    from clm_gs_amd import clm_kernels as K
+    g = torch.Generator().manual_seed(13)
+    N, n = 5000, 1200
+    params = torch.randn(N, 48, generator=g)
+    filt = torch.randperm(N, generator=g)[:n].sort().values
+    shs = torch.empty(n, 48, device=dev)
+    K.send_shs2gpu_stream(shs, params.to(dev), filt.to(dev))
+    assert torch.equal(shs.cpu(), params[filt])
+    # retention: half from "host", half from previous buffer
+    nxt = torch.full((n, 48), float("nan"), device=dev)
+    pos = torch.randperm(n, generator=g)
+    hpos, dpos = pos[: n // 2], pos[n // 2:]
+    hidx = torch.randint(0, N, (n // 2,), generator=g).to(torch.int32)
+    didx = torch.randint(0, n, (n - n // 2,), generator=g).to(torch.int32)
+    K.send_shs2gpu_stream_retention(nxt, params.to(dev), shs, hidx.to(dev), didx.to(dev),
+                                    hpos.to(torch.int32).to(dev), dpos.to(torch.int32).to(dev))
+    want = torch.empty(n, 48)
+    want[hpos] = params[hidx.long()]
+    want[dpos] = params[filt][didx.long()]
+    assert torch.equal(nxt.cpu(), want)
+    # gradient scatter-add
+    gb = torch.randn(N, 48, generator=g)
+    grad = torch.randn(n, 48, generator=g)
+    gbd = gb.clone().to(dev)
+    K.send_shs2cpu_grad_buffer_stream(grad.to(dev), gbd, filt.to(dev), True)
+    want = gb.clone(); want[filt] += grad
+    assert torch.allclose(gbd.cpu(), want, atol=1e-6)
+    # bitmap / ffs / overlap
+    bsz = 4
+    filters = [torch.randperm(N, generator=g)[: 800 + 100 * i].sort().values for i in range(bsz)]
+    bm = torch.zeros(N, dtype=torch.int8, device=dev)
+    for i, f in enumerate(filters):
+        K.scatter_to_bit(bm, f.to(dev), bsz - 1 - i)
+    ref = torch.zeros(N, dtype=torch.int64)
+    for i, f in enumerate(filters):
+        ref[f] |= 1 << (bsz - 1 - i)
+    assert torch.equal(bm.cpu().to(torch.int64) & 0xFF, ref)
+    ffs = torch.empty(N, dtype=torch.uint8, device=dev)
+    K.extract_ffs(bm, ffs)
+    want_ffs = torch.tensor([(int(v) & -int(v)).bit_length() for v in ref.tolist()], dtype=torch.uint8)
+    assert torch.equal(ffs.cpu(), want_ffs)
+    cnt = K.pair_overlap_count(bm, bsz)
+    sets = [set(f.tolist()) for f in filters]
+    assert cnt.cpu().tolist() == [len(sets[i] & sets[i + 1]) for i in range(bsz - 1)]
+
+
+def test_pinned_zero_copy_and_signal(dev):
+    import ctypes, numpy as np
+    from clm_gs_amd import clm_kernels as K, host as Hm
+    N, n = 3000, 500
+    buf = Hm.pinned_empty((N, 48))
+    g = torch.Generator().manual_seed(14)
+    buf.copy_(torch.randn(N, 48, generator=g))
+    filt = torch.randperm(N, generator=g)[:n].sort().values
+    shs = torch.empty(n, 48, device=dev)
+    K.send_shs2gpu_stream(shs, buf, filt.to(dev), 32, 256)
+    torch.cuda.synchronize()
+    assert torch.equal(shs.cpu(), buf[filt])
+    gb = Hm.pinned_empty((N, 48)); gb.zero_()
+    grad = torch.randn(n, 48, generator=g)
+    K.send_shs2cpu_grad_buffer_stream(grad.to(dev), gb, filt.to(dev), True, 32, 256)
+    sig = Hm.pinned_empty((4,), dtype=torch.int32); sig.zero_()
+    K.set_signal(sig, 2, 1)
+    torch.cuda.synchronize()
+    assert sig.tolist() == [0, 0, 1, 0]
+    want = torch.zeros(N, 48); want[filt] = grad
+    assert torch.equal(gb.clone(), want)
+
+
+def test_adam_rows_and_selective(dev):
+    from clm_gs_amd import clm_kernels as K
+    g = torch.Generator().manual_seed(15)
+    N, cols = 4000, 48
+    p, gr = torch.randn(N, cols, generator=g), torch.randn(N, cols, generator=g)
+    m, v = torch.rand(N, cols, generator=g) * 0.1, torch.rand(N, cols, generator=g) * 0.01
+    rows = torch.randperm(N, generator=g)[:900].to(torch.int32)
+    col_lr = torch.cat([torch.full((3,), 2.5e-3), torch.full((45,), 1.25e-4)])
+    ref = [t.clone().double() for t in (p, gr, m, v)]
+    O.adam_rows(*ref, rows, col_lr.double(), 0.9 ** 4, 0.999 ** 4, 1e-15 / 2, step=7, scale=0.25, zero_grad=True)
+    d = [t.clone().to(dev) for t in (p, gr, m, v)]
+    K.adam_rows(*d, rows.to(dev), col_lr.to(dev), 0.9 ** 4, 0.999 ** 4, 1e-15 / 2, 7, True, 0.25, True)
+    for a, b in zip(d, ref):
+        assert rel_l2(a.cpu(), b) < 1e-6
+    # selective (masked, no bias correction) on a [N,3] tensor
+    p3, g3 = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+    m3, v3 = torch.zeros(N, 3), torch.zeros(N, 3)
+    vis = torch.rand(N, generator=g) > 0.5
+    ref = [t.clone().double() for t in (p3, g3, m3, v3)]
+    O.selective_adam(*ref, vis, 1e-3, 0.9, 0.999, 1e-15)
+    d = [t.clone().to(dev) for t in (p3, g3, m3, v3)]
+    K.selective_adam_update(*d, vis.to(dev), 1e-3, 0.9, 0.999, 1e-15, N, 3)
+    for a, b in zip(d, ref):
+        assert rel_l2(a.cpu(), b) < 1e-6
+
+
+def test_densify_stats(dev):
+    from clm_gs_amd import clm_kernels as K
+    g = torch.Generator().manual_seed(16)
+    N, n = 2000, 600
+    filt = torch.randperm(N, generator=g)[:n].sort().values
+    vm = torch.randn(n, 2, generator=g)
+    radii = torch.randint(0, 30, (n,), generator=g).to(torch.int32)
+    mr, acc, den = torch.rand(N, generator=g) * 10, torch.rand(N, 1, generator=g), torch.rand(N, 1, generator=g)
+    d = [t.clone().to(dev) for t in (mr, acc, den)]
+    K.densify_stats(filt.to(dev), vm.to(dev), radii.to(dev), 640, 480, *d, only_visible=True)
+    vis = radii > 0
+    f = filt[vis]
+    mr2, acc2, den2 = mr.clone(), acc.clone(), den.clone()
+    mr2[f] = torch.maximum(mr2[f], radii[vis].float())
+    gg = vm[vis] * torch.tensor([320.0, 240.0])
+    acc2[f] += gg.norm(dim=-1, keepdim=True)
+    den2[f] += 1
+    assert torch.allclose(d[0].cpu(), mr2) and torch.allclose(d[1].cpu(), acc2, atol=1e-5) and torch.allclose(d[2].cpu(), den2)
