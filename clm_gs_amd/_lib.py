@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclmgs_hip.so")
 
 _vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_d = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/clmgs.h one to one
 SIGNATURES = {
@@ -37,8 +38,8 @@ SIGNATURES = {
     "clmgs_extract_ffs": (_i, [_vp, _vp, _i, _i64, _vp]),
     "clmgs_pair_overlap_count": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "clmgs_set_signal": (_i, [_vp, _vp, _i, ctypes.c_int32]),
-    "clmgs_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _f, _f, _f, _i, _i, _f, _i]),
-    "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _f, _f, _f, _i, _i, _f, _i, _vp, _i]),
+    "clmgs_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i]),
+    "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i, _vp, _i]),
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_pinned_alloc": (_vp, [_sz]),

@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(256)
 adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, const void* __restrict__ rows,
                  const uint8_t* __restrict__ mask, int64_t n_rows, int cols,
-                 const float* __restrict__ col_lr, float beta1, float beta2, float eps,
-                 float inv_bc1, float inv_sqrt_bc2, float grad_scale, int zero_grad) {
+                 const float* __restrict__ col_lr, float beta1, float beta2, float ob1, float ob2,
+                 float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale, int zero_grad) {
   const int64_t total = n_rows * cols;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -153,8 +153,8 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
     if (mask && !mask[row]) continue;
     const int64_t o = row * cols + k;
     const float gg = g[o] * grad_scale;
-    const float mm = beta1 * m[o] + (1.f - beta1) * gg;
-    const float vv = beta2 * v[o] + (1.f - beta2) * gg * gg;
+    const float mm = beta1 * m[o] + ob1 * gg;
+    const float vv = beta2 * v[o] + ob2 * gg * gg;
     m[o] = mm; v[o] = vv;
     const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
     p[o] -= (col_lr[k] * inv_bc1) * (mm / denom);
@@ -251,26 +251,30 @@ extern "C" int clmgs_set_signal(void* stream, int32_t* signal_pinned, int idx, i
 
 extern "C" int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v,
                                const void* rows, int idx_is_64, const uint8_t* mask,
-                               int64_t n_rows, int cols, const float* col_lr, float beta1,
-                               float beta2, float eps, int step, int bias_correction,
+                               int64_t n_rows, int cols, const float* col_lr, double beta1,
+                               double beta2, double eps, int step, int bias_correction,
                                float grad_scale, int zero_grad) {
   CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && step >= 1);
   if (n_rows == 0) return 0;
   CLMGS_CHECK_ARG(p && g && m && v && col_lr);
   float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
   if (bias_correction) {
-    inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
-    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    inv_bc1 = (float)(1.0 / (1.0 - pow(beta1, (double)step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
   }
+  // 1 - beta in double on the host: (1.f - 0.999f) alone is off by 1.3e-5 relative
+  const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
   const int grid = min(ceil_div(n_rows * cols, 256), 256 * 8);
   if (idx_is_64)
     hipLaunchKernelGGL(adam_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       g, m, v, rows, mask, n_rows, cols, col_lr, beta1, beta2, eps, inv_bc1,
-                       inv_sqrt_bc2, grad_scale, zero_grad);
+                       g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1, ob2,
+                       (float)eps,
+                       inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad);
   else
     hipLaunchKernelGGL(adam_rows_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       g, m, v, rows, mask, n_rows, cols, col_lr, beta1, beta2, eps, inv_bc1,
-                       inv_sqrt_bc2, grad_scale, zero_grad);
+                       g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1, ob2,
+                       (float)eps,
+                       inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

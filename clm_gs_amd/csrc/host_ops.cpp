@@ -52,8 +52,8 @@ extern "C" int clmgs_pinned_free(void* p) {
 // One row group of the overlapped host optimizer.  Waits (spinning, yielding) for the
 // GPU's set_signal write, then updates the listed rows with n_threads std::threads.
 extern "C" int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, const int32_t* rows,
-                                    int64_t n_rows, int cols, const float* col_lr, float beta1,
-                                    float beta2, float eps, int step, int bias_correction,
+                                    int64_t n_rows, int cols, const float* col_lr, double beta1d,
+                                    double beta2d, double epsd, int step, int bias_correction,
                                     float grad_scale, int zero_grad,
                                     const volatile int32_t* signal, int n_threads) {
   if (n_rows < 0 || cols <= 0 || step < 1 || (n_rows > 0 && !(p && g && m && v && col_lr))) {
@@ -64,14 +64,15 @@ extern "C" int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, cons
     while (__atomic_load_n((const int32_t*)signal, __ATOMIC_ACQUIRE) == 0) std::this_thread::yield();
   }
   if (n_rows == 0) return 0;
+  const float beta1 = (float)beta1d, beta2 = (float)beta2d, eps = (float)epsd;
   float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
   if (bias_correction) {
-    inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
-    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    inv_bc1 = (float)(1.0 / (1.0 - pow(beta1d, (double)step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2d, (double)step)));
   }
   std::vector<float> step_lr(cols);
   for (int k = 0; k < cols; ++k) step_lr[k] = col_lr[k] * inv_bc1;
-  const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
+  const float ob1 = (float)(1.0 - beta1d), ob2 = (float)(1.0 - beta2d);
   auto work = [&](int64_t lo, int64_t hi) {
     for (int64_t r = lo; r < hi; ++r) {
       const int64_t row = rows ? (int64_t)rows[r] : r;

@@ -1,0 +1,90 @@
+"""Raster front end shared by the engines (reference: strategies/base_engine.py:15-207):
+calculate_filters, the L1+SSIM training loss, and the one-camera forward used by eval."""
+import math
+
+import torch
+
+from .. import utils
+from ..clm_kernels import fused_ssim
+from ..gsplat import (fully_fused_projection, isect_offset_encode, isect_tiles,
+                      rasterize_to_pixels, spherical_harmonics, visibility_radii)
+
+LAMBDA_DSSIM = 0.2
+TILE_SIZE = 16
+
+
+def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotation_gpu):
+    """Per-camera visible index lists: ONE cull pass over (bsz cameras x N Gaussians).
+
+    Same index sets as the packed projection the reference runs (base_engine.py:18-76) -- the
+    cull is the projection's own (near plane, blur determinant, radius, off-screen) -- but only
+    radii are written.  Returns (filters, camera_ids, gaussian_ids)."""
+    args = utils.get_args()
+    with torch.no_grad():
+        Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in batched_cameras])
+        viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in batched_cameras])
+        radii = visibility_radii(xyz_gpu, rotation_gpu, scaling_gpu, viewmats, Ks,
+                                 int(utils.get_img_width()), int(utils.get_img_height()),
+                                 radius_clip=args.radius_clip)
+        vis = radii > 0
+        camera_ids, gaussian_ids = torch.nonzero(vis, as_tuple=True)
+        counts_cpu = vis.sum(dim=1).tolist()  # the one host sync of the filter stage
+        assert all(c > 0 for c in counts_cpu), (
+            "every camera must see at least one gaussian (base_engine.py:64-67)")
+        filters = torch.split(gaussian_ids, counts_cpu)
+    return filters, camera_ids, gaussian_ids
+
+
+def loss_combined(image, image_gt, ssim_loss):
+    Ll1 = torch.abs(image - image_gt).mean()
+    return (1.0 - LAMBDA_DSSIM) * Ll1 + LAMBDA_DSSIM * (1.0 - ssim_loss)
+
+
+def torch_compiled_loss(image, image_gt_original):
+    """0.8 * L1 + 0.2 * (1 - SSIM) against clamp(u8/255) (base_engine.py:79-103).  The
+    reference torch.compile's the mix; here the SSIM is the fused HIP kernel and the mix is
+    three elementwise torch ops."""
+    image_gt = torch.clamp(image_gt_original / 255.0, 0.0, 1.0)
+    ssim_loss = fused_ssim(image.unsqueeze(0), image_gt.unsqueeze(0))
+    return loss_combined(image, image_gt, ssim_loss)
+
+
+def _tile_counts(w, h):
+    return math.ceil(w / float(TILE_SIZE)), math.ceil(h / float(TILE_SIZE))
+
+
+def pipeline_forward_one_step(filtered_opacity_gpu, filtered_scaling_gpu, filtered_rotation_gpu,
+                              filtered_xyz_gpu, filtered_shs, camera, scene, gaussians, background,
+                              pipe_args, eval=False):
+    """One camera over the gathered rows, SH through autograd (base_engine.py:106-207)."""
+    image_width, image_height = int(utils.get_img_width()), int(utils.get_img_height())
+    fx = image_width / (2 * math.tan(camera.FoVx * 0.5))
+    fy = image_height / (2 * math.tan(camera.FoVy * 0.5))
+    K = torch.tensor([[fx, 0, image_width / 2.0], [0, fy, image_height / 2.0], [0, 0, 1]],
+                     device=filtered_xyz_gpu.device)
+    viewmat = camera.world_view_transform.transpose(0, 1)
+    n_selected = filtered_xyz_gpu.shape[0]
+    radiis, means2D, depths, conics, _ = fully_fused_projection(
+        means=filtered_xyz_gpu, covars=None, quats=filtered_rotation_gpu,
+        scales=filtered_scaling_gpu, viewmats=viewmat.unsqueeze(0), Ks=K.unsqueeze(0),
+        width=image_width, height=image_height, packed=False)
+    if not eval:
+        means2D.retain_grad()
+    camtoworlds = torch.inverse(viewmat.unsqueeze(0))
+    dirs = filtered_xyz_gpu[None, :, :] - camtoworlds[:, None, :3, 3]
+    colors = spherical_harmonics(degrees_to_use=gaussians.active_sh_degree, dirs=dirs,
+                                 coeffs=filtered_shs.reshape(1, n_selected, 16, 3))
+    colors = torch.clamp_min(colors + 0.5, 0.0)
+    opacities = filtered_opacity_gpu.squeeze(1).unsqueeze(0)
+    tile_width, tile_height = _tile_counts(image_width, image_height)
+    _, isect_ids, flatten_ids = isect_tiles(means2d=means2D, radii=radiis, depths=depths,
+                                            tile_size=TILE_SIZE, tile_width=tile_width,
+                                            tile_height=tile_height, packed=False)
+    isect_offsets = isect_offset_encode(isect_ids, 1, tile_width, tile_height)
+    backgrounds = background.reshape(1, 3) if background is not None else None
+    rendered_image, _ = rasterize_to_pixels(
+        means2d=means2D, conics=conics, colors=colors, opacities=opacities,
+        image_width=image_width, image_height=image_height, tile_size=TILE_SIZE,
+        isect_offsets=isect_offsets, flatten_ids=flatten_ids, backgrounds=backgrounds)
+    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1).contiguous()
+    return rendered_image, means2D, radiis

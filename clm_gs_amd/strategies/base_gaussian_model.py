@@ -1,0 +1,251 @@
+"""Shared Gaussian-model logic (reference: strategies/base_gaussian_model.py:32-399).
+
+Storage is described once, by name: every optimisable attribute is a row-major [N, d]
+tensor registered in ``self._store``; densify / clone / split / prune are written against
+that table, so the optimizer-state surgery exists exactly once for both strategies.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import utils
+from ..clm_kernels import densify_stats
+from ..utils import RGB2SH, build_rotation, get_expon_lr_func, inverse_sigmoid
+
+
+class BaseGaussianModel(ABC):
+    def setup_functions(self):
+        self.scaling_activation = torch.exp
+        self.scaling_inverse_activation = torch.log
+        self.opacity_activation = torch.sigmoid
+        self.inverse_opacity_activation = inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    def __init__(self, sh_degree: int, only_for_rendering: bool = False):
+        self.args = utils.get_args()
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self._xyz = torch.empty(0)
+        self._features_dc = torch.empty(0)
+        self._features_rest = torch.empty(0)
+        self._scaling = torch.empty(0)
+        self._rotation = torch.empty(0)
+        self._opacity = torch.empty(0)
+        self._parameters = torch.empty(0)
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0
+        self.spatial_lr_scale = 0
+        self.parameters_buffer = torch.empty(0)
+        self.parameters_grad_buffer = torch.empty(0)
+        self.only_for_rendering = only_for_rendering
+        self.setup_functions()
+        self.device = "cuda"
+        # densify_and_split draws from this generator; camera-DP replicas seed it identically
+        self.split_generator = None
+
+    # ------------------------------------------------------------------ getters
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    @property
+    @abstractmethod
+    def get_features(self):
+        ...
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ------------------------------------------------------------ initialisation
+    def _init_values_from_points(self, points, colors, dist2=None):
+        """xyz, SH dc from RGB, log-scale from mean 3-NN distance, identity quats,
+        opacity 0.1 (clm_offload/gaussian_model.py:24-111)."""
+        points = torch.as_tensor(np.asarray(points)).float()
+        colors = torch.as_tensor(np.asarray(colors)).float()
+        n = points.shape[0]
+        feats = torch.zeros((n, 16, 3))
+        feats[:, 0, :] = RGB2SH(colors)
+        if dist2 is None:
+            from ..simple_knn import distCUDA2
+            dist2 = distCUDA2(points.cuda()).cpu()
+        dist2 = torch.clamp_min(dist2, 1e-7)
+        scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3)
+        rots = torch.zeros((n, 4))
+        rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones((n, 1)))
+        return points, feats.reshape(n, 48), scales, rots, opac
+
+    @abstractmethod
+    def create_from_tensors(self, xyz, shs48, scaling, rotation, opacity, spatial_lr_scale=1.0):
+        ...
+
+    def create_from_pcd(self, pcd, spatial_lr_scale: float, subsample_ratio: float = 1.0):
+        pts, shs, sc, rot, op = self._init_values_from_points(pcd.points, pcd.colors)
+        if subsample_ratio != 1.0:
+            g = torch.Generator().manual_seed(1)
+            keep = torch.randperm(pts.shape[0], generator=g)[: int(pts.shape[0] * subsample_ratio)].sort().values
+            pts, shs, sc, rot, op = pts[keep], shs[keep], sc[keep], rot[keep], op[keep]
+        self.create_from_tensors(pts, shs, sc, rot, op, spatial_lr_scale)
+
+    # ---------------------------------------------------------------- optimiser
+    @abstractmethod
+    def all_parameters(self):
+        ...
+
+    @abstractmethod
+    def training_setup(self, training_args):
+        ...
+
+    def _scale_groups_for_bsz(self, training_args):
+        """bsz scaling of lr / eps / betas (no_offload/gaussian_model.py:223-246)."""
+        bsz = self.args.bsz
+        mode = training_args.lr_scale_mode
+        if mode == "linear":
+            lr_scale = bsz
+        elif mode == "sqrt":
+            lr_scale = float(np.sqrt(bsz))
+        elif mode == "accumu":
+            lr_scale = 1
+        else:
+            raise AssertionError(f"lr_scale_mode {mode} not supported.")
+        for g in self.optimizer.param_groups:
+            if mode == "accumu":
+                continue
+            g["lr"] *= lr_scale
+            if mode == "sqrt" and "eps" in g:
+                g["eps"] /= lr_scale
+                g["betas"] = [b ** bsz for b in g["betas"]]
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=training_args.position_lr_init * self.spatial_lr_scale * lr_scale * self.args.lr_scale_pos_and_scale,
+            lr_final=training_args.position_lr_final * self.spatial_lr_scale * lr_scale * self.args.lr_scale_pos_and_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult,
+            max_steps=training_args.position_lr_max_steps)
+        return lr_scale
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = self.xyz_scheduler_args(iteration)
+                return g["lr"]
+
+    # ---------------------------------------------------------- densification
+    def _reset_stats(self):
+        n = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device="cuda")
+        self.denom = torch.zeros((n, 1), device="cuda")
+        self.max_radii2D = torch.zeros((n,), device="cuda")
+
+    @abstractmethod
+    def _append_rows(self, new):
+        """new: dict name -> [k,d] device tensors for xyz/opacity/scaling/rotation/shs48."""
+
+    @abstractmethod
+    def prune_points(self, mask):
+        ...
+
+    @abstractmethod
+    def _shs48_rows(self, mask):
+        """[k,48] device copy of the SH rows selected by a device bool mask."""
+
+    @abstractmethod
+    def reset_opacity(self):
+        ...
+
+    def densification_postfix(self, new_xyz, new_shs48, new_opacities, new_scaling, new_rotation):
+        self._append_rows(dict(xyz=new_xyz, shs48=new_shs48, opacity=new_opacities,
+                               scaling=new_scaling, rotation=new_rotation))
+        self._reset_stats()
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = torch.norm(grads, dim=-1) >= grad_threshold
+        sel &= torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent
+        utils.get_log_file().write(f"Number of cloned gaussians: {int(sel.sum())}\n")
+        self.densification_postfix(self._xyz.detach()[sel], self._shs48_rows(sel),
+                                   self._opacity.detach()[sel], self._scaling.detach()[sel],
+                                   self._rotation.detach()[sel])
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        n_init = self.get_xyz.shape[0]
+        padded = torch.zeros((n_init,), device="cuda")
+        padded[: grads.shape[0]] = grads.squeeze()
+        sel = padded >= grad_threshold
+        sel &= torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent
+        stds = self.get_scaling.detach()[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=self.split_generator)
+        utils.get_log_file().write(f"Number of split gaussians: {int(sel.sum())}\n")
+        rots = build_rotation(self._rotation.detach()[sel]).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz.detach()[sel].repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(self.get_scaling.detach()[sel].repeat(N, 1) / (0.8 * N))
+        self.densification_postfix(new_xyz, self._shs48_rows(sel).repeat(N, 1),
+                                   self._opacity.detach()[sel].repeat(N, 1), new_scaling,
+                                   self._rotation.detach()[sel].repeat(N, 1))
+        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device="cuda", dtype=torch.bool)))
+        self.prune_points(prune)
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        """base_gaussian_model.py:364-388.  The screen-size prune is provably inert upstream
+        (max_radii2D has just been zeroed by densification_postfix; asserts at :376-381), so
+        only opacity and world-size pruning act."""
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent)
+        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            assert torch.all(self.max_radii2D == 0)
+            big_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
+            prune_mask = torch.logical_or(prune_mask, big_ws)
+        self.prune_points(prune_mask)
+
+    # ------------------------------------------------------------- statistics
+    def gsplat_add_densification_stats_exact_filter(self, viewspace_point_tensor_grad, radii,
+                                                    send2gpu_final_filter_indices, width, height):
+        """max_radii2D / |grad * (W/2,H/2)| / count on the filter's rows, every row
+        (clm_offload/gaussian_model.py:833-851), as one fused kernel."""
+        densify_stats(send2gpu_final_filter_indices, viewspace_point_tensor_grad, radii, width,
+                      height, self.max_radii2D, self.xyz_gradient_accum, self.denom,
+                      only_visible=False)
+
+    def gsplat_add_densification_stats(self, viewspace_point_tensor_grad, send2gpu_visibility_filter,
+                                       update_filter, width, height):
+        """Boolean-mask form (no_offload/gaussian_model.py:767-783); does not touch max_radii2D."""
+        grad = viewspace_point_tensor_grad
+        g = grad[update_filter] * torch.tensor([width * 0.5, height * 0.5], device=grad.device)
+        self.xyz_gradient_accum[send2gpu_visibility_filter] += torch.norm(g, dim=-1, keepdim=True)
+        self.denom[send2gpu_visibility_filter] += 1
+
+    # -------------------------------------------------------------------- I/O
+    def save_tensors(self, folder):
+        """Five-file .pt layout (clm_offload/gaussian_model.py:236-243)."""
+        import os
+        os.makedirs(folder, exist_ok=True)
+        torch.save(self._xyz.detach().cpu(), os.path.join(folder, "xyz.pt"))
+        torch.save(self._opacity.detach().cpu(), os.path.join(folder, "opacity.pt"))
+        torch.save(self._scaling.detach().cpu(), os.path.join(folder, "scaling.pt"))
+        torch.save(self._rotation.detach().cpu(), os.path.join(folder, "rotation.pt"))
+        torch.save(self._shs48_rows(None).cpu(), os.path.join(folder, "parameters.pt"))
+
+    def load_tensors(self, folder, spatial_lr_scale=1.0):
+        import os
+        ld = lambda n: torch.load(os.path.join(folder, n + ".pt"))
+        self.create_from_tensors(ld("xyz"), ld("parameters"), ld("scaling"), ld("rotation"),
+                                 ld("opacity"), spatial_lr_scale)
+        self.active_sh_degree = self.max_sh_degree

@@ -1,0 +1,414 @@
+"""clm_offload engine (reference: strategies/clm_offload/engine.py:30-979).
+
+``clm_offload_train_one_batch`` keeps the reference signature and return value.  Per batch:
+visibility filters for all cameras (one cull pass) -> per micro-batch: gather the visible rows,
+render, loss, backward, SH backward in place, scatter the small gradients back -> Adam.
+
+Two residency modes for the [N,48] SH rows and their optimizer state (see gaussian_model.py):
+
+* HBM-resident (MI355X default).  Rows are gathered / scatter-added inside HBM; the Adam for
+  rows NOT touched by this batch (pure momentum decay, needs no gradient) runs on the side
+  stream concurrently with rendering, the Adam for touched rows right after the last
+  micro-batch.  Camera re-ordering and the retention sets exist to save PCIe traffic and are
+  skipped here: they cannot change the batch gradient (exact arithmetic), only its float
+  summation order.
+* host-resident (the reference's design, for scenes beyond HBM).  Pinned host rows, zero-copy
+  gather / scatter-add kernels on the comm stream with the H / D / G retention sets
+  (engine.py:568-571), TSP camera order, row groups by last use, pinned signal flags and a
+  host Adam thread overlapped with rendering.
+"""
+import math
+import threading
+
+import torch
+
+from ... import clm_kernels, fast_tsp, utils
+from ...clm_kernels import (send_shs2cpu_grad_buffer_stream,
+                            send_shs2cpu_grad_buffer_stream_retention, send_shs2gpu_stream,
+                            send_shs2gpu_stream_retention, spherical_harmonics_bwd_inplace)
+from ...densification import update_densification_stats_offload_accum_grads
+from ...gsplat import (fully_fused_projection, isect_offset_encode, isect_tiles,
+                       rasterize_to_pixels, spherical_harmonics)
+from ...host import pinned_empty
+from ..base_engine import (TILE_SIZE, calculate_filters, pipeline_forward_one_step,
+                           torch_compiled_loss)
+
+_BITMAP_DTYPE = {4: torch.int8, 8: torch.int8, 16: torch.int16, 32: torch.int32, 64: torch.int64}
+
+
+def pipeline_forward_one_step_shs_inplace(filtered_opacity_gpu, filtered_scaling_gpu,
+                                          filtered_rotation_gpu, filtered_xyz_gpu, filtered_shs,
+                                          camera, scene, gaussians, background, pipe_args):
+    """One camera over the gathered rows; SH evaluated under no_grad and the colours re-leafed so
+    the SH backward can later accumulate in place (engine.py:30-127).
+    Returns (image[3,H,W], means2D[1,V,2], radii[1,V], colors_detached[1,V,3], dirs[1,V,3])."""
+    viewmat = camera.world_view_transform.transpose(0, 1)
+    K = camera.K
+    n_selected = filtered_xyz_gpu.shape[0]
+    image_width, image_height = int(utils.get_img_width()), int(utils.get_img_height())
+    radiis, means2D, depths, conics, _ = fully_fused_projection(
+        means=filtered_xyz_gpu, covars=None, quats=filtered_rotation_gpu,
+        scales=filtered_scaling_gpu, viewmats=viewmat.unsqueeze(0), Ks=K.unsqueeze(0),
+        width=image_width, height=image_height, packed=False)
+    means2D.retain_grad()
+    dirs = filtered_xyz_gpu[None, :, :] - camera.camtoworlds[:, None, :3, 3]
+    filtered_shs = filtered_shs.reshape(1, n_selected, 16, 3)
+    with torch.no_grad():
+        colors_origin = spherical_harmonics(degrees_to_use=gaussians.active_sh_degree, dirs=dirs,
+                                            coeffs=filtered_shs)
+    colors_detached = colors_origin.detach().requires_grad_()
+    colors = torch.clamp_min(colors_detached + 0.5, 0.0)
+    opacities = filtered_opacity_gpu.squeeze(1).unsqueeze(0)
+    tile_width = math.ceil(image_width / float(TILE_SIZE))
+    tile_height = math.ceil(image_height / float(TILE_SIZE))
+    _, isect_ids, flatten_ids = isect_tiles(means2d=means2D, radii=radiis, depths=depths,
+                                            tile_size=TILE_SIZE, tile_width=tile_width,
+                                            tile_height=tile_height, packed=False)
+    isect_offsets = isect_offset_encode(isect_ids, 1, tile_width, tile_height)
+    backgrounds = background.reshape(1, 3) if background is not None else None
+    rendered_image, _ = rasterize_to_pixels(
+        means2d=means2D, conics=conics, colors=colors, opacities=opacities,
+        image_width=image_width, image_height=image_height, tile_size=TILE_SIZE,
+        isect_offsets=isect_offsets, flatten_ids=flatten_ids, backgrounds=backgrounds)
+    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1).contiguous()
+    return rendered_image, means2D, radiis, colors_detached, dirs
+
+
+# --------------------------------------------------------------------------- ordering
+def _encode_bitmap(filters, n_gaussians, bsz):
+    bitmap = torch.zeros((n_gaussians,), dtype=_BITMAP_DTYPE[bsz], device=filters[0].device)
+    for i, f in enumerate(filters):  # MSB = first micro-batch (engine.py:150-153)
+        clm_kernels.scatter_to_bit(bitmap, f, bsz - 1 - i)
+    return bitmap
+
+
+def order_calculation(filters, batched_cameras, n_gaussians, bsz, perm_generator, args):
+    """Camera order + row groups by last use + retention-set sizes (engine.py:135-298).
+
+    Returns (finish_indices_filters[bsz+1] pinned-host i32, cameras, filters, sparsity,
+    ordered_cams, cnt_h, cnt_d, cnt_g (python int lists, len bsz-1), visibility_mask | None,
+    bitmap)."""
+    if bsz not in _BITMAP_DTYPE:
+        raise ValueError("Currently supported bsz: (4, 8, 16, 32, 64).")
+    dev = filters[0].device
+    bitmap = _encode_bitmap(filters, n_gaussians, bsz)
+    # sampled Hamming distance between the cameras' visibility sets (deterministic stride
+    # sample instead of the reference's randperm over N)
+    stride = bsz * bsz if bsz >= 32 else 32
+    sample = bitmap[::stride].to(torch.int64)
+    shifts = torch.arange(bsz - 1, -1, -1, device=dev)
+    unz = ((sample[None, :] >> shifts[:, None]) & 1).to(torch.float32)  # [bsz, n_s], row i = mb i
+    ones = unz.sum(dim=1)
+    inter = unz @ unz.t()
+    distance_matrix = (ones[:, None] + ones[None, :] - 2 * inter).round().to(torch.int64).tolist()
+    ordered_cams = fast_tsp.find_tour(distance_matrix, 0.001)
+    if args.reorder_by_min_sparsity_at_end:
+        k_min = bsz - 1
+        for k in range(bsz - 1):
+            if len(filters[ordered_cams[k]]) < len(filters[ordered_cams[k_min]]):
+                k_min = k
+        ordered_cams = ordered_cams[k_min + 1:] + ordered_cams[:k_min + 1]
+    batched_cameras = [batched_cameras[i] for i in ordered_cams]
+    filters = [filters[i] for i in ordered_cams]
+    sparsity = [len(f) / float(n_gaussians) for f in filters]
+
+    bitmap = _encode_bitmap(filters, n_gaussians, bsz)
+    ffs = torch.empty(n_gaussians, dtype=torch.uint8, device=dev)
+    clm_kernels.extract_ffs(bitmap, ffs)
+    # group 0: untouched; group k (k>=1): last used in micro-batch k-1  <=> ffs == bsz - (k-1)
+    groups = [torch.nonzero(ffs == 0).flatten()]
+    for mb in range(bsz):
+        groups.append(torch.nonzero(ffs == (bsz - mb)).flatten())
+    visibility_mask = (ffs != 0) if args.sparse_adam else None
+
+    cnt_d = clm_kernels.pair_overlap_count(bitmap, bsz).tolist()
+    lens = [len(f) for f in filters]
+    cnt_h = [lens[i + 1] - cnt_d[i] for i in range(bsz - 1)]
+    cnt_g = [lens[i] - cnt_d[i] for i in range(bsz - 1)]
+
+    # one pinned D2H copy of every index list, as int32 (engine.py:246-260)
+    sizes = [g.numel() for g in groups]
+    cat = torch.cat(groups).to(torch.int32)
+    cat_h = pinned_empty((max(cat.numel(), 1),), dtype=torch.int32)[:cat.numel()]
+    cat_h.copy_(cat)
+    finish_indices_filters = list(torch.split(cat_h, sizes))
+    assert len(finish_indices_filters) == bsz + 1
+    assert sum(sizes) == n_gaussians, (sum(sizes), n_gaussians)
+    return (finish_indices_filters, batched_cameras, filters, sparsity, ordered_cams, cnt_h, cnt_d,
+            cnt_g, visibility_mask, bitmap)
+
+
+def cpuadam_thread(bsz, n_gaussians, signal_tensor_pinned, finish_indices_filters, cpu_adam,
+                   parameters, parameters_grad, iteration, args):
+    """Host optimizer thread body (engine.py:301-335)."""
+    parameters.grad = parameters_grad
+    if not args.stop_update_param:
+        cpu_adam.batched_sparse_step(batch_size=bsz, batched_sparse_indices=finish_indices_filters,
+                                     signal_tensor_pinned=signal_tensor_pinned, version=3,
+                                     scale=1.0 / bsz, sparse_adam=args.sparse_adam)
+
+
+# ------------------------------------------------------------------ shared micro-batch
+def _gather_small(gaussians, this_filter):
+    idx = this_filter
+    xyz = gaussians._xyz.detach()[idx].requires_grad_(True)
+    opa = gaussians._opacity.detach()[idx].requires_grad_(True)
+    sca = gaussians._scaling.detach()[idx].requires_grad_(True)
+    rot = gaussians._rotation.detach()[idx].requires_grad_(True)
+    return xyz, opa, sca, rot
+
+
+def _scatter_small_grads(gaussians, this_filter, xyz, opa, sca, rot):
+    with torch.no_grad():
+        gaussians._xyz.grad.index_add_(0, this_filter, xyz.grad)
+        gaussians._opacity.grad.index_add_(0, this_filter, opa.grad)
+        gaussians._scaling.grad.index_add_(0, this_filter, sca.grad)
+        gaussians._rotation.grad.index_add_(0, this_filter, rot.grad)
+
+
+def _render_and_backward(gaussians, scene, camera, background, pipe_args, this_filter, shs,
+                         shs_grad, before_sh_backward=None):
+    """Forward + loss + backward for one camera on the gathered rows; SH gradients are
+    accumulated into shs_grad[V,48]; small gradients are scatter-added into the model's .grad."""
+    xyz, opa_raw, sca_raw, rot_raw = _gather_small(gaussians, this_filter)
+    opa = gaussians.opacity_activation(opa_raw)
+    sca = gaussians.scaling_activation(sca_raw)
+    rot = gaussians.rotation_activation(rot_raw)
+    image, means2D, radiis, colors_detached, dirs = pipeline_forward_one_step_shs_inplace(
+        opa, sca, rot, xyz, shs, camera, scene, gaussians, background, pipe_args)
+    loss = torch_compiled_loss(image, camera.original_image)
+    loss.backward()
+    if before_sh_backward is not None:
+        before_sh_backward()
+    v_dirs = spherical_harmonics_bwd_inplace(
+        degrees_to_use=gaussians.active_sh_degree, dirs=dirs, coeffs=shs.reshape(1, -1, 16, 3),
+        v_coeffs=shs_grad, v_colors=colors_detached.grad)
+    dirs.backward(v_dirs)
+    _scatter_small_grads(gaussians, this_filter, xyz, opa_raw, sca_raw, rot_raw)
+    update_densification_stats_offload_accum_grads(
+        scene, gaussians, int(utils.get_img_height()), int(utils.get_img_width()), this_filter,
+        means2D.grad.squeeze(0), radiis.squeeze(0))
+    return loss.detach()
+
+
+def _zero_small_grads(gaussians):
+    gaussians._xyz.grad = torch.zeros_like(gaussians._xyz)
+    gaussians._opacity.grad = torch.zeros_like(gaussians._opacity)
+    gaussians._scaling.grad = torch.zeros_like(gaussians._scaling)
+    gaussians._rotation.grad = torch.zeros_like(gaussians._rotation)
+
+
+def _gpu_adam_step(gaussians, args, visibility_mask):
+    for param in gaussians.all_parameters()[:4]:
+        if param.grad is not None:
+            param.grad /= args.bsz
+    if not args.stop_update_param:
+        if args.sparse_adam:
+            gaussians.optimizer.gpu_adam.step(visibility=visibility_mask)
+        else:
+            gaussians.optimizer.gpu_adam.step()
+    gaussians.optimizer.gpu_adam.zero_grad(set_to_none=True)
+
+
+# ----------------------------------------------------------------------- HBM-resident
+def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
+                         pipe_args, comm_stream, args):
+    bsz = len(batched_cameras)
+    N = gaussians._xyz.shape[0]
+    with torch.no_grad():
+        filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
+                                          gaussians.get_scaling, gaussians.get_rotation)
+    sparsity = [len(f) / float(N) for f in filters]
+    ordered_cams = list(range(bsz))
+    touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
+    for f in filters:
+        touched[f] = True
+    row_adam = gaussians.optimizer.cpu_adam
+    params = gaussians._parameters
+    grad_buf = parameters_grad_buffer[:N]
+    params.grad = grad_buf
+    row_adam.global_step += 1
+    step = row_adam.global_step
+    group = row_adam.param_groups[0]
+    st = row_adam.state[params]
+    default_stream = torch.cuda.current_stream()
+    side_event = None
+    col_lr = row_adam._col_lr(params.device)
+
+    def row_update(mask):
+        clm_kernels.adam_rows(params.data, grad_buf, st["exp_avg"], st["exp_avg_sq"], None, col_lr,
+                              group["betas"][0], group["betas"][1], group["eps"], step,
+                              group["bias_correction"], 1.0 / bsz, True, mask=mask)
+
+    if not args.stop_update_param and not args.sparse_adam:
+        # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
+        untouched = ~touched
+        comm_stream.wait_stream(default_stream)
+        with torch.cuda.stream(comm_stream):
+            row_update(untouched)
+            side_event = torch.cuda.Event()
+            side_event.record(comm_stream)
+        untouched.record_stream(comm_stream)
+
+    _zero_small_grads(gaussians)
+    losses = []
+    for micro_idx in range(bsz):
+        this_filter = filters[micro_idx]
+        with torch.no_grad():
+            shs = torch.empty((this_filter.shape[0], 48), device=params.device)
+            send_shs2gpu_stream(shs, params.data, this_filter)
+            shs_grad = torch.zeros_like(shs)
+        loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
+                                    pipe_args, this_filter, shs, shs_grad)
+        with torch.no_grad():
+            send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
+        losses.append(loss)
+
+    _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None)
+    if not args.stop_update_param:
+        row_update(touched)
+    st["step"] = step
+    if side_event is not None:
+        default_stream.wait_event(side_event)
+    torch.cuda.synchronize()
+    return losses, ordered_cams, sparsity
+
+
+# ---------------------------------------------------------------------- host-resident
+def _bit_of(bitmap, ids, bit):
+    return ((bitmap[ids].to(torch.int64) >> bit) & 1).to(torch.bool)
+
+
+def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
+                          pipe_args, comm_stream, perm_generator, args):
+    iteration = utils.get_cur_iter()
+    bsz = len(batched_cameras)
+    N = gaussians._xyz.shape[0]
+    dev = gaussians._xyz.device
+    with torch.no_grad():
+        filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
+                                          gaussians.get_scaling, gaussians.get_rotation)
+    (finish_indices_filters, batched_cameras, filters, sparsity, ordered_cams, cnt_h, cnt_d, cnt_g,
+     visibility_mask, bitmap) = order_calculation(filters, batched_cameras, N, bsz, perm_generator, args)
+
+    if not hasattr(gaussians, "signal_tensor_pinned") or gaussians.signal_tensor_pinned.numel() != bsz:
+        gaussians.signal_tensor_pinned = pinned_empty((bsz,), dtype=torch.int32)
+    gaussians.signal_tensor_pinned.zero_()
+    signal = gaussians.signal_tensor_pinned
+    torch.cuda.synchronize()
+
+    worker = threading.Thread(target=cpuadam_thread, args=(
+        bsz, N, signal, finish_indices_filters, gaussians.optimizer.cpu_adam, gaussians._parameters,
+        parameters_grad_buffer[:N, :], iteration, args))
+    worker.start()
+
+    _zero_small_grads(gaussians)
+    default_stream = torch.cuda.current_stream()
+    gH, gD = args.grid_size_H, args.grid_size_D
+    params_host = gaussians._parameters.data
+    grad_host = parameters_grad_buffer[:N, :]
+    keep_alive = []  # tensors touched by both streams live until the final synchronize
+    losses = []
+
+    with torch.cuda.stream(comm_stream), torch.no_grad():
+        shs = torch.empty((filters[0].shape[0], 48), device=dev)
+        send_shs2gpu_stream(shs, params_host, filters[0], gH, 256)
+        shs_grad = torch.zeros((filters[0].shape[0], 48), device=dev)
+        ready = torch.cuda.Event()
+        ready.record(comm_stream)
+        grad_ready = torch.cuda.Event()
+        grad_ready.record(comm_stream)
+    comm_stream.wait_stream(default_stream)
+
+    for i in range(bsz):
+        F = filters[i]
+        last = i == bsz - 1
+        nxt = None
+        if not last:
+            with torch.cuda.stream(comm_stream), torch.no_grad():
+                Fn = filters[i + 1]
+                # H = ~this & next, D = this & next, G = this & ~next  (engine.py:568-571);
+                # sizes are known, so nonzero_static never syncs
+                in_cur = _bit_of(bitmap, Fn, bsz - 1 - i)
+                d_pos_next = torch.nonzero_static(in_cur, size=cnt_d[i]).flatten()
+                h_pos_next = torch.nonzero_static(~in_cur, size=cnt_h[i]).flatten()
+                d_ids = Fn[d_pos_next]
+                d_pos_cur = torch.searchsorted(F, d_ids)
+                h_ids = Fn[h_pos_next].to(torch.int32)
+                in_next = _bit_of(bitmap, F, bsz - 2 - i)
+                g_pos_cur = torch.nonzero_static(~in_next, size=cnt_g[i]).flatten()
+                g_ids = F[g_pos_cur].to(torch.int32)
+                d_pos_next32, d_pos_cur32 = d_pos_next.to(torch.int32), d_pos_cur.to(torch.int32)
+                shs_next = torch.empty((Fn.shape[0], 48), device=dev)
+                send_shs2gpu_stream_retention(shs_next, params_host, shs, h_ids, d_pos_cur32,
+                                              h_pos_next.to(torch.int32), d_pos_next32, gH, 256,
+                                              gD, 256)
+                next_ready = torch.cuda.Event()
+                next_ready.record(comm_stream)
+                nxt = (shs_next, next_ready, g_ids, g_pos_cur.to(torch.int32), d_pos_next32, d_pos_cur32)
+                keep_alive += [in_cur, d_ids, h_ids, in_next]
+
+        default_stream.wait_event(ready)
+        loss = _render_and_backward(gaussians, scene, batched_cameras[i], background, pipe_args, F,
+                                    shs, shs_grad,
+                                    before_sh_backward=lambda: default_stream.wait_event(grad_ready))
+        losses.append(loss)
+        done = torch.cuda.Event()
+        done.record(default_stream)
+
+        with torch.cuda.stream(comm_stream), torch.no_grad():
+            comm_stream.wait_event(done)
+            if not last:
+                shs_next, next_ready, g_ids, g_pos_cur32, d_pos_next32, d_pos_cur32 = nxt
+                shs_grad_next = torch.zeros_like(shs_next)
+                send_shs2cpu_grad_buffer_stream_retention(
+                    shs_grad, grad_host, shs_grad_next, g_ids, d_pos_next32, g_pos_cur32,
+                    d_pos_cur32, True, gH, 256, gD, 256)
+                grad_ready = torch.cuda.Event()
+                grad_ready.record(comm_stream)
+            else:
+                send_shs2cpu_grad_buffer_stream(shs_grad, grad_host, F, True, gH, 256)
+            clm_kernels.set_signal(signal, i, 1)
+        keep_alive += [shs, shs_grad]
+        if not last:
+            keep_alive += list(nxt[2:])
+            shs, ready, shs_grad = shs_next, next_ready, shs_grad_next
+
+    assert args.lr_scale_mode == "sqrt", "Overlap CPUAdam only supports sqrt lr scaling"
+    assert not args.stop_update_param, "Overlap CPUAdam does not support stop_update_param"
+    _gpu_adam_step(gaussians, args, visibility_mask)
+    worker.join()
+    torch.cuda.synchronize()
+    del keep_alive
+    return losses, ordered_cams, sparsity
+
+
+def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_grad_buffer,
+                                background, pipe_args, comm_stream, perm_generator):
+    """-> (losses: list[Tensor0d], ordered_cams: list[int], sparsity: list[float])
+    (train.py:362-371)."""
+    args = utils.get_args()
+    bsz = len(batched_cameras)
+    assert bsz > 1 and bsz in _BITMAP_DTYPE, "clm_offload supports bsz in (4, 8, 16, 32, 64)"
+    if gaussians._parameters.is_cuda:
+        return _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer,
+                                    background, pipe_args, comm_stream, args)
+    return _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer,
+                                 background, pipe_args, comm_stream, perm_generator, args)
+
+
+def clm_offload_eval_one_cam(camera, gaussians, background, scene):
+    """Single-camera render of the visible rows (engine.py:928-979) -> image[3,H,W]."""
+    with torch.no_grad():
+        filters, _, _ = calculate_filters([camera], gaussians.get_xyz, gaussians.get_opacity,
+                                          gaussians.get_scaling, gaussians.get_rotation)
+        f = filters[0]
+        xyz = gaussians._xyz.detach()[f]
+        opa = gaussians.opacity_activation(gaussians._opacity.detach()[f])
+        sca = gaussians.scaling_activation(gaussians._scaling.detach()[f])
+        rot = gaussians.rotation_activation(gaussians._rotation.detach()[f])
+        shs = torch.empty((f.shape[0], 48), device=xyz.device)
+        send_shs2gpu_stream(shs, gaussians._parameters.data, f)
+        image, _, _ = pipeline_forward_one_step(opa, sca, rot, xyz, shs, camera, scene, gaussians,
+                                                background, None, eval=True)
+    return image

@@ -1,0 +1,191 @@
+"""GaussianModelCLMOffload (reference: strategies/clm_offload/gaussian_model.py:18-851).
+
+xyz / opacity / scaling / rotation are GPU parameters; the 48 SH floats per Gaussian are ONE
+row of a pre-allocated [capacity,48] buffer with a twin gradient buffer and twin Adam-state
+buffers.  Where those buffers live is the MI355X re-sizing of the CLM split:
+
+  sh_residency == "hbm"  (default): all four buffers in HBM -- 28 M Gaussians need 21.5 GB,
+      102 M need 78 GB, both fit a 288 GB MI355X; the row-sparse Adam runs on the GPU.
+  sh_residency == "host": pinned (hipHostMalloc, device-mapped) host buffers exactly like the
+      reference; zero-copy gather/scatter kernels on the comm stream + host Adam thread.
+The attribute surface (parameters_buffer, parameters_grad_buffer, _parameters, _features_dc/
+_rest as split views, all_parameters() order, optimizer.gpu_adam/.cpu_adam/.columns_lr) is
+the reference's, so the engine and train loop read the same in both modes.
+"""
+import torch
+from torch import nn
+
+from ... import utils
+from ...host import pinned_empty
+from ...optimizer import UnifiedAdam
+from ..base_gaussian_model import BaseGaussianModel
+
+_ROW_BUFFERS = ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer")
+
+
+class GaussianModelCLMOffload(BaseGaussianModel):
+    _GPU_GROUPS = (("xyz", "_xyz"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                   ("rotation", "_rotation"))
+
+    # ------------------------------------------------------------- storage
+    @property
+    def sh_on_host(self):
+        return getattr(self.args, "sh_residency", "hbm") == "host"
+
+    def _alloc_rows(self, capacity):
+        if self.sh_on_host:
+            return pinned_empty((capacity, 48))
+        return torch.empty((capacity, 48), dtype=torch.float32, device="cuda")
+
+    def _capacity_for(self, n):
+        cap = int(getattr(self.args, "prealloc_capacity", -1))
+        if cap <= 0:
+            cap = n
+        assert cap >= n, f"prealloc_capacity {cap} < number of gaussians {n}"
+        return cap
+
+    def _bind_rows(self, n):
+        """(Re)create the [:n] views after the row count changed."""
+        self._parameters = nn.Parameter(self.parameters_buffer[:n].requires_grad_(True))
+        self._features_dc, self._features_rest = torch.split(self._parameters, [3, 45], dim=1)
+
+    @property
+    def get_features(self):
+        return self._parameters.detach().reshape(-1, 16, 3)
+
+    def create_from_tensors(self, xyz, shs48, scaling, rotation, opacity, spatial_lr_scale=1.0):
+        self.spatial_lr_scale = spatial_lr_scale
+        n = xyz.shape[0]
+        cap = self._capacity_for(n)
+        self.parameters_buffer = self._alloc_rows(cap)
+        if not self.only_for_rendering:
+            self.parameters_grad_buffer = self._alloc_rows(cap)
+            self.parameters_grad_buffer.zero_()
+        self.parameters_buffer[:n].copy_(shs48.reshape(n, 48).float())
+        self._xyz = nn.Parameter(xyz.float().cuda().contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(scaling.float().cuda().contiguous().requires_grad_(True))
+        self._rotation = nn.Parameter(rotation.float().cuda().contiguous().requires_grad_(True))
+        self._opacity = nn.Parameter(opacity.float().cuda().contiguous().requires_grad_(True))
+        self._bind_rows(n)
+        self.max_radii2D = torch.zeros((n,), device="cuda")
+
+    def all_parameters(self):
+        # the engine relies on "first 4 are GPU" (clm_offload/engine.py:870)
+        return [self._xyz, self._opacity, self._scaling, self._rotation, self._parameters]
+
+    # ----------------------------------------------------------- optimiser
+    def training_setup(self, training_args):
+        self.percent_dense = training_args.percent_dense
+        n = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device="cuda")
+        self.denom = torch.zeros((n, 1), device="cuda")
+        a = self.args
+        l = [
+            {"params": [self._xyz], "lr": training_args.position_lr_init * self.spatial_lr_scale * a.lr_scale_pos_and_scale, "name": "xyz"},
+            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": training_args.scaling_lr * a.lr_scale_pos_and_scale, "name": "scaling"},
+            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
+            {"params": [self._parameters], "lr": training_args.feature_lr, "name": "parameters"},
+        ]
+        cap = self.parameters_buffer.shape[0]
+        self._exp_avg_buffer = self._alloc_rows(cap).zero_()
+        self._exp_avg_sq_buffer = self._alloc_rows(cap).zero_()
+        self.optimizer = UnifiedAdam(
+            l, [3, 45], [training_args.feature_lr, training_args.feature_lr / 20.0], lr=0.0,
+            bias_correction=True, betas=(0.9, 0.999), eps=1e-15, fused=True, sparse=a.sparse_adam,
+            state_tensors=(self._exp_avg_buffer[:n], self._exp_avg_sq_buffer[:n]))
+        lr_scale = self._scale_groups_for_bsz(training_args)
+        if training_args.lr_scale_mode in ("linear", "sqrt"):
+            self.optimizer.columns_lr *= lr_scale
+
+    def _rebind_row_state(self, n):
+        """Point the row optimizer at the [:n] views after append / prune."""
+        old = self._parameters
+        opt = self.optimizer.cpu_adam
+        st = opt.state.pop(old, None)
+        self._bind_rows(n)
+        opt.param_groups[0]["params"][0] = self._parameters
+        if st is None:
+            st = {"step": opt.global_step}
+        st["exp_avg"] = self._exp_avg_buffer[:n]
+        st["exp_avg_sq"] = self._exp_avg_sq_buffer[:n]
+        opt.state[self._parameters] = st
+        self.optimizer.state = self.optimizer.gpu_adam.state | self.optimizer.cpu_adam.state
+
+    def _replace_gpu(self, name, attr, new_tensor, state_fn):
+        opt = self.optimizer.gpu_adam
+        for g in opt.param_groups:
+            if g["name"] != name:
+                continue
+            old = g["params"][0]
+            st = opt.state.get(old, None)
+            if st is not None:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st:
+                        st[k] = state_fn(st[k])
+                del opt.state[old]
+            g["params"][0] = nn.Parameter(new_tensor.requires_grad_(True))
+            if st is not None:
+                opt.state[g["params"][0]] = st
+            setattr(self, attr, g["params"][0])
+            return
+        raise KeyError(name)
+
+    def _grow(self, need):
+        cap = self.parameters_buffer.shape[0]
+        if need <= cap:
+            return
+        new_cap = max(need, int(cap * 1.5))
+        n = self._parameters.shape[0]
+        for attr in _ROW_BUFFERS:
+            old = getattr(self, attr)
+            new = self._alloc_rows(new_cap)
+            new[:n].copy_(old[:n])
+            if attr != "parameters_buffer":
+                new[n:].zero_()
+            setattr(self, attr, new)
+
+    def _append_rows(self, new):
+        k = new["xyz"].shape[0]
+        n = self._parameters.shape[0]
+        self._grow(n + k)
+        self.parameters_buffer[n:n + k].copy_(new["shs48"])
+        self.parameters_grad_buffer[n:n + k].zero_()
+        self._exp_avg_buffer[n:n + k].zero_()
+        self._exp_avg_sq_buffer[n:n + k].zero_()
+        ext = {"xyz": new["xyz"], "opacity": new["opacity"], "scaling": new["scaling"],
+               "rotation": new["rotation"]}
+        for name, attr in self._GPU_GROUPS:
+            cur = getattr(self, attr).detach()
+            e = ext[name]
+            self._replace_gpu(name, attr, torch.cat((cur, e), dim=0),
+                              lambda s, e=e: torch.cat((s, torch.zeros_like(e)), dim=0))
+        self._rebind_row_state(n + k)
+
+    def prune_points(self, mask):
+        keep = ~mask
+        n = self._parameters.shape[0]
+        m = int(keep.sum())
+        keep_rows = keep.cpu() if self.sh_on_host else keep
+        for attr in _ROW_BUFFERS:
+            buf = getattr(self, attr)
+            buf[:m].copy_(buf[:n][keep_rows])  # in-place compaction (clm/gaussian_model.py:566-570)
+        for name, attr in self._GPU_GROUPS:
+            cur = getattr(self, attr).detach()
+            self._replace_gpu(name, attr, cur[keep].contiguous(), lambda s: s[keep].contiguous())
+        self._rebind_row_state(m)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    def _shs48_rows(self, mask):
+        p = self._parameters.detach()
+        if mask is None:
+            return p.clone() if p.is_cuda else p.cuda()
+        if self.sh_on_host:
+            return p[mask.cpu()].cuda()
+        return p[mask]
+
+    def reset_opacity(self):
+        new = utils.inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))
+        self._replace_gpu("opacity", "_opacity", new, lambda s: torch.zeros_like(s))

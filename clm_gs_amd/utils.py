@@ -1,0 +1,175 @@
+"""Process-wide run state and small host helpers the engines read.
+
+Mirrors the accessor names of the reference's utils/general_utils.py:23-100
+(get_args, get_img_width/height, get_cur_iter, get_log_file, get_timers) and
+restates check_update_at_this_iter (:130-142), inverse_sigmoid (:145-146) and
+get_expon_lr_func (:259-292) so engine code reads like the reference's.
+"""
+import io
+import math
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ARGS = None
+LOG_FILE = None
+CUR_ITER = 0
+IMG_W = 0
+IMG_H = 0
+TIMERS = None
+DENSIFY_ITER = 0
+
+
+def default_args(**over):
+    """Flag names and defaults of arguments/__init__.py (the subset the hot path reads)."""
+    a = SimpleNamespace(
+        # AuxiliaryParams (arguments/__init__.py:60-150)
+        no_offload=False, naive_offload=False, clm_offload=False, prealloc_capacity=-1,
+        comm_stream_priority=-1, grid_size_H=32, grid_size_D=128,
+        reorder_by_min_sparsity_at_end=True, sparse_adam=False, gpu=0, packed=False,
+        # ModelParams
+        sh_degree=3, radius_clip=0.0, white_background=False,
+        # OptimizationParams (:194-235)
+        iterations=30_000, position_lr_init=0.00016, position_lr_final=0.0000016,
+        position_lr_delay_mult=0.01, position_lr_max_steps=30_000, feature_lr=0.0025,
+        opacity_lr=0.05, scaling_lr=0.005, lr_scale_loss=1.0, lr_scale_pos_and_scale=1.0,
+        rotation_lr=0.001, percent_dense=0.01, lambda_dssim=0.2, densification_interval=100,
+        opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=15_000,
+        densify_grad_threshold=0.0002, disable_auto_densification=False, min_opacity=0.005,
+        lr_scale_mode="sqrt", bsz=1, exact_filter=True, log_cpu_adam_trailing_overhead=False,
+        # Debug
+        stop_update_param=False, drop_initial_3dgs_p=0.0,
+        # this build: where the SH rows + their optimizer state live
+        sh_residency="hbm",
+    )
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+class _NullLog(io.StringIO):
+    def write(self, s):
+        return len(s)
+
+
+class Timers:
+    def __init__(self):
+        self.t = {}
+        self.acc = {}
+
+    def start(self, k):
+        self.t[k] = time.perf_counter()
+
+    def stop(self, k):
+        if k in self.t:
+            self.acc[k] = self.acc.get(k, 0.0) + time.perf_counter() - self.t.pop(k)
+
+
+def set_args(a):
+    global ARGS
+    ARGS = a
+
+
+def get_args():
+    global ARGS
+    if ARGS is None:
+        ARGS = default_args()
+    return ARGS
+
+
+def set_log_file(f):
+    global LOG_FILE
+    LOG_FILE = f
+
+
+def get_log_file():
+    global LOG_FILE
+    if LOG_FILE is None:
+        LOG_FILE = _NullLog()
+    return LOG_FILE
+
+
+def set_cur_iter(i):
+    global CUR_ITER
+    CUR_ITER = i
+
+
+def get_cur_iter():
+    return CUR_ITER
+
+
+def set_img_size(h, w):
+    global IMG_H, IMG_W
+    IMG_H, IMG_W = int(h), int(w)
+
+
+def get_img_width():
+    return IMG_W
+
+
+def get_img_height():
+    return IMG_H
+
+
+def get_timers():
+    global TIMERS
+    if TIMERS is None:
+        TIMERS = Timers()
+    return TIMERS
+
+
+def inc_densify_iter():
+    global DENSIFY_ITER
+    DENSIFY_ITER += 1
+
+
+def check_update_at_this_iter(iteration, bsz, update_interval, update_residual):
+    """True when some image index in [iteration, iteration+bsz) is congruent to
+    update_residual mod update_interval (general_utils.py:130-142)."""
+    lo = iteration % update_interval
+    hi = lo + bsz
+    return (lo <= update_residual < hi) or (lo <= update_residual + update_interval < hi)
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear decay with optional warm-up (general_utils.py:259-292)."""
+
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        return delay * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+
+    return helper
+
+
+def build_rotation(r):
+    """(w,x,y,z) -> R [n,3,3] (general_utils.py:311-334)."""
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
+SH_C0 = 0.28209479177387814
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / SH_C0
+
+
+def SH2RGB(sh):
+    return sh * SH_C0 + 0.5

@@ -140,18 +140,19 @@ int clmgs_set_signal(void* stream, int32_t* signal_pinned, int idx, int32_t valu
  * Row-wise Adam over p,g,m,v [*, cols] with per-column learning rate col_lr[cols] (device).
  * rows: i32/i64 row list or NULL (all n_rows rows in order); mask: u8[n_rows] or NULL
  * (rows with mask==0 are skipped; this is clm_kernels.selective_adam_update).
- * g is multiplied by grad_scale; bias_correction uses the 1-based `step`;
+ * g is multiplied by grad_scale; bias_correction uses the 1-based `step`; betas/eps are
+ * doubles so 1-beta and beta^step are formed in double on the host;
  * zero_grad != 0 clears consumed gradient rows. */
 int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const void* rows,
                     int idx_is_64, const uint8_t* mask, int64_t n_rows, int cols,
-                    const float* col_lr, float beta1, float beta2, float eps, int step,
+                    const float* col_lr, double beta1, double beta2, double eps, int step,
                     int bias_correction, float grad_scale, int zero_grad);
 /* Host (OpenMP) variant on pinned/pageable host memory: cpu_adam.FusedCPUAdam row group
  * update (clm_offload/engine.py:316-328).  If signal != NULL, busy-waits until
  * *signal != 0 before touching the rows. */
 int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, const int32_t* rows,
-                         int64_t n_rows, int cols, const float* col_lr, float beta1, float beta2,
-                         float eps, int step, int bias_correction, float grad_scale,
+                         int64_t n_rows, int cols, const float* col_lr, double beta1,
+                         double beta2, double eps, int step, int bias_correction, float grad_scale,
                          int zero_grad, const volatile int32_t* signal, int n_threads);
 
 /* ---- densification statistics  (clm_offload/gaussian_model.py:833-851;
