@@ -1,0 +1,307 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/s (+ peak GPU bytes) of the clm_offload hot path on a
+seeded synthetic Rubble-4K-shaped scene (BASELINE.json: 28 M Gaussians, 4608x3456, bsz 4).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of `bsz` cameras
+(clm_offload_train_one_batch: visibility filters -> per camera projection / SH / tile binning
++ sort / rasterize / loss / backward -> Adam).  N > 1: one process per GPU (launched by
+torch.distributed.run), camera data parallel, weak scaling (every rank renders its own bsz
+cameras; one gradient exchange per batch over RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (N gaussians, W, H, bsz, visible fraction per camera, description)
+    "rubble28m": (28_000_000, 4608, 3456, 4, 0.10, "Rubble-4K 28M Gaussians, clm_offload, 1xMI355X (paper headline row)"),
+    "rubble10m": (10_000_000, 4608, 3456, 4, 0.15, "Rubble-4K 10M Gaussians, clm_offload"),
+    "bicycle6m": (6_000_000, 1237, 822, 4, 0.25, "MipNeRF360 Bicycle ~6M Gaussians"),
+    "small": (200_000, 640, 480, 4, 0.3, "CI-size smoke configuration"),
+}
+
+# algorithmic bytes per launch of each kernel: n rows in, V visible, I
+# intersections, P pixels, T tiles.  Used for roofline.achieved = bytes / measured duration.
+ALGO_BYTES = {
+    "clmgs_projection_fwd": lambda n, V, I, P, T: 68 * n,
+    "clmgs_projection_bwd": lambda n, V, I, P, T: 132 * n,
+    "clmgs_sh_fwd": lambda n, V, I, P, T: 216 * V,
+    "clmgs_sh_bwd": lambda n, V, I, P, T: 420 * V,
+    "clmgs_isect_count": lambda n, V, I, P, T: 28 * n,
+    "clmgs_isect_emit_sort": lambda n, V, I, P, T: (12 + 8 + 24 * 6) * I,
+    "clmgs_isect_offsets": lambda n, V, I, P, T: 8 * I + 4 * T,
+    "clmgs_rasterize_fwd": lambda n, V, I, P, T: 40 * I + 20 * P,
+    "clmgs_rasterize_bwd": lambda n, V, I, P, T: 76 * I + 24 * P,
+    "clmgs_ssim_fwd": lambda n, V, I, P, T: (12 + 12 + 36) * P,
+    "clmgs_ssim_bwd": lambda n, V, I, P, T: (36 + 24 + 12) * P,
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="rubble28m", choices=sorted(CONFIGS))
+    ap.add_argument("--strategy", default="clm_offload", choices=["clm_offload", "no_offload"])
+    ap.add_argument("--residency", default="hbm", choices=["hbm", "host"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_gt_images(cams, scene, args_ns, width, height):
+    """GT = render of a perturbed copy (xyz + N(0, 0.05^2)) quantised to uint8."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
+
+    g = torch.Generator(device="cuda").manual_seed(99)
+    gt_model = GaussianModelCLMOffload(3, only_for_rendering=True)
+    xyz = scene["xyz"] + torch.randn(scene["xyz"].shape, generator=g, device="cuda") * 0.05
+    gt_model.create_from_tensors(xyz, scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"])
+    gt_model.active_sh_degree = 3
+    for c in cams:
+        img = clm_offload_eval_one_cam(c, gt_model, None, None)
+        c.original_image = (img.clamp(0, 1) * 255.0).round().to(torch.uint8)
+    del gt_model
+    torch.cuda.empty_cache()
+
+
+def cpu_baseline(gaussians, cam, width, height, budget_s):
+    """C oracle (OpenMP port) on a bounded sample: one micro-batch (camera 0) of the same scene,
+    cropped to a centred window sized to ~budget_s of CPU work; forward + loss + backward."""
+    import numpy as np
+
+    from clm_gs_amd.strategies.base_engine import calculate_filters
+    from oracle import c_oracle as C
+
+    with torch.no_grad():
+        filters, _, _ = calculate_filters([cam], gaussians.get_xyz, gaussians.get_opacity,
+                                          gaussians.get_scaling, gaussians.get_rotation)
+        f = filters[0]
+        means = gaussians._xyz.detach()[f].cpu().numpy()
+        quats = gaussians.get_rotation.detach()[f].cpu().numpy()
+        scales = gaussians.get_scaling.detach()[f].cpu().numpy()
+        opac = gaussians.get_opacity.detach()[f].cpu().numpy()
+        p = gaussians._parameters.detach()
+        shs = (p[f] if p.is_cuda else p[f.cpu()]).cpu().numpy()
+        viewmat = cam.world_view_transform.t().contiguous().cpu().numpy()
+        K = cam.K.cpu().numpy().copy()
+        gt = cam.original_image.cpu().numpy()
+
+    def run(cw, ch):
+        x0, y0 = (width - cw) // 2 // 16 * 16, (height - ch) // 2 // 16 * 16
+        Kc = K.copy()
+        Kc[0, 2] -= x0
+        Kc[1, 2] -= y0
+        gtc = np.ascontiguousarray(gt[:, y0:y0 + ch, x0:x0 + cw])
+        t0 = time.perf_counter()
+        fw = C.render_forward(means, quats, scales, opac, shs, 3, viewmat, Kc, cw, ch)
+        C.loss_and_backward(fw, gtc)
+        return time.perf_counter() - t0, fw["n_isects"], int((fw["radii"] > 0).sum())
+
+    cw, ch = min(width, 512), min(height, 384)
+    t_cal, _, _ = run(cw, ch)  # calibration crop
+    frac = (cw * ch) / float(width * height)
+    scale = max(1.0, min(1.0 / frac, budget_s / max(t_cal, 1e-3)))
+    s = math.sqrt(scale)
+    cw2, ch2 = min(width, int(cw * s) // 16 * 16), min(height, int(ch * s) // 16 * 16)
+    t, isects, vis = run(cw2, ch2)
+    frac2 = (cw2 * ch2) / float(width * height)
+    return {
+        "value": frac2 / t, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
+        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads of {os.cpu_count()} host cores): "
+                   f"1 micro-batch (camera 0, V={len(means)} rows in), centred {cw2}x{ch2} crop = "
+                   f"{frac2:.4f} of the {width}x{height} image, {vis} visible, {isects} intersections, "
+                   f"forward+loss+backward in {t:.2f}s; value = crop fraction / time"),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+
+    from clm_gs_amd import _lib, dp, utils
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+
+    N, W, H, bsz, vis_frac, desc = CONFIGS[a.config]
+    args = utils.default_args(bsz=bsz, sh_residency=a.residency)
+    setattr(args, a.strategy, True)
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    torch.manual_seed(0)
+
+    scene = synth_gaussians(N, seed=0, device="cuda")
+    n_batches = a.warmup + a.steps
+    # weak scaling: every rank owns its own cameras (seeded by rank)
+    all_cams = nadir_cameras(n_batches * bsz * world, N, W, H, vis_frac, seed=0, device="cuda")
+    cams = all_cams[rank::world]
+    make_gt_images(cams, scene, args, W, H)
+
+    if a.strategy == "clm_offload":
+        from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+        gaussians = GaussianModelCLMOffload(3)
+    else:
+        from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload, baseline_accumGrads_impl
+        gaussians = GaussianModelNoOffload(3)
+    gaussians.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"],
+                                  scene["opacity"], spatial_lr_scale=scene["extent"])
+    extent = scene["extent"]
+    del scene
+    gaussians.active_sh_degree = 3
+    gaussians.training_setup(args)
+    torch.cuda.empty_cache()
+    comm_stream = torch.cuda.Stream()
+    perm_generator = torch.Generator(device="cuda").manual_seed(1)
+
+    class _Scene:
+        cameras_extent = extent
+
+    state = {"iteration": 1}
+
+    def step(batch_idx):
+        batch = cams[batch_idx * bsz:(batch_idx + 1) * bsz]
+        utils.set_cur_iter(state["iteration"])
+        gaussians.update_learning_rate(state["iteration"])
+        if a.strategy == "clm_offload":
+            losses, _, sparsity = clm_offload_train_one_batch(
+                gaussians, _Scene, batch, gaussians.parameters_grad_buffer, None, None, comm_stream,
+                perm_generator)
+        else:
+            losses, _ = baseline_accumGrads_impl(gaussians, _Scene, batch, None)
+            for p in gaussians.all_parameters():
+                if p.grad is not None:
+                    p.grad /= bsz
+            gaussians.optimizer.step()
+            gaussians.optimizer.zero_grad(set_to_none=True)
+            sparsity = None
+        state["iteration"] += bsz
+        return losses, sparsity
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for b in range(a.warmup):
+        step(b)
+    fence()
+    torch.cuda.reset_peak_memory_stats()
+    if not a.no_kernel_timing:
+        _lib.TIMING = {}
+    _lib.STATS["n_isects"].clear()
+    sparsities = []
+    t0 = time.perf_counter()
+    for b in range(a.warmup, a.warmup + a.steps):
+        losses, sp = step(b)
+        if sp:
+            sparsities += sp
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    peak = torch.cuda.max_memory_allocated()
+    timing = _lib.timing_summary()
+    _lib.TIMING = None
+    n_images = a.steps * bsz
+    isects = _lib.STATS["n_isects"][-n_images:] if a.strategy == "clm_offload" else _lib.STATS["n_isects"]
+    I_avg = sum(isects) / max(1, len(isects))
+    V_avg = (sum(sparsities) / max(1, len(sparsities))) * N if sparsities else float(N)
+    n_rows = V_avg if a.strategy == "clm_offload" else float(N)
+    P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
+
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+    value = n_images * world / dt
+    kernels = {}
+    for name, (calls, ms) in timing.items():
+        if name in ALGO_BYTES and calls:
+            avg_ms = ms / calls
+            b = ALGO_BYTES[name](n_rows, V_avg, I_avg, P, T)
+            kernels[name] = {"calls": calls, "avg_ms": round(avg_ms, 4),
+                             "algo_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
+                             "share_of_step": round(ms / (dt * 1e3), 4)}
+        elif calls:
+            kernels[name] = {"calls": calls, "avg_ms": round(ms / calls, 4),
+                             "share_of_step": round(ms / (dt * 1e3), 4)}
+    roofline = None
+    if kernels:
+        dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["calls"] * kernels[k]["avg_ms"])
+        ach = kernels[dom]["algo_GBps"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(a.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algo_bytes_per_launch": ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T),
+                    "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
+                    "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "
+                            "HBM fraction is structurally low, pairs/s reported beside it"}
+    # whole-image algorithmic bytes A(image) of SURVEY 8d, for the end-to-end HBM figure
+    p_pass = 6
+    A_img = 228 * n_rows + 636 * V_avg + (220 * V_avg if a.strategy == "clm_offload" else 0) + \
+        (144 + 24 * p_pass) * I_avg + 143 * P + 4 * T
+    adam_img = 1652.0 * N / bsz
+    out = {
+        "metric": "training images/s (Rubble-4K 28M Gaussians clm_offload)" if a.config == "rubble28m"
+        else f"training images/s ({a.config} {a.strategy})",
+        "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
+                   "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
+                   "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
+                   "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac},
+        "peak_gpu_bytes": int(peak),
+        "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
+                     "pixels": P, "tiles": T, "loss_last": float(losses[-1])},
+        "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1),
+                           "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),
+                           "frac_of_8TBps": round((A_img + adam_img) * value / world / 8e12, 5)},
+        "reference_rtx4090_img_s": 4.04 if a.config == "rubble28m" else None,
+        "roofline": roofline, "kernels": kernels,
+    }
+    if not a.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(gaussians, cams[0], W, H, a.cpu_seconds)
+        except Exception as e:  # the baseline is reporting, never the product path
+            out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -48,9 +48,49 @@ SIGNATURES = {
 
 _lib = None
 
+# Optional per-entry-point device timing (bench.py's roofline leg): when TIMING is a dict every
+# stream-taking call is bracketed by two events recorded on the stream it is launched on.
+TIMING = None
+# Data-dependent sizes seen by the front end (intersections per image), for the same purpose.
+STATS = {"n_isects": []}
+
 
 class ClmgsError(RuntimeError):
     pass
+
+
+class _Entry:
+    """One C entry point; times itself on the launch stream when TIMING is enabled."""
+
+    def __init__(self, name, fn, takes_stream):
+        self.name, self.fn, self.takes_stream = name, fn, takes_stream
+
+    def __call__(self, *args):
+        if TIMING is None or not self.takes_stream:
+            return self.fn(*args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = self.fn(*args)
+        e.record()
+        TIMING.setdefault(self.name, []).append((s, e))
+        return rc
+
+
+class _Namespace:
+    pass
+
+
+_NO_STREAM = {"clmgs_version", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
+              "clmgs_isect_sort_temp_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
+              "clmgs_pinned_alloc", "clmgs_pinned_free"}
+
+
+def timing_summary():
+    """name -> (n_calls, total_ms); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, evs in (TIMING or {}).items():
+        out[name] = (len(evs), sum(s.elapsed_time(e) for s, e in evs))
+    return out
 
 
 def lib():
@@ -63,11 +103,13 @@ def lib():
                 "(make -C clm_gs_amd/csrc).  clm_gs_amd has no CPU/eager fallback."
             )
         l = ctypes.CDLL(LIB_PATH)
+        ns = _Namespace()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError = ABI drift, also loud
             fn.restype = res
             fn.argtypes = args
-        _lib = l
+            setattr(ns, name, _Entry(name, fn, name not in _NO_STREAM))
+        _lib = ns
     return _lib
 
 

@@ -1,7 +1,7 @@
 """Densification schedule and per-micro-batch statistics (reference: densification.py:5-147)."""
 import torch
 
-from . import utils
+from . import dp, utils
 from .clm_kernels import densify_stats
 
 
@@ -22,6 +22,7 @@ def gsplat_densification(iteration, scene, gaussians, batched_screenspace_pkg=No
             iteration, args.bsz, args.densification_interval, 0):
         assert not args.stop_update_param
         gaussians.optimizer.zero_grad(set_to_none=True)
+        dp.allreduce_densify_stats(gaussians)  # camera-DP: sum / sum / max over ranks
         timers.start("densify_and_prune")
         size_threshold = 20 if iteration > args.opacity_reset_interval else None
         gaussians.densify_and_prune(args.densify_grad_threshold, args.min_opacity,

@@ -170,6 +170,9 @@ def isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort
                               int(tile_width), int(tile_height), dptr(tiles_per_gauss), dptr(cum),
                               dptr(temp), tb))
     n_isects = int(cum[-1].item())  # data-dependent size: the one host sync of the front end
+    _lib.STATS["n_isects"].append(n_isects)
+    if len(_lib.STATS["n_isects"]) > 4096:
+        del _lib.STATS["n_isects"][:2048]
     isect_ids = torch.empty((n_isects,), dtype=I64, device=dev)
     flatten_ids = torch.empty((n_isects,), dtype=I32, device=dev)
     if n_isects:

@@ -22,7 +22,7 @@ import threading
 
 import torch
 
-from ... import clm_kernels, fast_tsp, utils
+from ... import clm_kernels, dp, fast_tsp, utils
 from ...clm_kernels import (send_shs2cpu_grad_buffer_stream,
                             send_shs2cpu_grad_buffer_stream_retention, send_shs2gpu_stream,
                             send_shs2gpu_stream_retention, spherical_harmonics_bwd_inplace)
@@ -223,6 +223,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
     for f in filters:
         touched[f] = True
+    # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
+    # only globally untouched rows may take the early zero-gradient update
+    touched = dp.allreduce_touched(touched)
     row_adam = gaussians.optimizer.cpu_adam
     params = gaussians._parameters
     grad_buf = parameters_grad_buffer[:N]
@@ -264,6 +267,10 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
+    if dp.world_size() > 1:  # camera-DP: the one exchange of the batch
+        dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
+                                  gaussians._scaling.grad, gaussians._rotation.grad])
+        dp.allreduce_rows(grad_buf, touched)
     _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None)
     if not args.stop_update_param:
         row_update(touched)
