@@ -32,6 +32,9 @@ SIGNATURES = {
     "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "clmgs_loss_slots": (_i, []),
+    "clmgs_l1_ssim_loss_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_l1_ssim_loss_bwd": (_i, [_vp, _i, _i, _vp, _i64, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "clmgs_rows_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i]),
     "clmgs_rows_scatter_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i]),
     "clmgs_scatter_to_bit": (_i, [_vp, _vp, _i, _vp, _i64, _i]),
@@ -80,7 +83,7 @@ class _Namespace:
     pass
 
 
-_NO_STREAM = {"clmgs_version", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
+_NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
               "clmgs_isect_sort_temp_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free"}
 

@@ -22,7 +22,7 @@ class _FusedSSIM(torch.autograd.Function):
         img1, img2 = img1.contiguous(), img2.contiguous()
         B, CH, H, W = img1.shape
         need = img1.requires_grad
-        ssim_sum = torch.zeros((1,), dtype=F32, device=img1.device)
+        ssim_sum = torch.zeros((1024,), dtype=F32, device=img1.device)
         maps = [torch.empty_like(img1) for _ in range(3)] if need else [None, None, None]
         check(L.clmgs_ssim_fwd(stream(), B, CH, H, W, dptr(img1, F32), dptr(img2, F32),
                                dptr(ssim_sum), dptr(maps[0], F32, True), dptr(maps[1], F32, True),
@@ -30,7 +30,7 @@ class _FusedSSIM(torch.autograd.Function):
         ctx.shape = (B, CH, H, W)
         if need:
             ctx.save_for_backward(img1, img2, *maps)
-        return (ssim_sum / float(img1.numel())).reshape(())
+        return ssim_sum.sum() / float(img1.numel())
 
     @staticmethod
     def backward(ctx, v):
@@ -48,6 +48,52 @@ class _FusedSSIM(torch.autograd.Function):
 def fused_ssim(img1, img2):
     """Mean SSIM of [B,CH,H,W] images (11x11, sigma 1.5, zero padded), differentiable in img1."""
     return _FusedSSIM.apply(img1, img2)
+
+
+class _FusedL1SSIMLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt_u8, lambda_dssim):
+        L = _lib.lib()
+        assert image.dim() == 3 and image.shape[0] == 3 and image.dtype == F32 and image.is_cuda
+        _, H, W = image.shape
+        gt_u8 = gt_u8.contiguous()
+        assert gt_u8.dtype == U8 and gt_u8.shape == image.shape
+        need = image.requires_grad
+        slots = L.clmgs_loss_slots()
+        partials = torch.zeros((slots, 2), dtype=F32, device=image.device)
+        maps = torch.empty((3, 3, H, W), dtype=F32, device=image.device) if need else None
+        sc, sy, sx = image.stride()
+        check(L.clmgs_l1_ssim_loss_fwd(stream(), H, W, ctypes.c_void_p(image.data_ptr()), sc, sy, sx,
+                                       dptr(gt_u8, U8), dptr(partials),
+                                       dptr(maps[0] if need else None, F32, True),
+                                       dptr(maps[1] if need else None, F32, True),
+                                       dptr(maps[2] if need else None, F32, True)))
+        tot = partials.sum(dim=0) / float(image.numel())
+        ctx.lam = float(lambda_dssim)
+        if need:
+            ctx.save_for_backward(image, gt_u8, maps)
+        return (1.0 - ctx.lam) * tot[0] + ctx.lam * (1.0 - tot[1])
+
+    @staticmethod
+    def backward(ctx, v):
+        L = _lib.lib()
+        image, gt_u8, maps = ctx.saved_tensors
+        _, H, W = image.shape
+        v = v.reshape(1).to(F32).contiguous()
+        v_img = torch.empty_strided(image.shape, image.stride(), dtype=F32, device=image.device)
+        sc, sy, sx = image.stride()
+        check(L.clmgs_l1_ssim_loss_bwd(stream(), H, W, ctypes.c_void_p(image.data_ptr()), sc, sy, sx,
+                                       dptr(gt_u8, U8), dptr(v, F32), ctx.lam, dptr(maps[0]),
+                                       dptr(maps[1]), dptr(maps[2]),
+                                       ctypes.c_void_p(v_img.data_ptr())))
+        return v_img, None, None
+
+
+def fused_l1_ssim_loss(image, gt_u8, lambda_dssim=0.2):
+    """(1-lambda) * L1 + lambda * (1 - SSIM) of image [3,H,W] (any strides, e.g. a permuted view
+    of the rasterizer's [H,W,3] output) against a uint8 [3,H,W] ground truth; one forward and one
+    backward kernel (strategies/base_engine.py:79-103 semantics)."""
+    return _FusedL1SSIMLoss.apply(image, gt_u8, lambda_dssim)
 
 
 # ------------------------------------------------------------- SH row movement

@@ -4,25 +4,28 @@
 // strategies/clm_offload/engine.py:106-117; arithmetic: SURVEY.md A5/A6).
 //
 // CDNA4 mapping -- NOT the 16x16-threads-per-tile CUDA shape:
-//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels
-//     (column lane&15, rows (lane>>4) + 4k).  A tile's Gaussian record is read
-//     from LDS once per wave and reused for 4 pixels per lane, so LDS traffic per
-//     pixel-Gaussian pair is 1/4 of a thread-per-pixel kernel, there is no
-//     multi-wave barrier, and the 4 independent pixels give the exp/fma chain ILP;
-//   * the tile's depth-sorted list is staged 64 records at a time: lane l gathers
-//     record l (id -> mean, conic, opacity, colour) and parks it in LDS;
-//   * backward: each lane first sums its 4 pixels' contributions, then one DPP
-//     wave reduction per Gaussian (row_shr + row_bcast) and ONE set of float
-//     atomics per (Gaussian, tile), issued 64 Gaussians at a time by 64 lanes;
-//   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous
-//     stripe of tiles, so neighbouring tiles' shared Gaussians hit in L2.
+//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels, one in each 8x8
+//     quadrant (lane = 8x8 position).  A tile's Gaussian record is read from LDS once per wave
+//     and reused for up to 4 pixels per lane: LDS traffic per pixel-Gaussian pair is 1/4 of a
+//     thread-per-pixel kernel, there is no multi-wave barrier, and the independent pixels give
+//     the exp/fma chain ILP;
+//   * exact sub-tile culling: the staging lane computes the pixel bounding box of
+//     {alpha >= 1/255} from the conic and opacity and a 4-bit quadrant mask.  Records whose box
+//     misses the tile are compacted away with a ballot/popcount prefix (depth order kept),
+//     quadrants it misses are skipped with wave-uniform branches.  Only pairs the reference
+//     itself skips (alpha < 1/255) are dropped, so results are unchanged;
+//   * backward: each lane first sums its pixels' contributions, then one DPP wave reduction per
+//     Gaussian (row_shr + row_bcast) and ONE set of float atomics per (Gaussian, tile), issued
+//     64 Gaussians at a time by 64 lanes;
+//   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous stripe of tiles,
+//     so neighbouring tiles' shared Gaussians hit in L2.
 #include "common.h"
 #include "gs_math.h"
 
 namespace clmgs {
 
 constexpr int TILE = 16;
-constexpr int PPL = 4;        // pixels per lane
+constexpr int PPL = 4;        // pixels per lane (one per 8x8 quadrant)
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float T_EPS = 1e-4f;
 
@@ -30,13 +33,34 @@ struct TileLds {
   float4 a[64];   // x, y, opacity, conic.a
   float4 b[64];   // conic.b, conic.c, r, g
   float c[64];    // b
-  int id[64];     // Gaussian id (cam*N + g)
+  int meta[64];   // (offset in staging round << 4) | quadrant mask
 };
 
 __device__ __forceinline__ void tile_range(const int32_t* __restrict__ offsets, int tile,
                                            int n_tiles_total, int64_t n_isects, int& s, int& e) {
   s = offsets[tile];
   e = (tile == n_tiles_total - 1) ? (int)n_isects : offsets[tile + 1];
+}
+
+// Quadrant mask of the pixels (centres) where alpha can reach 1/255:
+// sigma <= L = ln(255 o)  =>  |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
+__device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, float ca, float cb,
+                                             float cc, float tile_x0, float tile_y0) {
+  if (!(opac >= ALPHA_MIN)) return 0;
+  const float L = __logf(255.f * opac);
+  const float det = ca * cc - cb * cb;
+  if (!(det > 0.f)) return 15;  // degenerate conic: never cull
+  const float s = 2.f * L / det;
+  const float ex = sqrtf(fmaxf(s * cc, 0.f)) * 1.0001f + 1e-3f;
+  const float ey = sqrtf(fmaxf(s * ca, 0.f)) * 1.0001f + 1e-3f;
+  if (!(ex == ex) || !(ey == ey)) return 15;
+  const float xl = mx - ex, xh = mx + ex, yl = my - ey, yh = my + ey;
+  // quadrant q covers pixel centres [q0 + 0.5, q0 + 7.5]
+  const bool x0 = (xh >= tile_x0 + 0.5f) && (xl <= tile_x0 + 7.5f);
+  const bool x1 = (xh >= tile_x0 + 8.5f) && (xl <= tile_x0 + 15.5f);
+  const bool y0 = (yh >= tile_y0 + 0.5f) && (yl <= tile_y0 + 7.5f);
+  const bool y1 = (yh >= tile_y0 + 8.5f) && (yl <= tile_y0 + 15.5f);
+  return (int)(x0 && y0) | ((int)(x1 && y0) << 1) | ((int)(x0 && y1) << 2) | ((int)(x1 && y1) << 3);
 }
 
 __global__ void __launch_bounds__(64)
@@ -54,17 +78,17 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   const int t_in = tile - cam * n_tiles;
   const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
   const int lane = threadIdx.x;
-  const int j = tx * TILE + (lane & 15);
-  const int i0 = ty * TILE + (lane >> 4);
-  const float px = (float)j + 0.5f;
+  const int qx = lane & 7, qy = lane >> 3;
+  const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
-  float T[PPL], cr[PPL], cg[PPL], cb[PPL], py[PPL];
+  float T[PPL], cr[PPL], cg[PPL], cb[PPL], px[PPL], py[PPL];
   int last[PPL];
   bool alive[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = i0 + 4 * k;
-    py[k] = (float)i + 0.5f;
+    const int j = tx * TILE + 8 * (k & 1) + qx;
+    const int i = ty * TILE + 8 * (k >> 1) + qy;
+    px[k] = (float)j + 0.5f; py[k] = (float)i + 0.5f;
     T[k] = 1.f; cr[k] = cg[k] = cb[k] = 0.f; last[k] = 0;
     alive[k] = (i < H) && (j < W);
   }
@@ -77,47 +101,51 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
 #pragma unroll
     for (int k = 0; k < PPL; ++k) any_alive |= alive[k];
     if (!__any(any_alive)) break;
-    __syncthreads();
     const int idx = bs + lane;
+    int mask = 0;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+    float blue = 0.f;
     if (idx < re) {
       const int g = flatten_ids[idx];
       const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
       const float* cn = conics + 3 * (size_t)g;
       const float* cl = colors + 3 * (size_t)g;
-      sm.a[lane] = make_float4(m.x, m.y, opacities[g], cn[0]);
-      sm.b[lane] = make_float4(cn[1], cn[2], cl[0], cl[1]);
-      sm.c[lane] = cl[2];
+      A = make_float4(m.x, m.y, opacities[g], cn[0]);
+      B = make_float4(cn[1], cn[2], cl[0], cl[1]);
+      blue = cl[2];
+      mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
+    }
+    const unsigned long long bal = __ballot(mask != 0);
+    const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    const int bn = __popcll(bal);
+    __syncthreads();
+    if (mask) {
+      sm.a[pos] = A; sm.b[pos] = B; sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
     }
     __syncthreads();
-    const int bn = min(64, re - bs);
     for (int t = 0; t < bn; ++t) {
-      const float4 A = sm.a[t];
-      const float4 B = sm.b[t];
-      float alpha[PPL];
-      bool valid[PPL];
-      bool any_valid = false;
-      const float dx = A.x - px;
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const float dy = A.y - py[k];
-        const float sigma = 0.5f * (A.w * dx * dx + B.y * dy * dy) + B.x * dx * dy;
-        alpha[k] = fminf(0.999f, A.z * __expf(-sigma));
-        valid[k] = alive[k] && (sigma >= 0.f) && (alpha[k] >= ALPHA_MIN);
-        any_valid |= valid[k];
-      }
-      if (!__any(any_valid)) continue;
-      const float blue = sm.c[t];
+      const float4 RA = sm.a[t];
+      const float4 RB = sm.b[t];
+      const int meta = __builtin_amdgcn_readfirstlane(sm.meta[t]);
+      const float rblue = sm.c[t];
+      const int gi = bs + (meta >> 4);
       bool still = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const float next_T = T[k] * (1.f - alpha[k]);
-        const bool term = valid[k] && (next_T <= T_EPS);
-        const bool acc = valid[k] && !term;
-        const float vis = acc ? alpha[k] * T[k] : 0.f;
-        cr[k] += B.z * vis; cg[k] += B.w * vis; cb[k] += blue * vis;
-        T[k] = acc ? next_T : T[k];
-        last[k] = acc ? (bs + t) : last[k];
-        alive[k] = alive[k] && !term;
+        if (meta & (1 << k)) {  // wave-uniform: this quadrant can be touched
+          const float dx = RA.x - px[k], dy = RA.y - py[k];
+          const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
+          const float alpha = fminf(0.999f, RA.z * __expf(-sigma));
+          const bool valid = alive[k] && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
+          const float next_T = T[k] * (1.f - alpha);
+          const bool term = valid && (next_T <= T_EPS);
+          const bool acc = valid && !term;
+          const float vis = acc ? alpha * T[k] : 0.f;
+          cr[k] += RB.z * vis; cg[k] += RB.w * vis; cb[k] += rblue * vis;
+          T[k] = acc ? next_T : T[k];
+          last[k] = acc ? gi : last[k];
+          alive[k] = alive[k] && !term;
+        }
         still |= alive[k];
       }
       if (!__any(still)) break;
@@ -128,7 +156,8 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = i0 + 4 * k;
+    const int j = tx * TILE + 8 * (k & 1) + qx;
+    const int i = ty * TILE + 8 * (k >> 1) + qy;
     if (i < H && j < W) {
       const size_t pix = ((size_t)cam * H + i) * W + j;
       render_colors[3 * pix] = cr[k] + T[k] * bgr;
@@ -144,7 +173,8 @@ struct TileLdsBwd {
   float4 a[64];
   float4 b[64];
   float c[64];
-  int id[64];
+  int meta[64];
+  int id[64];        // Gaussian id (cam*N + g) of the compacted slot
   float acc[64][9];  // reduced per-Gaussian gradient of this tile
 };
 
@@ -167,15 +197,14 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   const int t_in = tile - cam * n_tiles;
   const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
   const int lane = threadIdx.x;
-  const int j = tx * TILE + (lane & 15);
-  const int i0 = ty * TILE + (lane >> 4);
-  const float px = (float)j + 0.5f;
+  const int qx = lane & 7, qy = lane >> 3;
+  const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
   int rs, re;
   tile_range(offsets, tile, n_tiles_total, n_isects, rs, re);
   if (re <= rs) return;
 
-  float T[PPL], Tf[PPL], py[PPL], vr[PPL], vg[PPL], vb[PPL], va[PPL];
+  float T[PPL], Tf[PPL], px[PPL], py[PPL], vr[PPL], vg[PPL], vb[PPL], va[PPL];
   float br[PPL], bg_[PPL], bb[PPL];  // running sum of colour behind the current Gaussian
   int bin[PPL];
   bool inside[PPL];
@@ -184,8 +213,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = i0 + 4 * k;
-    py[k] = (float)i + 0.5f;
+    const int j = tx * TILE + 8 * (k & 1) + qx;
+    const int i = ty * TILE + 8 * (k >> 1) + qy;
+    px[k] = (float)j + 0.5f; py[k] = (float)i + 0.5f;
     inside[k] = (i < H) && (j < W);
     br[k] = bg_[k] = bb[k] = 0.f;
     if (inside[k]) {
@@ -206,64 +236,70 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   const int hi = min(re - 1, max_bin);  // nothing behind the deepest contributor matters
 
   for (int bh = hi; bh >= rs; bh -= 64) {
-    __syncthreads();
     const int idx = bh - lane;
+    int mask = 0, gid = 0;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+    float blue = 0.f;
     if (idx >= rs) {
-      const int g = flatten_ids[idx];
-      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
-      const float* cn = conics + 3 * (size_t)g;
-      const float* cl = colors + 3 * (size_t)g;
-      sm.a[lane] = make_float4(m.x, m.y, opacities[g], cn[0]);
-      sm.b[lane] = make_float4(cn[1], cn[2], cl[0], cl[1]);
-      sm.c[lane] = cl[2];
-      sm.id[lane] = g;
+      gid = flatten_ids[idx];
+      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)gid);
+      const float* cn = conics + 3 * (size_t)gid;
+      const float* cl = colors + 3 * (size_t)gid;
+      A = make_float4(m.x, m.y, opacities[gid], cn[0]);
+      B = make_float4(cn[1], cn[2], cl[0], cl[1]);
+      blue = cl[2];
+      mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
+    }
+    const unsigned long long bal = __ballot(mask != 0);
+    const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    const int bn = __popcll(bal);
+    __syncthreads();
+    if (mask) {
+      sm.a[pos] = A; sm.b[pos] = B; sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
+      sm.id[pos] = gid;
     }
     __syncthreads();
-    const int bn = min(64, bh - rs + 1);
     unsigned long long touched = 0ull;
     for (int t = 0; t < bn; ++t) {
-      const int gi = bh - t;
-      const float4 A = sm.a[t];
-      const float4 B = sm.b[t];
-      const float dx = A.x - px;
-      float alpha[PPL], gex[PPL], dy[PPL];
-      bool valid[PPL];
+      const float4 RA = sm.a[t];
+      const float4 RB = sm.b[t];
+      const int meta = __builtin_amdgcn_readfirstlane(sm.meta[t]);
+      const float rblue = sm.c[t];
+      const int gi = bh - (meta >> 4);
+      float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_x = 0.f,
+            g_y = 0.f, g_o = 0.f;
       bool any_valid = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        dy[k] = A.y - py[k];
-        const float sigma = 0.5f * (A.w * dx * dx + B.y * dy[k] * dy[k]) + B.x * dx * dy[k];
-        gex[k] = __expf(-sigma);
-        alpha[k] = fminf(0.999f, A.z * gex[k]);
-        valid[k] = inside[k] && (gi <= bin[k]) && (sigma >= 0.f) && (alpha[k] >= ALPHA_MIN);
-        any_valid |= valid[k];
-      }
-      if (!__any(any_valid)) continue;
-      const float blue = sm.c[t];
-      float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_x = 0.f,
-            g_y = 0.f, g_o = 0.f;
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        if (valid[k]) {
-          const float ra = 1.f / (1.f - alpha[k]);
-          T[k] *= ra;
-          const float fac = alpha[k] * T[k];
-          g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
-          float v_alpha = (B.z * T[k] - br[k] * ra) * vr[k] + (B.w * T[k] - bg_[k] * ra) * vg[k] +
-                          (blue * T[k] - bb[k] * ra) * vb[k];
-          v_alpha += Tf[k] * ra * va[k];
-          if (A.z * gex[k] <= 0.999f) {
-            const float v_sigma = -A.z * gex[k] * v_alpha;
-            g_ca += 0.5f * v_sigma * dx * dx;
-            g_cb += v_sigma * dx * dy[k];
-            g_cc += 0.5f * v_sigma * dy[k] * dy[k];
-            g_x += v_sigma * (A.w * dx + B.x * dy[k]);
-            g_y += v_sigma * (B.x * dx + B.y * dy[k]);
-            g_o += gex[k] * v_alpha;
+        if (meta & (1 << k)) {  // wave-uniform
+          const float dx = RA.x - px[k], dy = RA.y - py[k];
+          const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
+          const float gex = __expf(-sigma);
+          const float alpha = fminf(0.999f, RA.z * gex);
+          const bool valid = inside[k] && (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
+          if (valid) {
+            any_valid = true;
+            const float ra = 1.f / (1.f - alpha);
+            T[k] *= ra;
+            const float fac = alpha * T[k];
+            g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
+            float v_alpha = (RB.z * T[k] - br[k] * ra) * vr[k] + (RB.w * T[k] - bg_[k] * ra) * vg[k] +
+                            (rblue * T[k] - bb[k] * ra) * vb[k];
+            v_alpha += Tf[k] * ra * va[k];
+            if (RA.z * gex <= 0.999f) {
+              const float v_sigma = -RA.z * gex * v_alpha;
+              g_ca += 0.5f * v_sigma * dx * dx;
+              g_cb += v_sigma * dx * dy;
+              g_cc += 0.5f * v_sigma * dy * dy;
+              g_x += v_sigma * (RA.w * dx + RB.x * dy);
+              g_y += v_sigma * (RB.x * dx + RB.y * dy);
+              g_o += gex * v_alpha;
+            }
+            br[k] += RB.z * fac; bg_[k] += RB.w * fac; bb[k] += rblue * fac;
           }
-          br[k] += B.z * fac; bg_[k] += B.w * fac; bb[k] += blue * fac;
         }
       }
+      if (!__any(any_valid)) continue;
       g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
       g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
       g_x = wave_sum_to_lane63(g_x); g_y = wave_sum_to_lane63(g_y); g_o = wave_sum_to_lane63(g_o);

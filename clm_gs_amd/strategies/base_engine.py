@@ -5,7 +5,7 @@ import math
 import torch
 
 from .. import utils
-from ..clm_kernels import fused_ssim
+from ..clm_kernels import fused_l1_ssim_loss, fused_ssim
 from ..gsplat import (fully_fused_projection, isect_offset_encode, isect_tiles,
                       rasterize_to_pixels, spherical_harmonics, visibility_radii)
 
@@ -42,8 +42,10 @@ def loss_combined(image, image_gt, ssim_loss):
 
 def torch_compiled_loss(image, image_gt_original):
     """0.8 * L1 + 0.2 * (1 - SSIM) against clamp(u8/255) (base_engine.py:79-103).  The
-    reference torch.compile's the mix; here the SSIM is the fused HIP kernel and the mix is
-    three elementwise torch ops."""
+    reference torch.compile's the L1 mix next to a fused SSIM kernel; here the whole loss
+    (u8 -> float GT, L1, SSIM, mix) is one fused HIP kernel each way when the GT is uint8."""
+    if image_gt_original.dtype == torch.uint8:
+        return fused_l1_ssim_loss(image, image_gt_original, LAMBDA_DSSIM)
     image_gt = torch.clamp(image_gt_original / 255.0, 0.0, 1.0)
     ssim_loss = fused_ssim(image.unsqueeze(0), image_gt.unsqueeze(0))
     return loss_combined(image, image_gt, ssim_loss)
@@ -86,5 +88,5 @@ def pipeline_forward_one_step(filtered_opacity_gpu, filtered_scaling_gpu, filter
         means2d=means2D, conics=conics, colors=colors, opacities=opacities,
         image_width=image_width, image_height=image_height, tile_size=TILE_SIZE,
         isect_offsets=isect_offsets, flatten_ids=flatten_ids, backgrounds=backgrounds)
-    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1).contiguous()
+    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1)  # [3,H,W] view, no copy
     return rendered_image, means2D, radiis

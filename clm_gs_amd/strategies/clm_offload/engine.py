@@ -70,7 +70,7 @@ def pipeline_forward_one_step_shs_inplace(filtered_opacity_gpu, filtered_scaling
         means2d=means2D, conics=conics, colors=colors, opacities=opacities,
         image_width=image_width, image_height=image_height, tile_size=TILE_SIZE,
         isect_offsets=isect_offsets, flatten_ids=flatten_ids, backgrounds=backgrounds)
-    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1).contiguous()
+    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1)  # [3,H,W] view, no copy
     return rendered_image, means2D, radiis, colors_detached, dirs
 
 

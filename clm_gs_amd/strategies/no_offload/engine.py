@@ -44,7 +44,7 @@ def baseline_accumGrads_micro_step(means3D, opacities, scales, rotations, shs, s
         means2d=means2D, conics=conics, colors=colors, opacities=opacities.squeeze(1).unsqueeze(0),
         image_width=image_width, image_height=image_height, tile_size=tile_size,
         isect_offsets=isect_offsets, flatten_ids=flatten_ids, backgrounds=background)
-    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1).contiguous()
+    rendered_image = rendered_image.squeeze(0).permute(2, 0, 1)  # [3,H,W] view, no copy
     return rendered_image, means2D, radiis, None
 
 

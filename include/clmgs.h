@@ -100,8 +100,8 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const floa
                         float* v_colors, float* v_opacities);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
- * img1,img2 [B,CH,H,W].  fwd writes the per-pixel SSIM map sum into ssim_sum[1] (caller
- * zeroes it; mean = sum / (B*CH*H*W)) and, when the three dm_* maps are non-NULL, the
+ * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes
+ * it; mean = sum of the 1024 slots / (B*CH*H*W)) and, when the three dm_* maps are non-NULL, the
  * partial derivatives needed by bwd.  bwd writes v_img1 = v_mean[0] * inv_numel * dSSIM_sum/dimg1
  * (v_mean is a DEVICE scalar: the upstream cotangent never visits the host). */
 int clmgs_ssim_fwd(void* stream, int B, int CH, int H, int W, const float* img1,
@@ -110,6 +110,22 @@ int clmgs_ssim_fwd(void* stream, int B, int CH, int H, int W, const float* img1,
 int clmgs_ssim_bwd(void* stream, int B, int CH, int H, int W, const float* img1,
                    const float* img2, const float* v_mean, float inv_numel, const float* dm_dmu1,
                    const float* dm_dsigma1_sq, const float* dm_dsigma12, float* v_img1);
+
+/* ---- fused training loss  (strategies/base_engine.py:79-103: FusedCompiledLoss + loss_combined)
+ * loss = (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM(img, gt)), gt = clamp(gt_u8 / 255).
+ * img is a [3,H,W] VIEW given by its element strides (so the rasterizer's [H,W,3] output is read
+ * in place); gt_u8 is planar [3,H,W].  fwd adds per-block (sum|x-y|, sum SSIM) pairs into
+ * partials[2 * clmgs_loss_slots()] (caller zeroes; total = column sums) and, if m1..m3 != NULL,
+ * writes the three [3,H,W] derivative maps bwd needs.  bwd writes v_img with img's strides;
+ * v_loss is a DEVICE scalar. */
+int clmgs_loss_slots(void);
+int clmgs_l1_ssim_loss_fwd(void* stream, int H, int W, const float* img, int64_t stride_c,
+                           int64_t stride_y, int64_t stride_x, const uint8_t* gt_u8,
+                           float* partials, float* m1, float* m2, float* m3);
+int clmgs_l1_ssim_loss_bwd(void* stream, int H, int W, const float* img, int64_t stride_c,
+                           int64_t stride_y, int64_t stride_x, const uint8_t* gt_u8,
+                           const float* v_loss, float lambda_dssim, const float* m1,
+                           const float* m2, const float* m3, float* v_img);
 
 /* ---- clm_kernels row movers  (clm_offload/engine.py:499-505, 622-636, 789-802, 815-822)
  * dst/src may be device memory or pinned (mapped) host memory.
