@@ -359,3 +359,55 @@ def test_densify_stats(dev):
     acc2[f] += gg.norm(dim=-1, keepdim=True)
     den2[f] += 1
     assert torch.allclose(d[0].cpu(), mr2) and torch.allclose(d[1].cpu(), acc2, atol=1e-5) and torch.allclose(d[2].cpu(), den2)
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (37, 70)])
+@pytest.mark.parametrize("layout", ["chw", "hwc_view"])
+def test_fused_l1_ssim_loss(dev, hw, layout):
+    """strategies/base_engine.py:79-103 in one kernel each way, reading the image through strides."""
+    from clm_gs_amd import clm_kernels as K
+    h, w = hw
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(3, h, w, generator=g)
+    gt = (torch.rand(3, h, w, generator=g) * 255).to(torch.uint8)
+    a0 = img.double().requires_grad_()
+    l0 = O.training_loss(a0, gt)
+    l0.backward()
+    if layout == "chw":
+        leaf = img.to(dev).requires_grad_()
+        view = leaf
+    else:
+        leaf = img.permute(1, 2, 0).contiguous().to(dev).requires_grad_()  # [H,W,3] memory
+        view = leaf.permute(2, 0, 1)
+    l1 = K.fused_l1_ssim_loss(view, gt.to(dev), 0.2)
+    l1.backward()
+    assert abs(l1.item() - l0.item()) < 1e-5
+    got = leaf.grad.cpu() if layout == "chw" else leaf.grad.permute(2, 0, 1).cpu()
+    assert rel_l2(got, a0.grad) < 1e-4
+
+
+def test_rasterize_large_gaussians_and_culling_exactness(dev):
+    """Gaussians spanning many tiles plus tiny ones: the quadrant culling may only drop pairs the
+    reference drops (alpha < 1/255), so image and gradients must still match the oracle."""
+    from clm_gs_amd import gsplat as G
+    w, h = 96, 80
+    s = small_scene(n=300, width=w, height=h, seed=31, log_scale=-0.3)
+    s["scales"][:100] *= 0.05  # sub-pixel splats
+    s["opac"][::7] = 0.004     # below 1/255: never visible
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    _, ids, fids = O.isect_tiles(m2, radii, d, 16, tw, th)
+    off = O.isect_offset_encode(ids, 1, tw, th)
+    g = torch.Generator().manual_seed(2)
+    colors = torch.rand(1, 300, 3, generator=g)
+    opac = s["opac"].reshape(1, -1)
+    a = [t.clone().double().requires_grad_() for t in (m2, cn, colors, opac)]
+    img0, al0 = O.rasterize_to_pixels(*a, w, h, 16, off, fids)
+    b = [t.clone().to(dev).requires_grad_() for t in (m2, cn, colors, opac)]
+    img1, al1 = G.rasterize_to_pixels(*b, w, h, 16, off.to(dev), fids.to(dev))
+    assert psnr(img1.cpu(), img0) > 60 and (img1.cpu() - img0.float()).abs().max() < 2e-4
+    vi = torch.randn(img0.shape, generator=g)
+    (img0 * vi.double()).sum().backward()
+    (img1 * vi.to(dev)).sum().backward()
+    for name, x, y in zip(("means2d", "conics", "colors", "opacities"), b, a):
+        assert rel_l2(x.grad.cpu(), y.grad) < GRAD_TOL, name
