@@ -28,8 +28,11 @@ SIGNATURES = {
     "clmgs_isect_sort_temp_bytes": (_sz, [_i64]),
     "clmgs_isect_emit_sort": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "clmgs_isect_offsets": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
-    "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_rasterize_pack_bytes": (_sz, [_i, _i]),
+    "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_preprocess_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_preprocess_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "clmgs_loss_slots": (_i, []),
@@ -84,7 +87,7 @@ class _Namespace:
 
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
-              "clmgs_isect_sort_temp_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
+              "clmgs_isect_sort_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free"}
 
 

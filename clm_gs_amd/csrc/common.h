@@ -71,6 +71,24 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Four wave-wide sums for the price of ~1.6: gfx950's v_permlane32_swap / v_permlane16_swap fold
+// the 32- and 16-lane levels of TWO values per instruction ("reduce-scatter" butterfly), after
+// which one register carries a,c,b,d in rows 0..3 and four row_shr DPP adds finish all four.
+// Result: lane 15 holds sum(a), lane 31 sum(c), lane 47 sum(b), lane 63 sum(d).
+__device__ __forceinline__ float wave_sum4_rows(float a, float b, float c, float d) {
+  auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const float s1 = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);  // lanes 0-31: a, 32-63: b
+  auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  const float s2 = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);  // lanes 0-31: c, 32-63: d
+  auto r3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
+  float u = __uint_as_float(r3[0]) + __uint_as_float(r3[1]);          // rows: a, c, b, d
+  u = dpp_add<0x111>(u);
+  u = dpp_add<0x112>(u);
+  u = dpp_add<0x114>(u);
+  u = dpp_add<0x118>(u);
+  return u;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = wave_sum_to_lane63(v);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

@@ -19,6 +19,8 @@
 //     64 Gaussians at a time by 64 lanes;
 //   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous stripe of tiles,
 //     so neighbouring tiles' shared Gaussians hit in L2.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gs_math.h"
 
@@ -28,6 +30,43 @@ constexpr int TILE = 16;
 constexpr int PPL = 4;        // pixels per lane (one per 8x8 quadrant)
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float T_EPS = 1e-4f;
+
+// Per-Gaussian raster record, one 64 B line: {x, y, opacity, conic.a | conic.b, conic.c, r, g |
+// b, -, -, - | -}.  The tile kernels gather ONE line per (Gaussian, tile) instead of touching
+// four arrays (measured: 4.6 GB fetched per backward launch vs 1.3 GB algorithmic before).
+constexpr int REC_F4 = 4;
+
+__global__ void __launch_bounds__(256)
+raster_pack_kernel(int64_t n, const float* __restrict__ means2d, const float* __restrict__ conics,
+                   const float* __restrict__ colors, const float* __restrict__ opacities,
+                   float4* __restrict__ packed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * i);
+    const float* cn = conics + 3 * i;
+    const float* cl = colors + 3 * i;
+    float4* rec = packed + REC_F4 * i;
+    rec[0] = make_float4(m.x, m.y, opacities[i], cn[0]);
+    rec[1] = make_float4(cn[1], cn[2], cl[0], cl[1]);
+    rec[2] = make_float4(cl[2], 0.f, 0.f, 0.f);
+  }
+}
+
+// packed_grad line: x y ca cb | cc r g b | o - - - | -
+__global__ void __launch_bounds__(256)
+raster_unpack_grad_kernel(int64_t n, const float4* __restrict__ packed_grad,
+                          float* __restrict__ v_means2d, float* __restrict__ v_conics,
+                          float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = packed_grad[REC_F4 * i], b = packed_grad[REC_F4 * i + 1];
+    const float o = packed_grad[REC_F4 * i + 2].x;
+    *reinterpret_cast<float2*>(v_means2d + 2 * i) = make_float2(a.x, a.y);
+    v_conics[3 * i] = a.z; v_conics[3 * i + 1] = a.w; v_conics[3 * i + 2] = b.x;
+    v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
+    v_opacities[i] = o;
+  }
+}
 
 struct TileLds {
   float4 a[64];   // x, y, opacity, conic.a
@@ -64,9 +103,8 @@ __device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, flo
 }
 
 __global__ void __launch_bounds__(64)
-rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ means2d,
-                     const float* __restrict__ conics, const float* __restrict__ colors,
-                     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ packed,
+                     const float* __restrict__ backgrounds,
                      int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
                      const int32_t* __restrict__ flatten_ids, float* __restrict__ render_colors,
                      float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
@@ -107,12 +145,9 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
     float blue = 0.f;
     if (idx < re) {
       const int g = flatten_ids[idx];
-      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
-      const float* cn = conics + 3 * (size_t)g;
-      const float* cl = colors + 3 * (size_t)g;
-      A = make_float4(m.x, m.y, opacities[g], cn[0]);
-      B = make_float4(cn[1], cn[2], cl[0], cl[1]);
-      blue = cl[2];
+      const float4* rec = packed + REC_F4 * (size_t)g;  // one 64 B line per Gaussian
+      A = rec[0]; B = rec[1];
+      blue = rec[2].x;
       mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
     }
     const unsigned long long bal = __ballot(mask != 0);
@@ -178,17 +213,20 @@ struct TileLdsBwd {
   float acc[64][9];  // reduced per-Gaussian gradient of this tile
 };
 
-__global__ void __launch_bounds__(64)
-rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ means2d,
-                     const float* __restrict__ conics, const float* __restrict__ colors,
-                     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+// DBG: profiling-only ablations (1 = skip the atomics flush, 2 = skip the DPP reduction too);
+// the product launches DBG = 0.
+#ifndef CLMGS_BWD_WAVES
+#define CLMGS_BWD_WAVES 5
+#endif
+template <int DBG>
+__global__ void __launch_bounds__(64, CLMGS_BWD_WAVES)
+rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ packed,
+                     const float* __restrict__ backgrounds,
                      int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
                      const int32_t* __restrict__ flatten_ids,
                      const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
                      const float* __restrict__ v_render_colors,
-                     const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d,
-                     float* __restrict__ v_conics, float* __restrict__ v_colors,
-                     float* __restrict__ v_opacities) {
+                     const float* __restrict__ v_render_alphas, float* __restrict__ packed_grad) {
   __shared__ TileLdsBwd sm;
   const int n_tiles = tile_w * tile_h;
   const int n_tiles_total = C * n_tiles;
@@ -204,33 +242,34 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
   tile_range(offsets, tile, n_tiles_total, n_isects, rs, re);
   if (re <= rs) return;
 
-  float T[PPL], Tf[PPL], px[PPL], py[PPL], vr[PPL], vg[PPL], vb[PPL], va[PPL];
+  // per-pixel state kept lean (VGPR budget decides waves/SIMD): pixel centres are recomputed from
+  // the lane, "inside" is bin < 0, and T_final * v_alpha' is pre-multiplied.
+  float T[PPL], tfva[PPL], vr[PPL], vg[PPL], vb[PPL];
   float br[PPL], bg_[PPL], bb[PPL];  // running sum of colour behind the current Gaussian
   int bin[PPL];
-  bool inside[PPL];
   int max_bin = -1;
   float bgr = 0.f, bgg = 0.f, bgb = 0.f;
   if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
+  const float px0 = tile_x0 + (float)qx + 0.5f, py0 = tile_y0 + (float)qy + 0.5f;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int j = tx * TILE + 8 * (k & 1) + qx;
     const int i = ty * TILE + 8 * (k >> 1) + qy;
-    px[k] = (float)j + 0.5f; py[k] = (float)i + 0.5f;
-    inside[k] = (i < H) && (j < W);
     br[k] = bg_[k] = bb[k] = 0.f;
-    if (inside[k]) {
+    if ((i < H) && (j < W)) {
       const size_t pix = ((size_t)cam * H + i) * W + j;
-      Tf[k] = 1.f - render_alphas[pix];
+      const float Tf = 1.f - render_alphas[pix];
       bin[k] = last_ids[pix];
       vr[k] = v_render_colors[3 * pix]; vg[k] = v_render_colors[3 * pix + 1]; vb[k] = v_render_colors[3 * pix + 2];
-      va[k] = v_render_alphas ? v_render_alphas[pix] : 0.f;
+      float va = v_render_alphas ? v_render_alphas[pix] : 0.f;
       // d(out)/d(T_final) through the background term folds into the alpha cotangent
-      va[k] -= (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]);
+      va -= (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]);
+      tfva[k] = Tf * va;
+      T[k] = Tf;
       max_bin = max(max_bin, bin[k]);
     } else {
-      Tf[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = va[k] = 0.f;
+      T[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = tfva[k] = 0.f;
     }
-    T[k] = Tf[k];
   }
   max_bin = wave_max_i32(max_bin);
   const int hi = min(re - 1, max_bin);  // nothing behind the deepest contributor matters
@@ -242,12 +281,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
     float blue = 0.f;
     if (idx >= rs) {
       gid = flatten_ids[idx];
-      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)gid);
-      const float* cn = conics + 3 * (size_t)gid;
-      const float* cl = colors + 3 * (size_t)gid;
-      A = make_float4(m.x, m.y, opacities[gid], cn[0]);
-      B = make_float4(cn[1], cn[2], cl[0], cl[1]);
-      blue = cl[2];
+      const float4* rec = packed + REC_F4 * (size_t)gid;
+      A = rec[0]; B = rec[1];
+      blue = rec[2].x;
       mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
     }
     const unsigned long long bal = __ballot(mask != 0);
@@ -272,11 +308,12 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         if (meta & (1 << k)) {  // wave-uniform
-          const float dx = RA.x - px[k], dy = RA.y - py[k];
+          const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
+          const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
           const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
           const float gex = __expf(-sigma);
           const float alpha = fminf(0.999f, RA.z * gex);
-          const bool valid = inside[k] && (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
+          const bool valid = (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           if (valid) {
             any_valid = true;
             const float ra = 1.f / (1.f - alpha);
@@ -285,7 +322,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
             g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
             float v_alpha = (RB.z * T[k] - br[k] * ra) * vr[k] + (RB.w * T[k] - bg_[k] * ra) * vg[k] +
                             (rblue * T[k] - bb[k] * ra) * vb[k];
-            v_alpha += Tf[k] * ra * va[k];
+            v_alpha += tfva[k] * ra;
             if (RA.z * gex <= 0.999f) {
               const float v_sigma = -RA.z * gex * v_alpha;
               g_ca += 0.5f * v_sigma * dx * dx;
@@ -300,29 +337,31 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
         }
       }
       if (!__any(any_valid)) continue;
-      g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-      g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-      g_x = wave_sum_to_lane63(g_x); g_y = wave_sum_to_lane63(g_y); g_o = wave_sum_to_lane63(g_o);
-      if (lane == 63) {
-        float* a = sm.acc[t];
-        a[0] = g_x; a[1] = g_y; a[2] = g_ca; a[3] = g_cb; a[4] = g_cc;
-        a[5] = g_r; a[6] = g_g; a[7] = g_b; a[8] = g_o;
+      if (DBG < 2) {
+        // 9 wave-wide sums: two 4-packs on the permlane-swap butterfly + one plain DPP chain
+        const float u1 = wave_sum4_rows(g_x, g_y, g_ca, g_cb);   // lanes 15/31/47/63: x, ca, y, cb
+        const float u2 = wave_sum4_rows(g_cc, g_r, g_g, g_b);    //                    cc, g, r, b
+        g_o = wave_sum_to_lane63(g_o);
+        if ((lane & 15) == 15) {
+          const int r = lane >> 4;
+          const int m = ((r & 1) << 1) | (r >> 1);               // row -> slot {0,2,1,3}
+          float* a = sm.acc[t];                                   // x y ca cb | cc r g b | o
+          a[m] = u1;
+          a[4 + m] = u2;
+          if (lane == 63) a[8] = g_o;
+        }
       }
       touched |= (1ull << t);
     }
     __syncthreads();
-    if ((touched >> lane) & 1ull) {
-      const size_t g = (size_t)sm.id[lane];
+    if (DBG >= 1) {
+      if (((touched >> lane) & 1ull) && sm.acc[lane][0] == 1.2345e30f) packed_grad[0] = 1.f;
+    } else if ((touched >> lane) & 1ull) {
+      // all nine atomics of a Gaussian land in its one 64 B gradient line
+      float* dst = packed_grad + 4 * REC_F4 * (size_t)sm.id[lane];
       const float* a = sm.acc[lane];
-      atomicAdd(v_means2d + 2 * g, a[0]);
-      atomicAdd(v_means2d + 2 * g + 1, a[1]);
-      atomicAdd(v_conics + 3 * g, a[2]);
-      atomicAdd(v_conics + 3 * g + 1, a[3]);
-      atomicAdd(v_conics + 3 * g + 2, a[4]);
-      atomicAdd(v_colors + 3 * g, a[5]);
-      atomicAdd(v_colors + 3 * g + 1, a[6]);
-      atomicAdd(v_colors + 3 * g + 2, a[7]);
-      atomicAdd(v_opacities + g, a[8]);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) atomicAdd(dst + c, a[c]);
     }
   }
 }
@@ -331,47 +370,72 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float* __restrict__ m
 
 using namespace clmgs;
 
+extern "C" size_t clmgs_rasterize_pack_bytes(int C, int N) {
+  return (size_t)C * (size_t)N * REC_F4 * sizeof(float4);
+}
+
 extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
                                    const float* means2d, const float* conics, const float* colors,
                                    const float* opacities, const float* backgrounds, int width,
                                    int height, int tile_size, int tile_width, int tile_height,
-                                   const int32_t* offsets, const int32_t* flatten_ids,
+                                   const int32_t* offsets, const int32_t* flatten_ids, void* packed,
                                    float* render_colors, float* render_alphas, int32_t* last_ids) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
   CLMGS_CHECK_ARG(offsets && render_colors && render_alphas && last_ids);
-  CLMGS_CHECK_ARG(n_isects == 0 || (means2d && conics && colors && opacities && flatten_ids));
+  CLMGS_CHECK_ARG(n_isects == 0 || (flatten_ids && packed));
+  CLMGS_CHECK_ARG(!means2d || (conics && colors && opacities));
+  CLMGS_CHECK_ARG(((uintptr_t)packed & 63) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t CN = (int64_t)C * N;
+  if (means2d && n_isects > 0 && CN > 0) {  // means2d == NULL: `packed` was filled by the caller
+    hipLaunchKernelGGL(raster_pack_kernel, dim3(min(ceil_div(CN, 256), 256 * 8)), dim3(256), 0, s, CN,
+                       means2d, conics, colors, opacities, (float4*)packed);
+    CLMGS_LAUNCH_CHECK();
+  }
   const int n_blocks = C * tile_width * tile_height;
-  hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, C, N,
-                     n_isects, means2d, conics, colors, opacities, backgrounds, width, height,
-                     tile_width, tile_height, offsets, flatten_ids, render_colors, render_alphas,
-                     last_ids);
+  hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), 0, s, C, N, n_isects,
+                     (const float4*)packed, backgrounds, width, height, tile_width, tile_height,
+                     offsets, flatten_ids, render_colors, render_alphas, last_ids);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
-                                   const float* means2d, const float* conics, const float* colors,
-                                   const float* opacities, const float* backgrounds, int width,
-                                   int height, int tile_size, int tile_width, int tile_height,
-                                   const int32_t* offsets, const int32_t* flatten_ids,
-                                   const float* render_alphas, const int32_t* last_ids,
-                                   const float* v_render_colors, const float* v_render_alphas,
+extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void* packed,
+                                   const float* backgrounds, int width, int height, int tile_size,
+                                   int tile_width, int tile_height, const int32_t* offsets,
+                                   const int32_t* flatten_ids, const float* render_alphas,
+                                   const int32_t* last_ids, const float* v_render_colors,
+                                   const float* v_render_alphas, void* packed_grad,
                                    float* v_means2d, float* v_conics, float* v_colors,
                                    float* v_opacities) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
-  if (n_isects == 0) return 0;
-  CLMGS_CHECK_ARG(means2d && conics && colors && opacities && offsets && flatten_ids &&
-                  render_alphas && last_ids && v_render_colors && v_means2d && v_conics &&
-                  v_colors && v_opacities);
-  const int n_blocks = C * tile_width * tile_height;
-  hipLaunchKernelGGL(rasterize_bwd_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, C, N,
-                     n_isects, means2d, conics, colors, opacities, backgrounds, width, height,
-                     tile_width, tile_height, offsets, flatten_ids, render_alphas, last_ids,
-                     v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities);
-  CLMGS_LAUNCH_CHECK();
+  CLMGS_CHECK_ARG(!v_means2d || (v_conics && v_colors && v_opacities));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t CN = (int64_t)C * N;
+  if (CN == 0) return 0;
+  CLMGS_CHECK_ARG(packed_grad && (((uintptr_t)packed_grad & 63) == 0));
+  CLMGS_HIP(hipMemsetAsync(packed_grad, 0, clmgs_rasterize_pack_bytes(C, N), s));
+  if (n_isects > 0) {
+    CLMGS_CHECK_ARG(packed && offsets && flatten_ids && render_alphas && last_ids && v_render_colors);
+    const int n_blocks = C * tile_width * tile_height;
+    static const int dbg = getenv("CLMGS_BWD_DEBUG") ? atoi(getenv("CLMGS_BWD_DEBUG")) : 0;
+#define CLMGS_LAUNCH_BWD(D)                                                                        \
+  hipLaunchKernelGGL(rasterize_bwd_kernel<D>, dim3(n_blocks), dim3(64), 0, s, C, N, n_isects,      \
+                     (const float4*)packed, backgrounds, width, height, tile_width, tile_height,   \
+                     offsets, flatten_ids, render_alphas, last_ids, v_render_colors,               \
+                     v_render_alphas, (float*)packed_grad)
+    if (dbg == 1) CLMGS_LAUNCH_BWD(1); else if (dbg == 2) CLMGS_LAUNCH_BWD(2); else CLMGS_LAUNCH_BWD(0);
+#undef CLMGS_LAUNCH_BWD
+    CLMGS_LAUNCH_CHECK();
+  }
+  if (v_means2d) {  // NULL: the caller consumes the packed gradient lines directly
+    hipLaunchKernelGGL(raster_unpack_grad_kernel, dim3(min(ceil_div(CN, 256), 256 * 8)), dim3(256), 0,
+                       s, CN, (const float4*)packed_grad, v_means2d, v_conics, v_colors, v_opacities);
+    CLMGS_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -1,0 +1,118 @@
+"""Engine-internal fast path: one camera forward + loss + backward with NO autograd tape and the
+fused front-end kernels (csrc/preprocess.hip).  It computes exactly what the op-by-op chain of
+strategies/clm_offload/engine.py:650-742 computes (gather -> activations -> projection -> SH ->
+clamp -> isect -> rasterize -> loss -> backward of all of it -> scatter-add -> densification
+stats) in 9 launches; the op-by-op path (clm_gs_amd.gsplat / clm_kernels) stays as the API-parity
+surface and as the cross-check (tests/test_gpu_engines.py).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from ._lib import check, dptr, stream
+from .gsplat import isect_offset_encode, isect_tiles
+
+F32, I32, U8 = torch.float32, torch.int32, torch.uint8
+TILE = 16
+
+
+def _cam_host(camera):
+    """Host copies of viewmat (row-major world->camera), K and the camera centre, cached."""
+    h = getattr(camera, "_clmgs_host", None)
+    if h is None:
+        vm = camera.world_view_transform.detach().t().contiguous().cpu().numpy().astype(np.float32)
+        K = camera.K.detach().cpu().numpy().astype(np.float32) if getattr(camera, "K", None) is not None \
+            else camera.create_k_on_gpu().cpu().numpy().astype(np.float32)
+        c2w = getattr(camera, "camtoworlds", None)
+        if c2w is not None:
+            campos = c2w.detach().reshape(-1, 4, 4)[0, :3, 3].cpu().numpy().astype(np.float32)
+        else:
+            campos = np.linalg.inv(vm.astype(np.float64))[:3, 3].astype(np.float32)
+        h = (np.ascontiguousarray(vm.reshape(16)), np.ascontiguousarray(K.reshape(9)),
+             np.ascontiguousarray(campos.reshape(3)))
+        camera._clmgs_host = h
+    return h
+
+
+def _np(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
+                     gt_u8, lambda_dssim=0.2, update_stats=True, keep=None):
+    """Forward, loss, backward for one camera over the rows of `this_filter`.
+
+    Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
+    exist) and into g_sh_rows (indexed like sh_rows: by row id when sh_by_filter else by position).
+    Returns the detached loss (0-dim tensor).  `keep`, if a list, receives tensors that must stay
+    alive until the stream has consumed them."""
+    L = _lib.lib()
+    args = utils.get_args()
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    dev = gaussians._xyz.device
+    V = int(this_filter.shape[0])
+    vm, K, campos = _cam_host(camera)
+    deg = int(gaussians.active_sh_degree)
+    xyz, opa = gaussians._xyz.detach(), gaussians._opacity.detach()
+    sca, rot = gaussians._scaling.detach(), gaussians._rotation.detach()
+    radii = torch.empty((1, V), dtype=I32, device=dev)
+    means2d = torch.empty((1, V, 2), dtype=F32, device=dev)
+    depths = torch.empty((1, V), dtype=F32, device=dev)
+    conics = torch.empty((V, 3), dtype=F32, device=dev)
+    colors = torch.empty((V, 3), dtype=F32, device=dev)
+    opac = torch.empty((V,), dtype=F32, device=dev)
+    packed = torch.empty((V, 16), dtype=F32, device=dev)
+    filt = this_filter.contiguous()
+    s = stream()
+    check(L.clmgs_preprocess_fwd(
+        s, V, dptr(filt, torch.int64), dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32),
+        dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
+        0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
+        dptr(depths), dptr(conics), dptr(colors), dptr(opac), dptr(packed)))
+    tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
+    _, isect_ids, fids = isect_tiles(means2d, radii, depths, TILE, tw, th)
+    offsets = isect_offset_encode(isect_ids, 1, tw, th)
+    out = torch.empty((H, W, 3), dtype=F32, device=dev)
+    alphas = torch.empty((H, W), dtype=F32, device=dev)
+    last_ids = torch.empty((H, W), dtype=I32, device=dev)
+    bg = background.reshape(1, 3).to(F32).contiguous() if background is not None else None
+    n_isects = fids.numel()
+    check(L.clmgs_rasterize_fwd(s, 1, V, n_isects, None, None, None, None, dptr(bg, F32, True), W, H,
+                                TILE, tw, th, dptr(offsets), dptr(fids), dptr(packed), dptr(out),
+                                dptr(alphas), dptr(last_ids)))
+    # loss forward + backward straight on the [H,W,3] buffer viewed as [3,H,W]
+    slots = L.clmgs_loss_slots()
+    partials = torch.zeros((slots, 2), dtype=F32, device=dev)
+    maps = torch.empty((3, 3, H, W), dtype=F32, device=dev)
+    sc, sy, sx = 1, 3 * W, 3
+    gt = gt_u8.contiguous()
+    check(L.clmgs_l1_ssim_loss_fwd(s, H, W, dptr(out), sc, sy, sx, dptr(gt, U8), dptr(partials),
+                                   dptr(maps[0]), dptr(maps[1]), dptr(maps[2])))
+    tot = partials.sum(dim=0) / float(3 * H * W)
+    loss = (1.0 - lambda_dssim) * tot[0] + lambda_dssim * (1.0 - tot[1])
+    one = torch.ones((1,), dtype=F32, device=dev)
+    v_out = torch.empty_like(out)
+    check(L.clmgs_l1_ssim_loss_bwd(s, H, W, dptr(out), sc, sy, sx, dptr(gt, U8), dptr(one),
+                                   float(lambda_dssim), dptr(maps[0]), dptr(maps[1]), dptr(maps[2]),
+                                   dptr(v_out)))
+    packed_grad = torch.empty_like(packed)
+    check(L.clmgs_rasterize_bwd(s, 1, V, n_isects, dptr(packed), dptr(bg, F32, True), W, H, TILE, tw,
+                                th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
+                                dptr(v_out), None, dptr(packed_grad), None, None, None, None))
+    stats = update_stats and (not args.disable_auto_densification) and \
+        utils.get_cur_iter() <= args.densify_until_iter
+    check(L.clmgs_preprocess_bwd(
+        s, V, dptr(filt), dptr(xyz), dptr(opa), dptr(sca), dptr(rot), dptr(sh_rows, F32, allow_host=True),
+        int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
+        dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
+        dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32),
+        dptr(g_sh_rows, F32, allow_host=True),
+        dptr(gaussians.max_radii2D if stats else None, F32, True),
+        dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
+        dptr(gaussians.denom if stats else None, F32, True), None))
+    if keep is not None:
+        keep += [packed, packed_grad, radii, filt]
+    return loss.detach()

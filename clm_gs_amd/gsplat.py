@@ -212,32 +212,38 @@ class _Rasterize(torch.autograd.Function):
         alphas = torch.empty((C, height, width, 1), dtype=F32, device=dev)
         last_ids = torch.empty((C, height, width), dtype=I32, device=dev)
         n_isects = fids.numel()
+        packed = torch.empty((C * N, 16), dtype=F32, device=dev)  # one 64 B record per Gaussian
         check(L.clmgs_rasterize_fwd(
             stream(), C, N, n_isects, dptr(means2d, F32), dptr(conics, F32), dptr(colors, F32),
             dptr(opacities, F32), dptr(bg, F32, True), int(width), int(height), int(tile_size), tw,
-            th, dptr(offsets, I32), dptr(fids, I32), dptr(out), dptr(alphas), dptr(last_ids)))
-        ctx.save_for_backward(means2d, conics, colors, opacities, bg, offsets, fids, alphas, last_ids)
+            th, dptr(offsets, I32), dptr(fids, I32), dptr(packed), dptr(out), dptr(alphas),
+            dptr(last_ids)))
+        ctx.save_for_backward(packed, bg, offsets, fids, alphas, last_ids)
+        ctx.shapes = (means2d.shape, conics.shape, colors.shape, opacities.shape)
         ctx.cfg = (int(width), int(height), int(tile_size))
         return out, alphas
 
     @staticmethod
     def backward(ctx, v_out, v_alphas):
         L = _lib.lib()
-        means2d, conics, colors, opacities, bg, offsets, fids, alphas, last_ids = ctx.saved_tensors
+        packed, bg, offsets, fids, alphas, last_ids = ctx.saved_tensors
         width, height, tile_size = ctx.cfg
-        C, N = opacities.shape
+        s_m2, s_cn, s_col, s_op = ctx.shapes
+        C, N = s_op
         th, tw = offsets.shape[1:]
+        dev = packed.device
         v_out = v_out.contiguous()
         v_alphas = v_alphas.contiguous() if v_alphas is not None else None
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
+        v_means2d = torch.empty(s_m2, dtype=F32, device=dev)
+        v_conics = torch.empty(s_cn, dtype=F32, device=dev)
+        v_colors = torch.empty(s_col, dtype=F32, device=dev)
+        v_opacities = torch.empty(s_op, dtype=F32, device=dev)
+        packed_grad = torch.empty_like(packed)
         check(L.clmgs_rasterize_bwd(
-            stream(), C, N, fids.numel(), dptr(means2d), dptr(conics), dptr(colors),
-            dptr(opacities), dptr(bg, F32, True), width, height, tile_size, tw, th, dptr(offsets),
-            dptr(fids), dptr(alphas), dptr(last_ids), dptr(v_out, F32), dptr(v_alphas, F32, True),
-            dptr(v_means2d), dptr(v_conics), dptr(v_colors), dptr(v_opacities)))
+            stream(), C, N, fids.numel(), dptr(packed), dptr(bg, F32, True), width, height,
+            tile_size, tw, th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
+            dptr(v_out, F32), dptr(v_alphas, F32, True), dptr(packed_grad), dptr(v_means2d),
+            dptr(v_conics), dptr(v_colors), dptr(v_opacities)))
         return v_means2d, v_conics, v_colors, v_opacities, None, None, None, None, None, None
 
 

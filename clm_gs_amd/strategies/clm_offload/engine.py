@@ -170,6 +170,12 @@ def _render_and_backward(gaussians, scene, camera, background, pipe_args, this_f
                          shs_grad, before_sh_backward=None):
     """Forward + loss + backward for one camera on the gathered rows; SH gradients are
     accumulated into shs_grad[V,48]; small gradients are scatter-added into the model's .grad."""
+    if getattr(utils.get_args(), "fused_front_end", True):
+        from ...fused import train_one_camera
+        if before_sh_backward is not None:
+            before_sh_backward()
+        return train_one_camera(gaussians, camera, this_filter, shs, 0, shs_grad, background,
+                                camera.original_image)
     xyz, opa_raw, sca_raw, rot_raw = _gather_small(gaussians, this_filter)
     opa = gaussians.opacity_activation(opa_raw)
     sca = gaussians.scaling_activation(sca_raw)
@@ -255,16 +261,23 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
 
     _zero_small_grads(gaussians)
     losses = []
+    fused = getattr(args, "fused_front_end", True)
     for micro_idx in range(bsz):
         this_filter = filters[micro_idx]
-        with torch.no_grad():
-            shs = torch.empty((this_filter.shape[0], 48), device=params.device)
-            send_shs2gpu_stream(shs, params.data, this_filter)
-            shs_grad = torch.zeros_like(shs)
-        loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
-                                    pipe_args, this_filter, shs, shs_grad)
-        with torch.no_grad():
-            send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
+        if fused:
+            # rows are read from / accumulated into the resident [N,48] buffers in place
+            from ...fused import train_one_camera
+            loss = train_one_camera(gaussians, batched_cameras[micro_idx], this_filter, params.data, 1,
+                                    grad_buf, background, batched_cameras[micro_idx].original_image)
+        else:
+            with torch.no_grad():
+                shs = torch.empty((this_filter.shape[0], 48), device=params.device)
+                send_shs2gpu_stream(shs, params.data, this_filter)
+                shs_grad = torch.zeros_like(shs)
+            loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
+                                        pipe_args, this_filter, shs, shs_grad)
+            with torch.no_grad():
+                send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
     if dp.world_size() > 1:  # camera-DP: the one exchange of the batch

@@ -43,6 +43,9 @@ def default_args(**over):
         stop_update_param=False, drop_initial_3dgs_p=0.0,
         # this build: where the SH rows + their optimizer state live
         sh_residency="hbm",
+        # this build: fused front-end kernels + no autograd tape inside the engines (fused.py);
+        # False = the op-by-op gsplat/clm_kernels chain the reference engines spell out
+        fused_front_end=True,
     )
     for k, v in over.items():
         setattr(a, k, v)

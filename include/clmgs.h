@@ -81,23 +81,54 @@ int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids
 
 /* ---- gsplat.rasterize_to_pixels  (base_engine.py:192-203)
  * means2d[C*N,2] conics[C*N,3] colors[C*N,3] opacities[C*N], backgrounds[C,3] or NULL ->
- * render_colors[C,H,W,3], render_alphas[C,H,W], last_ids[C,H,W] i32.  tile_size must be 16. */
+ * render_colors[C,H,W,3], render_alphas[C,H,W], last_ids[C,H,W] i32.  tile_size must be 16.
+ * `packed` is caller scratch of clmgs_rasterize_pack_bytes(C,N) bytes (64 B aligned): fwd fills it
+ * with one 64 B raster record per Gaussian and the tile kernels gather that one line; keep it for
+ * the backward call.  means2d == NULL: `packed` already holds the records (clmgs_preprocess_fwd). */
+size_t clmgs_rasterize_pack_bytes(int C, int N);
 int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects, const float* means2d,
                         const float* conics, const float* colors, const float* opacities,
                         const float* backgrounds, int width, int height, int tile_size,
                         int tile_width, int tile_height, const int32_t* offsets,
-                        const int32_t* flatten_ids, float* render_colors, float* render_alphas,
-                        int32_t* last_ids);
-/* v_means2d[C*N,2] v_conics[C*N,3] v_colors[C*N,3] v_opacities[C*N] must be ZEROED by the
- * caller; the kernel accumulates with float atomics. */
-int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const float* means2d,
-                        const float* conics, const float* colors, const float* opacities,
+                        const int32_t* flatten_ids, void* packed, float* render_colors,
+                        float* render_alphas, int32_t* last_ids);
+/* VJP.  packed = the forward's record buffer; packed_grad = scratch of the same size (zeroed
+ * here; per-(Gaussian,tile) sums are accumulated into it with float atomics, one 64 B line per
+ * Gaussian).  v_means2d[C*N,2] v_conics[C*N,3] v_colors[C*N,3] v_opacities[C*N] are OVERWRITTEN;
+ * v_means2d == NULL skips the unpack (the caller reads packed_grad: x y ca cb | cc r g b | o). */
+int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void* packed,
                         const float* backgrounds, int width, int height, int tile_size,
                         int tile_width, int tile_height, const int32_t* offsets,
                         const int32_t* flatten_ids, const float* render_alphas,
                         const int32_t* last_ids, const float* v_render_colors,
-                        const float* v_render_alphas, float* v_means2d, float* v_conics,
-                        float* v_colors, float* v_opacities);
+                        const float* v_render_alphas, void* packed_grad, float* v_means2d,
+                        float* v_conics, float* v_colors, float* v_opacities);
+
+/* ---- fused per-camera front end (engine-internal fast path; same arithmetic as the op chain
+ * strategies/clm_offload/engine.py:650-691 forward and :703-742 + densification.py:59-102 backward)
+ * For i < V, row g = filter ? filter[i] : i of the RAW parameter tensors (xyz[N,3], opacity_raw[N],
+ * scaling_raw[N,3], rotation_raw[N,4]); SH rows from sh_rows[g] (sh_by_filter) or sh_rows[i].
+ * viewmat[16] (row-major world->camera), K[9], campos[3] are HOST pointers (copied into the launch).
+ * fwd: exp / sigmoid, projection, SH colour, +0.5 clamp -> radii[V] means2d[V,2] depths[V]
+ * conics[V,3] colors[V,3] opacities[V] and the packed raster records packed[V,16].
+ * bwd: from packed_grad[V,16] ACCUMULATES into g_xyz[N,3] g_opacity[N] g_scaling[N,3]
+ * g_rotation[N,4] (raw-parameter gradients) and g_sh_rows (indexed like sh_rows), and, if
+ * max_radii2D != NULL, updates the densification statistics of every filter row. */
+int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
+                         const float* opacity_raw, const float* scaling_raw,
+                         const float* rotation_raw, const float* sh_rows, int sh_by_filter,
+                         const float* viewmat_host, const float* K_host, const float* campos_host,
+                         int width, int height, int degree, float eps2d, float near_plane,
+                         float far_plane, float radius_clip, int32_t* radii, float* means2d,
+                         float* depths, float* conics, float* colors, float* opacities, void* packed);
+int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float* xyz,
+                         const float* opacity_raw, const float* scaling_raw,
+                         const float* rotation_raw, const float* sh_rows, int sh_by_filter,
+                         const float* viewmat_host, const float* K_host, const float* campos_host,
+                         int width, int height, int degree, float eps2d, const int32_t* radii,
+                         const void* packed_grad, float* g_xyz, float* g_opacity, float* g_scaling,
+                         float* g_rotation, float* g_sh_rows, float* max_radii2D, float* grad_accum,
+                         float* denom, float* v_means2d_out);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
  * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes

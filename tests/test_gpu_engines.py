@@ -19,10 +19,13 @@ pytestmark = pytest.mark.gpu
 W, H, N, BSZ = 96, 64, 3000, 4
 
 
+FUSED = True
+
+
 def _setup(strategy, residency="hbm", sparse=False, seed=0):
     from clm_gs_amd import utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
-    args = utils.default_args(bsz=BSZ, sh_residency=residency, sparse_adam=sparse)
+    args = utils.default_args(bsz=BSZ, sh_residency=residency, sparse_adam=sparse, fused_front_end=FUSED)
     setattr(args, strategy, True)
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -134,6 +137,26 @@ def test_clm_hbm_equals_host_equals_no_offload_after_one_step(dev, sparse):
             frac = _frac_differs(x[k], y[k], x["init"][init_k], 0.02)
             assert frac < 0.01, (k, frac)
     assert (a["xyz"] - a["init"]["xyz"]).abs().max() > 0
+
+
+def test_fused_front_end_equals_op_by_op_path(dev):
+    """fused.py (2 front-end kernels, no autograd) == the gsplat/clm_kernels op chain."""
+    global FUSED
+    try:
+        FUSED = True
+        a = _one_step("clm_offload", "hbm")
+        FUSED = False
+        b = _one_step("clm_offload", "hbm")
+    finally:
+        FUSED = True
+    for u, v in zip(a["losses"], b["losses"]):
+        assert abs(u - v) < 1e-6
+    for k, init_k in (("xyz", "xyz"), ("opacity", "opacity"), ("scaling", "scaling"), ("rotation", "rotation"), ("shs", "shs48")):
+        frac = _frac_differs(a[k], b[k], a["init"][init_k], 0.02)
+        assert frac < 0.005, (k, frac)
+    ma, mb = a["model"], b["model"]
+    assert torch.allclose(ma.denom, mb.denom) and torch.allclose(ma.max_radii2D, mb.max_radii2D)
+    assert rel_l2(ma.xyz_gradient_accum.cpu(), mb.xyz_gradient_accum.cpu()) < 1e-4
 
 
 def test_order_calculation_invariants(dev):

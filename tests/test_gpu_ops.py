@@ -193,8 +193,10 @@ def test_rasterize_last_ids_and_saturation(dev):
     t = [x.to(dev).contiguous() for x in (m2, cn, colors, opac, off, fids)]
     out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
     last = torch.empty(1, h, w, dtype=torch.int32, device=dev)
+    packed = torch.empty(900, 16, device=dev)
+    assert L.clmgs_rasterize_pack_bytes(1, 900) == packed.numel() * 4
     check(L.clmgs_rasterize_fwd(stream(), 1, 900, fids.numel(), dptr(t[0]), dptr(t[1]), dptr(t[2]), dptr(t[3]), None,
-                                w, h, 16, tw, th, dptr(t[4]), dptr(t[5]), dptr(out), dptr(al), dptr(last)))
+                                w, h, 16, tw, th, dptr(t[4]), dptr(t[5]), dptr(packed), dptr(out), dptr(al), dptr(last)))
     assert psnr(out.cpu(), img0) > 60
     mism = (last.cpu() != last0).float().mean().item()
     assert mism < 0.01, f"last_ids mismatch fraction {mism} (threshold ties only)"
