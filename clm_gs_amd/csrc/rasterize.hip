@@ -89,7 +89,7 @@ __device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, flo
   const float L = __logf(255.f * opac);
   const float det = ca * cc - cb * cb;
   if (!(det > 0.f)) return 15;  // degenerate conic: never cull
-  const float s = 2.f * L / det;
+  const float s = 2.f * L * __builtin_amdgcn_rcpf(det);
   const float ex = sqrtf(fmaxf(s * cc, 0.f)) * 1.0001f + 1e-3f;
   const float ey = sqrtf(fmaxf(s * ca, 0.f)) * 1.0001f + 1e-3f;
   if (!(ex == ex) || !(ey == ey)) return 15;
@@ -316,7 +316,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           const bool valid = (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           if (valid) {
             any_valid = true;
-            const float ra = 1.f / (1.f - alpha);
+            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp), not the 10-op IEEE divide
             T[k] *= ra;
             const float fac = alpha * T[k];
             g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];

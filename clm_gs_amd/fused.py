@@ -42,13 +42,16 @@ def _np(a):
 
 
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
-                     gt_u8, lambda_dssim=0.2, update_stats=True, keep=None):
+                     gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
+                     return_event=False):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
     exist) and into g_sh_rows (indexed like sh_rows: by row id when sh_by_filter else by position).
     Returns the detached loss (0-dim tensor).  `keep`, if a list, receives tensors that must stay
-    alive until the stream has consumed them."""
+    alive until the stream has consumed them.  Everything is enqueued on the CURRENT torch stream;
+    `accumulate_after` (an event) gates the gradient-accumulating kernel so two cameras can be in
+    flight on two streams while their read-modify-write accumulations stay ordered."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -104,6 +107,8 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
                                 dptr(v_out), None, dptr(packed_grad), None, None, None, None))
     stats = update_stats and (not args.disable_auto_densification) and \
         utils.get_cur_iter() <= args.densify_until_iter
+    if accumulate_after is not None:
+        torch.cuda.current_stream().wait_event(accumulate_after)
     check(L.clmgs_preprocess_bwd(
         s, V, dptr(filt), dptr(xyz), dptr(opa), dptr(sca), dptr(rot), dptr(sh_rows, F32, allow_host=True),
         int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
@@ -115,4 +120,8 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         dptr(gaussians.denom if stats else None, F32, True), None))
     if keep is not None:
         keep += [packed, packed_grad, radii, filt]
+    if return_event:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return loss.detach(), ev
     return loss.detach()

@@ -244,40 +244,55 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     side_event = None
     col_lr = row_adam._col_lr(params.device)
 
-    def row_update(mask):
-        clm_kernels.adam_rows(params.data, grad_buf, st["exp_avg"], st["exp_avg_sq"], None, col_lr,
+    def row_update(rows):
+        # explicit row lists: the kernel walks |rows| x 48 elements instead of scanning all N rows
+        clm_kernels.adam_rows(params.data, grad_buf, st["exp_avg"], st["exp_avg_sq"], rows, col_lr,
                               group["betas"][0], group["betas"][1], group["eps"], step,
-                              group["bias_correction"], 1.0 / bsz, True, mask=mask)
+                              group["bias_correction"], 1.0 / bsz, True)
 
+    touched_rows = torch.nonzero(touched).flatten().to(torch.int32)
     if not args.stop_update_param and not args.sparse_adam:
         # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
-        untouched = ~touched
+        untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
         comm_stream.wait_stream(default_stream)
         with torch.cuda.stream(comm_stream):
-            row_update(untouched)
+            row_update(untouched_rows)
             side_event = torch.cuda.Event()
             side_event.record(comm_stream)
-        untouched.record_stream(comm_stream)
+        untouched_rows.record_stream(comm_stream)
 
     _zero_small_grads(gaussians)
     losses = []
     fused = getattr(args, "fused_front_end", True)
-    for micro_idx in range(bsz):
+    if fused:
+        # Two cameras in flight on two streams: the ALU-bound tile kernels of one overlap with the
+        # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
+        # events so the read-modify-write gradient sums stay ordered.
+        from ...fused import train_one_camera
+        aux = getattr(gaussians, "_clmgs_aux_stream", None)
+        if aux is None:
+            aux = gaussians._clmgs_aux_stream = torch.cuda.Stream()
+        lanes = [default_stream, aux] if getattr(args, "overlap_cameras", True) else [default_stream]
+        aux.wait_stream(default_stream)
+        prev = None
+        for micro_idx in range(bsz):
+            with torch.cuda.stream(lanes[micro_idx % len(lanes)]):
+                loss, prev = train_one_camera(
+                    gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
+                    background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
+                    return_event=True)
+            losses.append(loss)
+        default_stream.wait_stream(aux)
+    for micro_idx in range(0 if fused else bsz):  # op-by-op path (fused_front_end=False)
         this_filter = filters[micro_idx]
-        if fused:
-            # rows are read from / accumulated into the resident [N,48] buffers in place
-            from ...fused import train_one_camera
-            loss = train_one_camera(gaussians, batched_cameras[micro_idx], this_filter, params.data, 1,
-                                    grad_buf, background, batched_cameras[micro_idx].original_image)
-        else:
-            with torch.no_grad():
-                shs = torch.empty((this_filter.shape[0], 48), device=params.device)
-                send_shs2gpu_stream(shs, params.data, this_filter)
-                shs_grad = torch.zeros_like(shs)
-            loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
-                                        pipe_args, this_filter, shs, shs_grad)
-            with torch.no_grad():
-                send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
+        with torch.no_grad():
+            shs = torch.empty((this_filter.shape[0], 48), device=params.device)
+            send_shs2gpu_stream(shs, params.data, this_filter)
+            shs_grad = torch.zeros_like(shs)
+        loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
+                                    pipe_args, this_filter, shs, shs_grad)
+        with torch.no_grad():
+            send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
     if dp.world_size() > 1:  # camera-DP: the one exchange of the batch
@@ -286,7 +301,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         dp.allreduce_rows(grad_buf, touched)
     _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None)
     if not args.stop_update_param:
-        row_update(touched)
+        row_update(touched_rows)
     st["step"] = step
     if side_event is not None:
         default_stream.wait_event(side_event)
