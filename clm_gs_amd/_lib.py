@@ -28,6 +28,10 @@ SIGNATURES = {
     "clmgs_isect_sort_temp_bytes": (_sz, [_i64]),
     "clmgs_isect_emit_sort": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "clmgs_isect_offsets": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
+    "clmgs_isect2_order_temp_bytes": (_sz, [_i]),
+    "clmgs_isect2_order_count": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
+    "clmgs_isect2_sort_temp_bytes": (_sz, [_i64]),
+    "clmgs_isect2_emit_sort": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_rasterize_pack_bytes": (_sz, [_i, _i]),
     "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -87,7 +91,7 @@ class _Namespace:
 
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
-              "clmgs_isect_sort_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
+              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free"}
 
 

@@ -225,7 +225,7 @@ def adam_rows(p, g, m, v, rows, col_lr, beta1, beta2, eps, step, bias_correction
     L = _lib.lib()
     n_rows = rows.numel() if rows is not None else p.shape[0]
     cols = p.shape[-1] if p.dim() > 1 else 1
-    check(L.clmgs_adam_rows(stream(), dptr(p, F32), dptr(g, F32), dptr(m, F32), dptr(v, F32),
+    check(L.clmgs_adam_rows(stream(), dptr(p, F32), dptr(g, F32, True), dptr(m, F32), dptr(v, F32),
                             dptr(rows, None, True), _idx64(rows),
                             dptr(mask.view(U8) if mask is not None else None, U8, True),
                             int(n_rows), int(cols), dptr(col_lr, F32), float(beta1), float(beta2),

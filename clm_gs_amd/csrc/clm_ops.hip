@@ -152,13 +152,13 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
     const int64_t row = row_of<IdxT>(rows, r);
     if (mask && !mask[row]) continue;
     const int64_t o = row * cols + k;
-    const float gg = g[o] * grad_scale;
+    const float gg = g ? g[o] * grad_scale : 0.f;  // g == NULL: rows known to have zero gradient
     const float mm = beta1 * m[o] + ob1 * gg;
     const float vv = beta2 * v[o] + ob2 * gg * gg;
     m[o] = mm; v[o] = vv;
     const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
     p[o] -= (col_lr[k] * inv_bc1) * (mm / denom);
-    if (zero_grad) g[o] = 0.f;
+    if (zero_grad && g) g[o] = 0.f;
   }
 }
 
@@ -256,7 +256,7 @@ extern "C" int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float
                                float grad_scale, int zero_grad) {
   CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && step >= 1);
   if (n_rows == 0) return 0;
-  CLMGS_CHECK_ARG(p && g && m && v && col_lr);
+  CLMGS_CHECK_ARG(p && m && v && col_lr);  // g may be NULL (= all-zero gradient)
   float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
   if (bias_correction) {
     inv_bc1 = (float)(1.0 / (1.0 - pow(beta1, (double)step)));

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, utils
 from ._lib import check, dptr, stream
-from .gsplat import isect_offset_encode, isect_tiles
+from .gsplat import isect_tiles_two_level
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
@@ -76,8 +76,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
         dptr(depths), dptr(conics), dptr(colors), dptr(opac), dptr(packed)))
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
-    _, isect_ids, fids = isect_tiles(means2d, radii, depths, TILE, tw, th)
-    offsets = isect_offset_encode(isect_ids, 1, tw, th)
+    fids, offsets, _ = isect_tiles_two_level(means2d, radii, depths, TILE, tw, th)
     out = torch.empty((H, W, 3), dtype=F32, device=dev)
     alphas = torch.empty((H, W), dtype=F32, device=dev)
     last_ids = torch.empty((H, W), dtype=I32, device=dev)

@@ -195,6 +195,42 @@ def isect_offset_encode(isect_ids, n_cameras, tile_width, tile_height):
     return offsets
 
 
+@torch.no_grad()
+def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_height,
+                          want_isect_ids=False):
+    """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
+    sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
+    identical to isect_tiles + isect_offset_encode for C = 1."""
+    L = _lib.lib()
+    V = radii.numel()
+    dev = radii.device
+    means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    offsets = torch.empty((1, tile_height, tile_width), dtype=I32, device=dev)
+    if V == 0:
+        offsets.zero_()
+        return torch.empty(0, dtype=I32, device=dev), offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None)
+    order = torch.empty((V,), dtype=I32, device=dev)
+    cum = torch.empty((V,), dtype=I64, device=dev)
+    tb = L.clmgs_isect2_order_temp_bytes(V)
+    temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    check(L.clmgs_isect2_order_count(stream(), V, dptr(means2d, F32), dptr(radii, I32), dptr(depths, F32),
+                                     int(tile_size), int(tile_width), int(tile_height), dptr(order),
+                                     dptr(cum), dptr(temp), tb))
+    n_isects = int(cum[-1].item())  # the one host sync of the front end
+    _lib.STATS["n_isects"].append(n_isects)
+    if len(_lib.STATS["n_isects"]) > 4096:
+        del _lib.STATS["n_isects"][:2048]
+    fids = torch.empty((n_isects,), dtype=I32, device=dev)
+    ids = torch.empty((n_isects,), dtype=I64, device=dev) if want_isect_ids else None
+    sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
+    temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
+    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(means2d), dptr(radii), dptr(depths),
+                                   dptr(order), dptr(cum), int(tile_size), int(tile_width),
+                                   int(tile_height), dptr(fids), dptr(offsets), dptr(ids, I64, True),
+                                   dptr(temp2), sb))
+    return fids, offsets, ids
+
+
 # ---------------------------------------------------------------------- rasterize
 class _Rasterize(torch.autograd.Function):
     @staticmethod

@@ -13,12 +13,15 @@ LAMBDA_DSSIM = 0.2
 TILE_SIZE = 16
 
 
-def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotation_gpu):
+def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotation_gpu,
+                      return_ids=False):
     """Per-camera visible index lists: ONE cull pass over (bsz cameras x N Gaussians).
 
     Same index sets as the packed projection the reference runs (base_engine.py:18-76) -- the
     cull is the projection's own (near plane, blur determinant, radius, off-screen) -- but only
-    radii are written.  Returns (filters, camera_ids, gaussian_ids)."""
+    radii are written, and the (camera, gaussian) pairs are compacted with a single one-column
+    nonzero over the flat [C*N] mask (camera boundaries by binary search on the sorted result).
+    Returns (filters, camera_ids, gaussian_ids); the id vectors only when return_ids."""
     args = utils.get_args()
     with torch.no_grad():
         Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in batched_cameras])
@@ -26,12 +29,19 @@ def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotati
         radii = visibility_radii(xyz_gpu, rotation_gpu, scaling_gpu, viewmats, Ks,
                                  int(utils.get_img_width()), int(utils.get_img_height()),
                                  radius_clip=args.radius_clip)
-        vis = radii > 0
-        camera_ids, gaussian_ids = torch.nonzero(vis, as_tuple=True)
-        counts_cpu = vis.sum(dim=1).tolist()  # the one host sync of the filter stage
+        C, N = radii.shape
+        flat = torch.nonzero(radii.reshape(-1) > 0).flatten()  # sorted: camera-major, then gaussian
+        edges = torch.searchsorted(flat, torch.arange(0, C + 1, device=flat.device) * N)
+        e = edges.tolist()  # the one host sync of the filter stage
+        counts_cpu = [e[i + 1] - e[i] for i in range(C)]
         assert all(c > 0 for c in counts_cpu), (
             "every camera must see at least one gaussian (base_engine.py:64-67)")
-        filters = torch.split(gaussian_ids, counts_cpu)
+        pieces = torch.split(flat, counts_cpu)
+        filters = tuple(p - i * N if i else p for i, p in enumerate(pieces))
+        camera_ids = gaussian_ids = None
+        if return_ids:
+            camera_ids = torch.div(flat, N, rounding_mode="floor")
+            gaussian_ids = flat - camera_ids * N
     return filters, camera_ids, gaussian_ids
 
 

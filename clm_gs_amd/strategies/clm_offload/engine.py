@@ -244,9 +244,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     side_event = None
     col_lr = row_adam._col_lr(params.device)
 
-    def row_update(rows):
-        # explicit row lists: the kernel walks |rows| x 48 elements instead of scanning all N rows
-        clm_kernels.adam_rows(params.data, grad_buf, st["exp_avg"], st["exp_avg_sq"], rows, col_lr,
+    def row_update(rows, zero_grad_rows=False):
+        # explicit row lists: the kernel walks |rows| x 48 elements instead of scanning all N rows;
+        # rows the batch never touches have an all-zero gradient -> the grad buffer is not read
+        clm_kernels.adam_rows(params.data, None if zero_grad_rows else grad_buf, st["exp_avg"],
+                              st["exp_avg_sq"], rows, col_lr,
                               group["betas"][0], group["betas"][1], group["eps"], step,
                               group["bias_correction"], 1.0 / bsz, True)
 
@@ -256,7 +258,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
         comm_stream.wait_stream(default_stream)
         with torch.cuda.stream(comm_stream):
-            row_update(untouched_rows)
+            row_update(untouched_rows, zero_grad_rows=True)
             side_event = torch.cuda.Event()
             side_event.record(comm_stream)
         untouched_rows.record_stream(comm_stream)

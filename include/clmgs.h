@@ -79,6 +79,22 @@ int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isects, const fl
 int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids, int C,
                         int tile_width, int tile_height, int32_t* offsets);
 
+/* ---- two-level binning (engine fast path; single camera).  Same (tile, depth, row) order as
+ * clmgs_isect_emit_sort, ~1/4 of its traffic: A = stable depth sort of the V rows + tile counts
+ * in that order (order[V] i32, cum[V] i64 inclusive; caller reads cum[V-1] = I);
+ * B = emit in depth order + ONE stable sort on the tile-id bits -> flatten_ids[I] i32 (row ids),
+ * offsets[tile_w*tile_h] i32, and isect_ids[I] i64 if non-NULL. */
+size_t clmgs_isect2_order_temp_bytes(int V);
+int clmgs_isect2_order_count(void* stream, int V, const float* means2d, const int32_t* radii,
+                             const float* depths, int tile_size, int tile_width, int tile_height,
+                             int32_t* order, int64_t* cum, void* temp, size_t temp_bytes);
+size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects);
+int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* means2d,
+                           const int32_t* radii, const float* depths, const int32_t* order,
+                           const int64_t* cum, int tile_size, int tile_width, int tile_height,
+                           int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids, void* temp,
+                           size_t temp_bytes);
+
 /* ---- gsplat.rasterize_to_pixels  (base_engine.py:192-203)
  * means2d[C*N,2] conics[C*N,3] colors[C*N,3] opacities[C*N], backgrounds[C,3] or NULL ->
  * render_colors[C,H,W,3], render_alphas[C,H,W], last_ids[C,H,W] i32.  tile_size must be 16.
@@ -187,6 +203,7 @@ int clmgs_set_signal(void* stream, int32_t* signal_pinned, int idx, int32_t valu
  * Row-wise Adam over p,g,m,v [*, cols] with per-column learning rate col_lr[cols] (device).
  * rows: i32/i64 row list or NULL (all n_rows rows in order); mask: u8[n_rows] or NULL
  * (rows with mask==0 are skipped; this is clm_kernels.selective_adam_update).
+ * g == NULL means an all-zero gradient (pure moment decay; nothing read or cleared).
  * g is multiplied by grad_scale; bias_correction uses the 1-based `step`; betas/eps are
  * doubles so 1-beta and beta^step are formed in double on the host;
  * zero_grad != 0 clears consumed gradient rows. */

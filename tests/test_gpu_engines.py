@@ -165,7 +165,7 @@ def test_order_calculation_invariants(dev):
     args, sc, cams = _setup("clm_offload", "host")
     m = _make("clm_offload", sc, args)
     with torch.no_grad():
-        filters, cam_ids, g_ids = calculate_filters(cams, m.get_xyz, m.get_opacity, m.get_scaling, m.get_rotation)
+        filters, cam_ids, g_ids = calculate_filters(cams, m.get_xyz, m.get_opacity, m.get_scaling, m.get_rotation, return_ids=True)
     # same index sets as the oracle's packed projection (base_engine.py:36-73)
     vms = torch.stack([c.world_view_transform.t() for c in cams]).cpu()
     Ks = torch.stack([c.K for c in cams]).cpu()

@@ -413,3 +413,22 @@ def test_rasterize_large_gaussians_and_culling_exactness(dev):
     (img1 * vi.to(dev)).sum().backward()
     for name, x, y in zip(("means2d", "conics", "colors", "opacities"), b, a):
         assert rel_l2(x.grad.cpu(), y.grad) < GRAD_TOL, name
+
+
+@pytest.mark.parametrize("wh", [(64, 48), (70, 37), (160, 128)])
+def test_two_level_binning_equals_64bit_sort(dev, wh):
+    """Depth sort of rows + one stable tile-id sort == the single stable (tile|depth) sort, bit for bit
+    (including ties: duplicated depths keep row order)."""
+    from clm_gs_amd import gsplat as G
+    w, h = wh
+    s = small_scene(n=900, width=w, height=h, seed=41, log_scale=-1.0)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    d = d.clone()
+    d[0, 100:140] = d[0, 100]  # exact depth ties
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    _, i0, f0 = G.isect_tiles(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th)
+    o0 = G.isect_offset_encode(i0, 1, tw, th)
+    f1, o1, i1 = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th, want_isect_ids=True)
+    assert torch.equal(f1, f0) and torch.equal(o1, o0) and torch.equal(i1, i0)
+    _, ic, fc = O.isect_tiles(m2, radii, d, 16, tw, th)
+    assert torch.equal(f1.cpu(), fc) and torch.equal(i1.cpu(), ic)
