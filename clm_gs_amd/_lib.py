@@ -20,6 +20,7 @@ SIGNATURES = {
     "clmgs_version": (_i, []),
     "clmgs_last_error": (ctypes.c_char_p, []),
     "clmgs_projection_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "clmgs_visibility_raw": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "clmgs_projection_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_sh_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "clmgs_sh_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "clmgs_pair_overlap_count": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "clmgs_set_signal": (_i, [_vp, _vp, _i, ctypes.c_int32]),
     "clmgs_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i]),
+    "clmgs_adam_catch_up": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _d, _d, _i, _i, _i]),
     "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i, _vp, _i]),
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),

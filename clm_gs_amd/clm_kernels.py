@@ -233,6 +233,22 @@ def adam_rows(p, g, m, v, rows, col_lr, beta1, beta2, eps, step, bias_correction
                             int(bool(zero_grad))))
 
 
+def adam_catch_up(p, m, v, last_step, rows, col_lr, beta1, beta2, eps, to_step, bias_correction=True,
+                  max_replay=256):
+    """Replay the deferred zero-gradient Adam steps of `rows` (None = all) up to `to_step` and
+    stamp them (see clmgs_adam_catch_up)."""
+    L = _lib.lib()
+    n_rows = rows.numel() if rows is not None else p.shape[0]
+    check(L.clmgs_adam_catch_up(stream(), dptr(p, F32), dptr(m, F32), dptr(v, F32), dptr(last_step, I32),
+                                dptr(rows, None, True), _idx64(rows), int(n_rows), int(p.shape[-1]),
+                                dptr(col_lr, F32), float(beta1), float(beta2), float(eps), int(to_step),
+                                int(bool(bias_correction)), int(max_replay)))
+    if rows is None:
+        last_step[: p.shape[0]].fill_(int(to_step))
+    else:
+        last_step[rows.long()] = int(to_step)
+
+
 def densify_stats(filter_idx, v_means2d, radii, width, height, max_radii2D, xyz_gradient_accum,
                   denom, only_visible=True):
     """Fused form of gsplat_add_densification_stats[_exact_filter]

@@ -162,6 +162,55 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
   }
 }
 
+// Deferred ("lazy") dense Adam for rows that receive no gradient.  A row untouched for k steps
+// only needs   m <- b1 m,  v <- b2 v,  p <- p - lr/bc1_j * m / (sqrt(v)/sqrt(bc2_j) + eps)
+// k times -- nothing that depends on other rows or on data produced in between -- so the k updates
+// can be REPLAYED in registers the next time the row is needed, instead of streaming all N rows
+// through HBM every batch.  Same operations in the same order per element as the eager update
+// (bias corrections come from a running product in float instead of a double pow: ~1e-7 relative).
+// Steps older than max_replay are folded analytically (m *= b1^d, v *= b2^d): their parameter
+// increments are below half an ulp of p by then.
+template <typename IdxT>
+__global__ void __launch_bounds__(256)
+adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                     const int32_t* __restrict__ last_step, const void* __restrict__ rows,
+                     int64_t n_rows, int cols, const float* __restrict__ col_lr, float beta1,
+                     float beta2, float eps, int to_step, int bias_correction, int max_replay) {
+  const int64_t total = n_rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int k = (int)(i - r * cols);
+    const int64_t row = row_of<IdxT>(rows, r);
+    int a = last_step[row];
+    int missed = to_step - a;
+    if (missed <= 0) continue;
+    const int64_t o = row * cols + k;
+    float mm = m[o], vv = v[o], pp = p[o];
+    if (missed > max_replay) {
+      const int d = missed - max_replay;
+      mm *= powf(beta1, (float)d);
+      vv *= powf(beta2, (float)d);
+      a += d;
+      missed = max_replay;
+    }
+    const float lr = col_lr[k];
+    float pw1 = powf(beta1, (float)(a + 1)), pw2 = powf(beta2, (float)(a + 1));
+    for (int j = 0; j < missed; ++j) {
+      mm *= beta1;
+      vv *= beta2;
+      float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+      if (bias_correction) {
+        inv_bc1 = 1.f / (1.f - pw1);
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - pw2);
+      }
+      pp -= (lr * inv_bc1) * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+      pw1 *= beta1; pw2 *= beta2;
+    }
+    m[o] = mm; v[o] = vv; p[o] = pp;
+  }
+}
+
 // ------------------------------------------------------- densification stats
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(int64_t n, const int64_t* __restrict__ filter,
@@ -275,6 +324,27 @@ extern "C" int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float
                        g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1, ob2,
                        (float)eps,
                        inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
+                                   const int32_t* last_step, const void* rows, int idx_is_64,
+                                   int64_t n_rows, int cols, const float* col_lr, double beta1,
+                                   double beta2, double eps, int to_step, int bias_correction,
+                                   int max_replay) {
+  CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && to_step >= 0 && max_replay >= 1);
+  if (n_rows == 0) return 0;
+  CLMGS_CHECK_ARG(p && m && v && last_step && col_lr);
+  const int grid = min(ceil_div(n_rows * cols, 256), 256 * 8);
+  if (idx_is_64)
+    hipLaunchKernelGGL(adam_catch_up_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                       m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,
+                       (float)eps, to_step, bias_correction, max_replay);
+  else
+    hipLaunchKernelGGL(adam_catch_up_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
+                       m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,
+                       (float)eps, to_step, bias_correction, max_replay);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

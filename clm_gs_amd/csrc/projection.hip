@@ -35,6 +35,27 @@ projection_fwd_kernel(int C, int N, const float* __restrict__ means, const float
   }
 }
 
+// Visibility-only cull straight from the RAW parameters (log-scales; the quaternion is
+// normalised inside project_fwd anyway): what calculate_filters needs, without first
+// materialising exp / normalize / sigmoid over all N Gaussians every batch.
+__global__ void __launch_bounds__(256)
+visibility_raw_kernel(int C, int N, const float* __restrict__ means, const float* __restrict__ quats_raw,
+                      const float* __restrict__ log_scales, const float* __restrict__ viewmats,
+                      const float* __restrict__ Ks, float W, float H, float eps2d, float near_plane,
+                      float far_plane, float radius_clip, int32_t* __restrict__ radii) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float m[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    const float4 q4 = *reinterpret_cast<const float4*>(quats_raw + 4 * n);
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float s[3] = {__expf(log_scales[3 * n]), __expf(log_scales[3 * n + 1]), __expf(log_scales[3 * n + 2])};
+    for (int c = 0; c < C; ++c) {  // parameters are read once for all cameras of the batch
+      const Cam cam = load_cam(viewmats + 16 * c, Ks + 9 * c);
+      const Proj p = project_fwd(cam, m, q, s, W, H, eps2d, near_plane, far_plane, radius_clip);
+      radii[(size_t)c * N + n] = p.radius;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 projection_bwd_kernel(int C, int N, const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ viewmats,
@@ -89,6 +110,21 @@ extern "C" int clmgs_projection_fwd(void* stream, int C, int N, const float* mea
   hipLaunchKernelGGL(projection_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
                      quats, scales, viewmats, Ks, (float)width, (float)height, eps2d, near_plane,
                      far_plane, radius_clip, radii, means2d, depths, conics);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_visibility_raw(void* stream, int C, int N, const float* means,
+                                    const float* quats_raw, const float* log_scales,
+                                    const float* viewmats, const float* Ks, int width, int height,
+                                    float eps2d, float near_plane, float far_plane,
+                                    float radius_clip, int32_t* radii) {
+  CLMGS_CHECK_ARG(C >= 1 && N >= 0 && width > 0 && height > 0);
+  if (N == 0) return 0;
+  CLMGS_CHECK_ARG(means && quats_raw && log_scales && viewmats && Ks && radii);
+  hipLaunchKernelGGL(visibility_raw_kernel, dim3(min(ceil_div(N, 256), 256 * 16)), dim3(256), 0,
+                     (hipStream_t)stream, C, N, means, quats_raw, log_scales, viewmats, Ks,
+                     (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, radii);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

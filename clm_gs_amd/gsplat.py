@@ -93,14 +93,21 @@ def fully_fused_projection(means, covars, quats, scales, viewmats, Ks, width, he
 
 
 def visibility_radii(means, quats, scales, viewmats, Ks, width, height, eps2d=0.3,
-                     near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+                     near_plane=0.01, far_plane=1e10, radius_clip=0.0, raw=False):
     """radii[C,N] only: the cull of fully_fused_projection without writing the 24 B of
-    per-pair outputs (what calculate_filters, strategies/base_engine.py:18-76, needs)."""
+    per-pair outputs (what calculate_filters, strategies/base_engine.py:18-76, needs).
+    raw=True: `quats` un-normalised and `scales` as logs (the stored parameters)."""
     L = _lib.lib()
     means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
     viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
     C, N = viewmats.shape[0], means.shape[0]
     radii = torch.empty((C, N), dtype=I32, device=means.device)
+    if raw:
+        check(L.clmgs_visibility_raw(
+            stream(), C, N, dptr(means, F32), dptr(quats, F32), dptr(scales, F32), dptr(viewmats, F32),
+            dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+            float(radius_clip), dptr(radii)))
+        return radii
     check(L.clmgs_projection_fwd(
         stream(), C, N, dptr(means, F32), dptr(quats, F32), dptr(scales, F32), dptr(viewmats, F32),
         dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),

@@ -14,21 +14,23 @@ TILE_SIZE = 16
 
 
 def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotation_gpu,
-                      return_ids=False):
+                      return_ids=False, raw=False):
     """Per-camera visible index lists: ONE cull pass over (bsz cameras x N Gaussians).
 
     Same index sets as the packed projection the reference runs (base_engine.py:18-76) -- the
     cull is the projection's own (near plane, blur determinant, radius, off-screen) -- but only
     radii are written, and the (camera, gaussian) pairs are compacted with a single one-column
     nonzero over the flat [C*N] mask (camera boundaries by binary search on the sorted result).
-    Returns (filters, camera_ids, gaussian_ids); the id vectors only when return_ids."""
+    Returns (filters, camera_ids, gaussian_ids); the id vectors only when return_ids.
+    raw=True: scaling_gpu / rotation_gpu are the stored parameters (log-scales, un-normalised
+    quaternions) and the activations happen inside the cull kernel."""
     args = utils.get_args()
     with torch.no_grad():
         Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in batched_cameras])
         viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in batched_cameras])
         radii = visibility_radii(xyz_gpu, rotation_gpu, scaling_gpu, viewmats, Ks,
                                  int(utils.get_img_width()), int(utils.get_img_height()),
-                                 radius_clip=args.radius_clip)
+                                 radius_clip=args.radius_clip, raw=raw)
         C, N = radii.shape
         flat = torch.nonzero(radii.reshape(-1) > 0).flatten()  # sorted: camera-major, then gaussian
         edges = torch.searchsorted(flat, torch.arange(0, C + 1, device=flat.device) * N)

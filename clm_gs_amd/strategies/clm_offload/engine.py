@@ -222,8 +222,14 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
     with torch.no_grad():
-        filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
-                                          gaussians.get_scaling, gaussians.get_rotation)
+        if getattr(args, "fused_front_end", True):
+            # same fast exp as the fused front end -> filter and render agree on every cull
+            filters, _, _ = calculate_filters(batched_cameras, gaussians._xyz.detach(), None,
+                                              gaussians._scaling.detach(), gaussians._rotation.detach(),
+                                              raw=True)
+        else:
+            filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
+                                              gaussians.get_scaling, gaussians.get_rotation)
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
     touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
@@ -253,7 +259,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                               group["bias_correction"], 1.0 / bsz, True)
 
     touched_rows = torch.nonzero(touched).flatten().to(torch.int32)
-    if not args.stop_update_param and not args.sparse_adam:
+    lazy = gaussians.lazy_rows and not args.stop_update_param
+    if lazy:
+        # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
+        # (exactly the updates the eager pass would have streamed through HBM every batch);
+        # untouched rows are not visited at all.
+        gaussians.catch_up_rows(touched_rows, to_step=step - 1)
+    elif not args.stop_update_param and not args.sparse_adam:
         # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
         untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
         comm_stream.wait_stream(default_stream)
@@ -304,6 +316,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None)
     if not args.stop_update_param:
         row_update(touched_rows)
+        if lazy:
+            gaussians._row_last_step[touched_rows.long()] = step
     st["step"] = step
     if side_event is not None:
         default_stream.wait_event(side_event)
@@ -440,6 +454,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
         filters, _, _ = calculate_filters([camera], gaussians.get_xyz, gaussians.get_opacity,
                                           gaussians.get_scaling, gaussians.get_rotation)
         f = filters[0]
+        if getattr(gaussians, "lazy_rows", False):
+            gaussians.catch_up_rows(f.to(torch.int32))
         xyz = gaussians._xyz.detach()[f]
         opa = gaussians.opacity_activation(gaussians._opacity.detach()[f])
         sca = gaussians.scaling_activation(gaussians._scaling.detach()[f])

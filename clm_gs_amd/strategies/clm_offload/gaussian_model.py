@@ -97,6 +97,34 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         lr_scale = self._scale_groups_for_bsz(training_args)
         if training_args.lr_scale_mode in ("linear", "sqrt"):
             self.optimizer.columns_lr *= lr_scale
+        # deferred dense Adam (HBM rows only): optimizer step each row is current as of
+        self._row_last_step = None
+        if (not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True):
+            self._row_last_step = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+
+    # ---------------------------------------------------- deferred dense Adam
+    @property
+    def lazy_rows(self):
+        return getattr(self, "_row_last_step", None) is not None
+
+    def catch_up_rows(self, rows=None, to_step=None):
+        """Bring `rows` (None = all) up to date with the zero-gradient Adam steps they skipped."""
+        if not self.lazy_rows:
+            return
+        from ...clm_kernels import adam_catch_up
+        opt = self.optimizer.cpu_adam
+        g = opt.param_groups[0]
+        p = self._parameters
+        st = opt.state[p]
+        to_step = opt.global_step if to_step is None else to_step
+        if to_step <= 0:
+            return
+        col_lr = opt._col_lr(p.device)
+        adam_catch_up(p.data, st["exp_avg"], st["exp_avg_sq"], self._row_last_step, rows, col_lr,
+                      g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"])
+
+    def flush_lazy_rows(self):
+        self.catch_up_rows(None)
 
     def _rebind_row_state(self, n):
         """Point the row optimizer at the [:n] views after append / prune."""
@@ -148,7 +176,14 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def _append_rows(self, new):
         k = new["xyz"].shape[0]
         n = self._parameters.shape[0]
+        self.flush_lazy_rows()
         self._grow(n + k)
+        if self.lazy_rows:
+            if self._row_last_step.shape[0] < self.parameters_buffer.shape[0]:
+                grown = torch.zeros((self.parameters_buffer.shape[0],), dtype=torch.int32, device="cuda")
+                grown[:n] = self._row_last_step[:n]
+                self._row_last_step = grown
+            self._row_last_step[n:n + k] = self.optimizer.cpu_adam.global_step
         self.parameters_buffer[n:n + k].copy_(new["shs48"])
         self.parameters_grad_buffer[n:n + k].zero_()
         self._exp_avg_buffer[n:n + k].zero_()
@@ -166,6 +201,9 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         keep = ~mask
         n = self._parameters.shape[0]
         m = int(keep.sum())
+        self.flush_lazy_rows()  # afterwards every surviving row carries the same step stamp
+        if self.lazy_rows:
+            self._row_last_step[:m] = self.optimizer.cpu_adam.global_step
         keep_rows = keep.cpu() if self.sh_on_host else keep
         for attr in _ROW_BUFFERS:
             buf = getattr(self, attr)
@@ -179,6 +217,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self.max_radii2D = self.max_radii2D[keep]
 
     def _shs48_rows(self, mask):
+        self.flush_lazy_rows()
         p = self._parameters.detach()
         if mask is None:
             return p.clone() if p.is_cuda else p.cuda()

@@ -41,6 +41,13 @@ int clmgs_projection_fwd(void* stream, int C, int N, const float* means, const f
                          int height, float eps2d, float near_plane, float far_plane,
                          float radius_clip, int32_t* radii, float* means2d, float* depths,
                          float* conics);
+/* The same cull from the RAW parameters (quaternions un-normalised, scales as logs), radii[C,N]
+ * only: what calculate_filters (strategies/base_engine.py:18-76) needs, reading each Gaussian
+ * once for all C cameras and skipping the exp / normalize passes over N. */
+int clmgs_visibility_raw(void* stream, int C, int N, const float* means, const float* quats_raw,
+                         const float* log_scales, const float* viewmats, const float* Ks, int width,
+                         int height, float eps2d, float near_plane, float far_plane,
+                         float radius_clip, int32_t* radii);
 /* VJP of the above.  v_means[N,3], v_quats[N,4], v_scales[N,3] are overwritten
  * with the sum over the C cameras. */
 int clmgs_projection_bwd(void* stream, int C, int N, const float* means, const float* quats,
@@ -211,6 +218,15 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
                     int idx_is_64, const uint8_t* mask, int64_t n_rows, int cols,
                     const float* col_lr, double beta1, double beta2, double eps, int step,
                     int bias_correction, float grad_scale, int zero_grad);
+/* Deferred dense Adam: replay, for the listed rows (NULL = rows 0..n_rows-1), the zero-gradient
+ * updates of steps last_step[row]+1 .. to_step (moment decay + parameter step, same per-element
+ * operations as clmgs_adam_rows with g == NULL, bias corrections from a running product).  The
+ * caller then sets last_step[rows] = to_step.  Steps older than max_replay are folded into the
+ * moments analytically (their parameter increments are below float resolution). */
+int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v, const int32_t* last_step,
+                        const void* rows, int idx_is_64, int64_t n_rows, int cols,
+                        const float* col_lr, double beta1, double beta2, double eps, int to_step,
+                        int bias_correction, int max_replay);
 /* Host (OpenMP) variant on pinned/pageable host memory: cpu_adam.FusedCPUAdam row group
  * update (clm_offload/engine.py:316-328).  If signal != NULL, busy-waits until
  * *signal != 0 before touching the rows. */
