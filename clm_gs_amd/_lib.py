@@ -54,6 +54,7 @@ SIGNATURES = {
     "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i, _vp, _i]),
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
+    "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),
     "clmgs_pinned_free": (_i, [_vp]),
 }
@@ -94,7 +95,7 @@ class _Namespace:
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
               "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
-              "clmgs_pinned_alloc", "clmgs_pinned_free"}
+              "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters"}
 
 
 def timing_summary():

@@ -134,21 +134,34 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   int rs, re;
   tile_range(offsets, tile, n_tiles_total, n_isects, rs, re);
 
+  // Software-pipelined staging: the id -> record gather of round r+1 is issued before round r's
+  // blend loop and consumed after it, so its two dependent HBM/L2 latencies hide under compute.
+  // Two-deep: ids run two rounds ahead of the blend loop, records one round ahead, so neither of
+  // the two dependent gathers (id -> record) is ever waited for right after it is issued.
+  float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+  float nblue = 0.f;
+  int cur_g = (rs + lane < re) ? flatten_ids[rs + lane] : -1;        // ids of round 0
+  int nxt_g = (rs + 64 + lane < re) ? flatten_ids[rs + 64 + lane] : -1;  // ids of round 1
+  if (cur_g >= 0) {
+    const float4* rec = packed + REC_F4 * (size_t)cur_g;
+    nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
+  }
   for (int bs = rs; bs < re; bs += 64) {
     bool any_alive = false;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) any_alive |= alive[k];
     if (!__any(any_alive)) break;
-    const int idx = bs + lane;
-    int mask = 0;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
-    float blue = 0.f;
-    if (idx < re) {
-      const int g = flatten_ids[idx];
-      const float4* rec = packed + REC_F4 * (size_t)g;  // one 64 B line per Gaussian
-      A = rec[0]; B = rec[1];
-      blue = rec[2].x;
-      mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
+    const float4 A = nA, B = nB;
+    const float blue = nblue;
+    const int mask = (cur_g >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
+    cur_g = nxt_g;
+    if (cur_g >= 0) {  // records of the next round (their ids arrived a round ago)
+      const float4* rec = packed + REC_F4 * (size_t)cur_g;
+      nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
+    }
+    {
+      const int nidx = bs + 128 + lane;  // ids of the round after next
+      nxt_g = (nidx < re) ? flatten_ids[nidx] : -1;
     }
     const unsigned long long bal = __ballot(mask != 0);
     const int pos = __popcll(bal & ((1ull << lane) - 1ull));
@@ -213,10 +226,13 @@ struct TileLdsBwd {
   float acc[64][9];  // reduced per-Gaussian gradient of this tile
 };
 
-// DBG: profiling-only ablations (1 = skip the atomics flush, 2 = skip the DPP reduction too);
-// the product launches DBG = 0.
+// DBG: profiling-only variants (1 = skip the atomics flush, 2 = skip the reduction too, 3 = phase
+// timers + work counters accumulated into g_dbg, read with clmgs_debug_counters); the product
+// launches DBG = 0.
+__device__ unsigned long long g_dbg[16];
+#define DBG_CLK() (DBG == 3 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
 #ifndef CLMGS_BWD_WAVES
-#define CLMGS_BWD_WAVES 5
+#define CLMGS_BWD_WAVES 4  // 5 spills (96 VGPRs): scratch reloads force vmcnt(0) and kill the prefetch
 #endif
 template <int DBG>
 __global__ void __launch_bounds__(64, CLMGS_BWD_WAVES)
@@ -273,18 +289,34 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   }
   max_bin = wave_max_i32(max_bin);
   const int hi = min(re - 1, max_bin);  // nothing behind the deepest contributor matters
+  unsigned long long c_stage = 0, c_loop = 0, c_flush = 0, n_ent = 0, n_valid = 0, n_quad = 0, n_round = 0;
+  const unsigned long long t_begin = DBG_CLK();
 
+  // two-deep software-pipelined staging (see the forward kernel): ids two rounds ahead,
+  // records one round ahead; nothing is waited for right after issue, and the waits never
+  // include the previous round's atomics
+  float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+  float nblue = 0.f;
+  int cur_g = (hi - lane >= rs) ? flatten_ids[hi - lane] : -1;
+  int nxt_g = (hi - 64 - lane >= rs) ? flatten_ids[hi - 64 - lane] : -1;
+  if (cur_g >= 0) {
+    const float4* rec = packed + REC_F4 * (size_t)cur_g;
+    nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
+  }
   for (int bh = hi; bh >= rs; bh -= 64) {
-    const int idx = bh - lane;
-    int mask = 0, gid = 0;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
-    float blue = 0.f;
-    if (idx >= rs) {
-      gid = flatten_ids[idx];
-      const float4* rec = packed + REC_F4 * (size_t)gid;
-      A = rec[0]; B = rec[1];
-      blue = rec[2].x;
-      mask = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0);
+    const unsigned long long tA = DBG_CLK();
+    const float4 A = nA, B = nB;
+    const float blue = nblue;
+    const int gid = cur_g;
+    const int mask = (gid >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
+    cur_g = nxt_g;
+    if (cur_g >= 0) {
+      const float4* rec = packed + REC_F4 * (size_t)cur_g;
+      nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
+    }
+    {
+      const int nidx = bh - 128 - lane;
+      nxt_g = (nidx >= rs) ? flatten_ids[nidx] : -1;
     }
     const unsigned long long bal = __ballot(mask != 0);
     const int pos = __popcll(bal & ((1ull << lane) - 1ull));
@@ -295,6 +327,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       sm.id[pos] = gid;
     }
     __syncthreads();
+    const unsigned long long tB = DBG_CLK();
     unsigned long long touched = 0ull;
     for (int t = 0; t < bn; ++t) {
       const float4 RA = sm.a[t];
@@ -302,6 +335,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       const int meta = __builtin_amdgcn_readfirstlane(sm.meta[t]);
       const float rblue = sm.c[t];
       const int gi = bh - (meta >> 4);
+      if (DBG == 3) { n_ent++; n_quad += __popc(meta & 15); }
       float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_x = 0.f,
             g_y = 0.f, g_o = 0.f;
       bool any_valid = false;
@@ -337,7 +371,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
         }
       }
       if (!__any(any_valid)) continue;
-      if (DBG < 2) {
+      if (DBG == 3) n_valid++;
+      if (DBG != 2) {
         // 9 wave-wide sums: two 4-packs on the permlane-swap butterfly + one plain DPP chain
         const float u1 = wave_sum4_rows(g_x, g_y, g_ca, g_cb);   // lanes 15/31/47/63: x, ca, y, cb
         const float u2 = wave_sum4_rows(g_cc, g_r, g_g, g_b);    //                    cc, g, r, b
@@ -354,7 +389,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       touched |= (1ull << t);
     }
     __syncthreads();
-    if (DBG >= 1) {
+    const unsigned long long tC = DBG_CLK();
+    if (DBG == 1 || DBG == 2) {
       if (((touched >> lane) & 1ull) && sm.acc[lane][0] == 1.2345e30f) packed_grad[0] = 1.f;
     } else if ((touched >> lane) & 1ull) {
       // all nine atomics of a Gaussian land in its one 64 B gradient line
@@ -363,12 +399,34 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
 #pragma unroll
       for (int c = 0; c < 9; ++c) atomicAdd(dst + c, a[c]);
     }
+    if (DBG == 3) {
+      const unsigned long long tD = DBG_CLK();
+      c_stage += tB - tA; c_loop += tC - tB; c_flush += tD - tC; n_round++;
+    }
+  }
+  if (DBG == 3 && lane == 0) {
+    atomicAdd(&g_dbg[0], c_stage); atomicAdd(&g_dbg[1], c_loop); atomicAdd(&g_dbg[2], c_flush);
+    atomicAdd(&g_dbg[3], DBG_CLK() - t_begin); atomicAdd(&g_dbg[4], n_ent); atomicAdd(&g_dbg[5], n_valid);
+    atomicAdd(&g_dbg[6], n_quad); atomicAdd(&g_dbg[7], n_round); atomicAdd(&g_dbg[8], 1ull);
+    atomicAdd(&g_dbg[9], (unsigned long long)(re - rs));
   }
 }
 
 }  // namespace clmgs
 
 using namespace clmgs;
+
+// Profiling aid (CLMGS_BWD_DEBUG=3): stage / loop / flush / total cycles, entries, entries with a
+// valid pixel, quadrant passes, staging rounds, tiles, list length.  out[16]; reset != 0 clears.
+extern "C" int clmgs_debug_counters(unsigned long long* out, int reset) {
+  CLMGS_HIP(hipDeviceSynchronize());
+  CLMGS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    CLMGS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)));
+  }
+  return 0;
+}
 
 extern "C" size_t clmgs_rasterize_pack_bytes(int C, int N) {
   return (size_t)C * (size_t)N * REC_F4 * sizeof(float4);
@@ -428,7 +486,8 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
                      (const float4*)packed, backgrounds, width, height, tile_width, tile_height,   \
                      offsets, flatten_ids, render_alphas, last_ids, v_render_colors,               \
                      v_render_alphas, (float*)packed_grad)
-    if (dbg == 1) CLMGS_LAUNCH_BWD(1); else if (dbg == 2) CLMGS_LAUNCH_BWD(2); else CLMGS_LAUNCH_BWD(0);
+    if (dbg == 1) CLMGS_LAUNCH_BWD(1); else if (dbg == 2) CLMGS_LAUNCH_BWD(2);
+    else if (dbg == 3) CLMGS_LAUNCH_BWD(3); else CLMGS_LAUNCH_BWD(0);
 #undef CLMGS_LAUNCH_BWD
     CLMGS_LAUNCH_CHECK();
   }

@@ -46,9 +46,15 @@ def allreduce_rows(grad_rows, touched_global):
     ws = world_size()
     if ws == 1:
         return
-    rows = torch.nonzero(touched_global).flatten()
-    if rows.numel() == 0:
+    n_touched = int(touched_global.sum())
+    if n_touched == 0:
         return
+    if 2 * n_touched >= grad_rows.shape[0]:
+        # most rows are in play: reduce the whole buffer in place, no pack / unpack copies
+        dist.all_reduce(grad_rows, op=dist.ReduceOp.SUM)
+        grad_rows /= ws
+        return
+    rows = torch.nonzero(touched_global).flatten()
     buf = grad_rows[rows]
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     buf /= ws

@@ -248,6 +248,9 @@ int clmgs_densify_stats(void* stream, int64_t n, const int64_t* filter, const fl
  * integer distance matrix (greedy nearest neighbour + 2-opt until no improvement). */
 int clmgs_tsp_tour(int n, const int64_t* dist, int32_t* tour);
 
+/* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
+int clmgs_debug_counters(unsigned long long* out16, int reset);
+
 /* ---- pinned host memory  (numba.cuda.pinned_array at clm_offload/gaussian_model.py:34-44) */
 void* clmgs_pinned_alloc(size_t bytes);
 int clmgs_pinned_free(void* p);
