@@ -260,7 +260,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(a.config, {}).get(dom)
+                traffic = json.load(open(tpath)).get(a.config, {}).get(dom, {}).get("traffic")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
