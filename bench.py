@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
 
@@ -149,6 +150,10 @@ def main():
     N, W, H, bsz, vis_frac, desc = CONFIGS[a.config]
     args = utils.default_args(bsz=bsz, sh_residency=a.residency)
     setattr(args, a.strategy, True)
+    for kv in a.opt:
+        k, v = kv.split("=", 1)
+        cur = getattr(args, k)
+        setattr(args, k, (v.lower() in ("1", "true", "yes")) if isinstance(cur, bool) else type(cur)(v))
     utils.set_args(args)
     utils.set_img_size(H, W)
     torch.manual_seed(0)

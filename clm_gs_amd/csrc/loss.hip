@@ -11,7 +11,11 @@
 
 namespace clmgs {
 
-constexpr int LT = 16, LR = 5, LH = LT + 2 * LR;  // tile, radius, halo edge
+// 32x32 output pixels per 256-thread block (halo overhead 1.7x instead of 2.6x for 16x16) and
+// 4-wide register blocking of both separable passes: a thread loads 14 taps once and produces 4
+// neighbouring outputs, ~3x fewer LDS reads than one output per thread -- these kernels are
+// LDS-issue bound, not HBM bound.
+constexpr int LT = 32, LR = 5, LH = LT + 2 * LR;  // tile, radius, halo edge (42)
 constexpr int LOSS_SLOTS = 1024;                  // partial-sum slots (spreads the atomics)
 constexpr float L_C1 = 0.01f * 0.01f, L_C2 = 0.03f * 0.03f;
 
@@ -32,62 +36,86 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ void __launch_bounds__(256)
 loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float* __restrict__ partials,
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
-  __shared__ float sx[3][LH][LH + 1];
-  __shared__ float sy[3][LH][LH + 1];
+  __shared__ float sx[LH][LH + 1];
+  __shared__ float sy[LH][LH + 1];
   __shared__ float hz[5][LH][LT + 1];
   __shared__ float red[4];
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
-  for (int i = tid; i < LH * LH * 3; i += 256) {
-    const int r = i / (LH * 3), xc = i - r * (LH * 3);
-    const int cx = xc / 3, c = xc - cx * 3;
-    const int y = y0 + r - LR, x = x0 + cx - LR;
-    float a = 0.f, b = 0.f;
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      a = img.p[c * img.sc + y * img.sy + x * img.sx];
-      b = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
-    }
-    sx[c][r][cx] = a; sy[c][r][cx] = b;
-  }
-  const int ty = tid >> 4, tx = tid & 15;
-  const int y = y0 + ty, x = x0 + tx;
-  const bool in = (y < H) && (x < W);
+  float w[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) w[k] = l_win[k];
   float l1 = 0.f, ss = 0.f;
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
-    for (int i = tid; i < LH * LT; i += 256) {
-      const int r = i / LT, cc = i - r * LT;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const float w = l_win[k], a = sx[c][r][cc + k], b = sy[c][r][cc + k];
-        s0 += w * a; s1 += w * b; s2 += w * a * a; s3 += w * b * b; s4 += w * a * b;
+    for (int i = tid; i < LH * LH; i += 256) {
+      const int r = i / LH, cx = i - r * LH;
+      const int y = y0 + r - LR, x = x0 + cx - LR;
+      float a = 0.f, b = 0.f;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        a = img.p[c * img.sc + y * img.sy + x * img.sx];
+        b = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
       }
-      hz[0][r][cc] = s0; hz[1][r][cc] = s1; hz[2][r][cc] = s2; hz[3][r][cc] = s3; hz[4][r][cc] = s4;
+      sx[r][cx] = a; sy[r][cx] = b;
     }
     __syncthreads();
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: task = (row, 4 consecutive output columns)
+    for (int t = tid; t < LH * (LT / 4); t += 256) {
+      const int r = t / (LT / 4), c4 = (t - r * (LT / 4)) * 4;
+      float a[14], b[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = l_win[k];
-      mu1 += w * hz[0][ty + k][tx]; mu2 += w * hz[1][ty + k][tx];
-      e11 += w * hz[2][ty + k][tx]; e22 += w * hz[3][ty + k][tx]; e12 += w * hz[4][ty + k][tx];
+      for (int k = 0; k < 14; ++k) { a[k] = sx[r][c4 + k]; b[k] = sy[r][c4 + k]; }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const float av = a[o + k], bv = b[o + k], wk = w[k];
+          s0 += wk * av; s1 += wk * bv; s2 += wk * av * av; s3 += wk * bv * bv; s4 += wk * av * bv;
+        }
+        hz[0][r][c4 + o] = s0; hz[1][r][c4 + o] = s1; hz[2][r][c4 + o] = s2;
+        hz[3][r][c4 + o] = s3; hz[4][r][c4 + o] = s4;
+      }
     }
-    if (in) {
-      const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-      const float s1 = e11 - mu1sq, s2 = e22 - mu2sq, s12 = e12 - mu12;
-      const float A = 2.f * mu12 + L_C1, B = 2.f * s12 + L_C2;
-      const float D = mu1sq + mu2sq + L_C1, E = s1 + s2 + L_C2;
-      const float iDE = 1.f / (D * E);
-      const float val = A * B * iDE;
-      ss += val;
-      l1 += fabsf(sx[c][ty + LR][tx + LR] - sy[c][ty + LR][tx + LR]);
-      if (m1) {
-        const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 / D;
-        const float d_s1 = -val / E, d_s12 = 2.f * A * iDE;
-        const size_t o = c * plane + (size_t)y * W + x;
-        m1[o] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12; m2[o] = d_s1; m3[o] = d_s12;
+    __syncthreads();
+    // vertical pass: task = (column, 4 consecutive output rows); 256 tasks = one per thread
+    {
+      const int col = tid & 31, r4 = (tid >> 5) * 4;
+      float acc[5][4];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = hz[q][r4 + k][col];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; ++k) sacc += w[k] * v[o + k];
+          acc[q][o] = sacc;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int y = y0 + r4 + o, x = x0 + col;
+        if (y < H && x < W) {
+          const float mu1 = acc[0][o], mu2 = acc[1][o];
+          const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+          const float s1 = acc[2][o] - mu1sq, s2 = acc[3][o] - mu2sq, s12 = acc[4][o] - mu12;
+          const float A = 2.f * mu12 + L_C1, B = 2.f * s12 + L_C2;
+          const float D = mu1sq + mu2sq + L_C1, E = s1 + s2 + L_C2;
+          const float iDE = 1.f / (D * E);
+          const float val = A * B * iDE;
+          ss += val;
+          l1 += fabsf(sx[r4 + o + LR][col + LR] - sy[r4 + o + LR][col + LR]);
+          if (m1) {
+            const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 / D;
+            const float d_s1 = -val / E, d_s12 = 2.f * A * iDE;
+            const size_t oidx = c * plane + (size_t)y * W + x;
+            m1[oidx] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12; m2[oidx] = d_s1; m3[oidx] = d_s12;
+          }
+        }
       }
     }
   }
@@ -111,9 +139,9 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
   const float vv = v[0];
-  const int ty = tid >> 4, tx = tid & 15;
-  const int y = y0 + ty, x = x0 + tx;
-  const bool in = (y < H) && (x < W);
+  float w[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) w[k] = l_win[k];
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
     for (int i = tid; i < LH * LH; i += 256) {
@@ -127,30 +155,49 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
       sm[0][r][cc] = a; sm[1][r][cc] = b; sm[2][r][cc] = d;
     }
     __syncthreads();
-    for (int i = tid; i < LH * LT; i += 256) {
-      const int r = i / LT, cc = i - r * LT;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = tid; t < 3 * LH * (LT / 4); t += 256) {
+      const int q = t / (LH * (LT / 4)), rem = t - q * (LH * (LT / 4));
+      const int r = rem / (LT / 4), c4 = (rem - r * (LT / 4)) * 4;
+      float a[14];
 #pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const float w = l_win[k];
-        s0 += w * sm[0][r][cc + k]; s1 += w * sm[1][r][cc + k]; s2 += w * sm[2][r][cc + k];
+      for (int k = 0; k < 14; ++k) a[k] = sm[q][r][c4 + k];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) sacc += w[k] * a[o + k];
+        hz[q][r][c4 + o] = sacc;
       }
-      hz[0][r][cc] = s0; hz[1][r][cc] = s1; hz[2][r][cc] = s2;
     }
     __syncthreads();
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    {
+      const int col = tid & 31, r4 = (tid >> 5) * 4;
+      float g[3][4];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = l_win[k];
-      g0 += w * hz[0][ty + k][tx]; g1 += w * hz[1][ty + k][tx]; g2 += w * hz[2][ty + k][tx];
-    }
-    if (in) {
-      const int64_t o = c * img.sc + y * img.sy + x * img.sx;
-      const float xv = img.p[o];
-      const float yv = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
-      const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
-      const float dss = g0 + 2.f * xv * g1 + yv * g2;
-      v_img[o] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
+      for (int q = 0; q < 3; ++q) {
+        float vcol[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) vcol[k] = hz[q][r4 + k][col];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; ++k) sacc += w[k] * vcol[o + k];
+          g[q][o] = sacc;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int y = y0 + r4 + o, x = x0 + col;
+        if (y < H && x < W) {
+          const int64_t oi = c * img.sc + y * img.sy + x * img.sx;
+          const float xv = img.p[oi];
+          const float yv = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
+          const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
+          const float dss = g[0][o] + 2.f * xv * g[1][o] + yv * g[2][o];
+          v_img[oi] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
+        }
+      }
     }
   }
 }
