@@ -108,6 +108,7 @@ struct PreGrads {
   float* grad_accum;     // [N]
   float* denom;          // [N]
   float* v_means2d_out;  // [V,2] or NULL: copy of the screen-space gradient (API parity)
+  int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
 };
 
 __global__ void __launch_bounds__(PP_ROWS)
@@ -146,7 +147,8 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       // line: x y ca cb | cc r g b | o
       const float v_m2[2] = {ga.x, ga.y};
       if (o.v_means2d_out) *reinterpret_cast<float2*>(o.v_means2d_out + 2 * (size_t)i) = make_float2(ga.x, ga.y);
-      if (o.max_radii2D) {  // every filter row, as gsplat_add_densification_stats_exact_filter
+      if (o.max_radii2D && (radius > 0 || !o.stats_only_visible)) {  // default: every filter row,
+        // as gsplat_add_densification_stats_exact_filter; only_visible = the no_offload mask form
         const float gx = v_m2[0] * (0.5f * a.width), gy = v_m2[1] * (0.5f * a.height);
         o.max_radii2D[g] = fmaxf(o.max_radii2D[g], (float)radius);
         o.grad_accum[g] += sqrtf(gx * gx + gy * gy);
@@ -272,7 +274,7 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     const void* packed_grad, float* g_xyz, float* g_opacity,
                                     float* g_scaling, float* g_rotation, float* g_sh_rows,
                                     float* max_radii2D, float* grad_accum, float* denom,
-                                    float* v_means2d_out) {
+                                    float* v_means2d_out, int stats_only_visible) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && opacity_raw && scaling_raw && rotation_raw && sh_rows && viewmat_host &&
@@ -283,7 +285,7 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
-             v_means2d_out};
+             v_means2d_out, stats_only_visible};
   const size_t lds = PP_ROWS * PP_PITCH * sizeof(float);
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 3);
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(PP_ROWS), lds, (hipStream_t)stream, V, a,

@@ -43,7 +43,7 @@ def _np(a):
 
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
-                     return_event=False):
+                     return_event=False, stats_only_visible=False, visibility_out=None):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -56,7 +56,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
     dev = gaussians._xyz.device
-    V = int(this_filter.shape[0])
+    V = int(this_filter.shape[0]) if this_filter is not None else int(gaussians._xyz.shape[0])
     vm, K, campos = _cam_host(camera)
     deg = int(gaussians.active_sh_degree)
     xyz, opa = gaussians._xyz.detach(), gaussians._opacity.detach()
@@ -68,10 +68,10 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     colors = torch.empty((V, 3), dtype=F32, device=dev)
     opac = torch.empty((V,), dtype=F32, device=dev)
     packed = torch.empty((V, 16), dtype=F32, device=dev)
-    filt = this_filter.contiguous()
+    filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
     s = stream()
     check(L.clmgs_preprocess_fwd(
-        s, V, dptr(filt, torch.int64), dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32),
+        s, V, dptr(filt, torch.int64, True), dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32),
         dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
         dptr(depths), dptr(conics), dptr(colors), dptr(opac), dptr(packed)))
@@ -108,15 +108,17 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         utils.get_cur_iter() <= args.densify_until_iter
     if accumulate_after is not None:
         torch.cuda.current_stream().wait_event(accumulate_after)
+    if visibility_out is not None:
+        visibility_out |= (radii.reshape(-1) > 0)
     check(L.clmgs_preprocess_bwd(
-        s, V, dptr(filt), dptr(xyz), dptr(opa), dptr(sca), dptr(rot), dptr(sh_rows, F32, allow_host=True),
+        s, V, dptr(filt, torch.int64, True), dptr(xyz), dptr(opa), dptr(sca), dptr(rot), dptr(sh_rows, F32, allow_host=True),
         int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
         dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
         dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32),
         dptr(g_sh_rows, F32, allow_host=True),
         dptr(gaussians.max_radii2D if stats else None, F32, True),
         dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
-        dptr(gaussians.denom if stats else None, F32, True), None))
+        dptr(gaussians.denom if stats else None, F32, True), None, int(bool(stats_only_visible))))
     if keep is not None:
         keep += [packed, packed_grad, radii, filt]
     if return_event:

@@ -53,6 +53,8 @@ def baseline_accumGrads_impl(gaussians, scene, batched_cameras, background, scal
     """Activations once per batch, detached leaves accumulate over the cameras, then one
     backward through the activations.  Returns (losses, visibility | None); .grad lands on the
     model's six parameters (the optimizer step is the caller's, train.py:533-578)."""
+    if getattr(utils.get_args(), "fused_front_end", True) and scaling_modifier == 1.0:
+        return _baseline_fused(gaussians, scene, batched_cameras, background, sparse_adam)
     losses = []
     means3D = gaussians.get_xyz
     opacities_origin = gaussians.get_opacity
@@ -83,4 +85,30 @@ def baseline_accumGrads_impl(gaussians, scene, batched_cameras, background, scal
     scales_origin.backward(scales.grad)
     rotations_origin.backward(rotations.grad)
     shs_origin.backward(shs.grad)
+    return losses, visibility
+
+
+def _baseline_fused(gaussians, scene, batched_cameras, background, sparse_adam):
+    """Same batch through the fused front end (clm_gs_amd/fused.py): every camera runs over all N
+    rows (filter = None), raw-parameter gradients are accumulated in place (activation VJPs are
+    inside the kernel, so there is no separate "backward to origin" step), statistics follow the
+    radii > 0 mask form of densification.py:105-147."""
+    from ...fused import train_one_camera
+    dev = gaussians._xyz.device
+    N = gaussians._xyz.shape[0]
+    with torch.no_grad():
+        shs = gaussians.get_features.reshape(N, 48).contiguous()  # one [N,48] view of dc | rest
+        g_shs = torch.zeros_like(shs)
+        for p in (gaussians._xyz, gaussians._opacity, gaussians._scaling, gaussians._rotation):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        visibility = torch.zeros((N,), dtype=torch.bool, device=dev) if sparse_adam else None
+        losses = []
+        for camera in batched_cameras:
+            losses.append(train_one_camera(gaussians, camera, None, shs, 1, g_shs, background,
+                                           camera.original_image, stats_only_visible=True,
+                                           visibility_out=visibility))
+        g3 = g_shs.reshape(N, 16, 3)
+        for p, g in ((gaussians._features_dc, g3[:, :1, :]), (gaussians._features_rest, g3[:, 1:, :])):
+            p.grad = g.contiguous() if p.grad is None else p.grad + g
     return losses, visibility

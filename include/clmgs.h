@@ -136,7 +136,8 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * conics[V,3] colors[V,3] opacities[V] and the packed raster records packed[V,16].
  * bwd: from packed_grad[V,16] ACCUMULATES into g_xyz[N,3] g_opacity[N] g_scaling[N,3]
  * g_rotation[N,4] (raw-parameter gradients) and g_sh_rows (indexed like sh_rows), and, if
- * max_radii2D != NULL, updates the densification statistics of every filter row. */
+ * max_radii2D != NULL, updates the densification statistics of every filter row (or, with
+ * stats_only_visible, of the rows with radius > 0: densification.py:105-147). */
 int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,
@@ -151,7 +152,7 @@ int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float
                          int width, int height, int degree, float eps2d, const int32_t* radii,
                          const void* packed_grad, float* g_xyz, float* g_opacity, float* g_scaling,
                          float* g_rotation, float* g_sh_rows, float* max_radii2D, float* grad_accum,
-                         float* denom, float* v_means2d_out);
+                         float* denom, float* v_means2d_out, int stats_only_visible);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
  * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes
