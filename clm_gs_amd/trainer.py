@@ -1,0 +1,152 @@
+"""Thin training loop around the engines (scope row f1; reference: train.py:68-666).
+
+Keeps what the published numbers depend on: the image-strided iteration counter
+(train.py:202-204), xyz LR schedule per image index, SH-degree ramp every 1000 images
+(:253-254), the engine call (:316-432), gsplat_densification (:452), the no_offload optimizer
+epilogue (:533-578), the end-to-end timer that pauses during evaluation (:438-447, utils/timer.py:
+87-111), and the exact log strings release_scripts/log2csv.py:54-102 scrapes.  Dataset readers,
+checkpoint directories and CLI plumbing are out of scope: cameras are handed in as objects.
+"""
+import random
+import time
+
+import torch
+
+from . import utils
+from .densification import gsplat_densification
+
+
+class End2endTimer:
+    """utils/timer.py:87-111: wall clock that can be paused; throughput = iterations / total."""
+
+    def __init__(self):
+        self.total_time = 0.0
+        self.last_time_point = None
+
+    def start(self):
+        torch.cuda.synchronize()
+        self.last_time_point = time.time()
+
+    def stop(self):
+        torch.cuda.synchronize()
+        self.total_time += time.time() - self.last_time_point
+        self.last_time_point = None
+
+    def print_time(self, log_file, n_iterations):
+        log_file.write("end2end total_time: {:.3f} s, iterations: {}, throughput {:.2f} it/s\n".format(
+            self.total_time, n_iterations, n_iterations / max(self.total_time, 1e-9)))
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def _pinned_gb(gaussians):
+    tot = 0
+    for name in ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer"):
+        t = getattr(gaussians, name, None)
+        if isinstance(t, torch.Tensor) and t.numel() and not t.is_cuda:
+            tot += t.numel() * t.element_size()
+    return tot / 2 ** 30
+
+
+def memory_line(iteration, bsz, gaussians, what="densify_and_prune"):
+    """utils/general_utils.py:216-240 format (the part log2csv.py reads)."""
+    return ("iteration[{},{}) {}. Now num of 3dgs: {}. Now Memory usage: {} GB. Max Memory usage: {} GB. "
+            "Now Pinned Memory: {} GB\n").format(
+        iteration, iteration + bsz, what, gaussians.get_xyz.shape[0],
+        torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.max_memory_allocated() / 2 ** 30,
+        _pinned_gb(gaussians))
+
+
+@torch.no_grad()
+def evaluate(name, iteration, cameras, render_fn, log_file, max_images=10 ** 9):
+    """train.py:669-846 in essence: mean L1 / PSNR over a camera set."""
+    l1s, ps = [], []
+    for cam in cameras[:max_images]:
+        img = torch.clamp(render_fn(cam), 0.0, 1.0)
+        gt = torch.clamp(cam.original_image.float() / 255.0, 0.0, 1.0)
+        l1s.append((img - gt).abs().mean().item())
+        ps.append(psnr(img[None], gt[None]).mean().item())
+    l1, p = sum(l1s) / len(l1s), sum(ps) / len(ps)
+    log_file.write("[ITER {}] Evaluating {}: L1 {} PSNR {}\n".format(iteration, name, l1, p))
+    return l1, p
+
+
+def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations=None,
+             test_iterations=(), background=None, shuffle_seed=0):
+    """Runs `iterations` images of training; returns the End2endTimer."""
+    args = utils.get_args()
+    bsz = args.bsz
+    iterations = iterations or args.iterations
+    utils.set_log_file(log_file)
+    clm = bool(getattr(args, "clm_offload", False))
+    if clm:
+        from .strategies.clm_offload import clm_offload_eval_one_cam, clm_offload_train_one_batch
+        comm_stream = torch.cuda.Stream()
+        perm_generator = torch.Generator(device="cuda")
+        perm_generator.manual_seed(1)
+        render_fn = lambda cam: clm_offload_eval_one_cam(cam, gaussians, background, scene)
+    else:
+        from .strategies.no_offload import baseline_accumGrads_impl, baseline_accumGrads_micro_step
+
+        def render_fn(cam):
+            img, _, _, _ = baseline_accumGrads_micro_step(
+                gaussians.get_xyz, gaussians.get_opacity, gaussians.get_scaling, gaussians.get_rotation,
+                gaussians.get_features, gaussians.active_sh_degree, cam, background, mode="test")
+            return img
+    rng = random.Random(shuffle_seed)
+    order = []
+    timer = End2endTimer()
+    timer.start()
+    for iteration in range(1, iterations + 1, bsz):
+        utils.set_cur_iter(iteration)
+        gaussians.update_learning_rate(iteration)
+        if utils.check_update_at_this_iter(iteration, bsz, 1000, 0):
+            gaussians.oneupSHdegree()
+        if len(order) < bsz:  # new epoch: shuffle, drop_last (train.py:156-167)
+            order = list(range(len(train_cameras)))
+            rng.shuffle(order)
+        batch = [train_cameras[order.pop()] for _ in range(bsz)]
+        if clm:
+            losses, ordered_cams, sparsity = clm_offload_train_one_batch(
+                gaussians, scene, batch, gaussians.parameters_grad_buffer, background, None, comm_stream,
+                perm_generator)
+            names = [batch[i].image_name for i in ordered_cams]
+        else:
+            losses, visibility = baseline_accumGrads_impl(gaussians, scene, batch, background,
+                                                          sparse_adam=args.sparse_adam)
+            names, sparsity = [c.image_name for c in batch], None
+        batched_loss = torch.stack(losses).cpu().tolist()
+        log_file.write("iteration[{},{}) loss: {} image: {}".format(
+            iteration, iteration + bsz, " ".join("%.6f" % l for l in batched_loss), names))
+        log_file.write((" sparsity: " + " ".join("%.4f" % s for s in sparsity) + "\n") if sparsity else "\n")
+        if any(iteration <= t < iteration + bsz for t in test_iterations):
+            timer.stop()  # evaluation is excluded from the throughput figure
+            evaluate("train", iteration, train_cameras, render_fn, log_file, max_images=5)
+            if test_cameras:
+                evaluate("test", iteration, test_cameras, render_fn, log_file)
+            timer.start()
+        n_before = gaussians.get_xyz.shape[0]
+        gsplat_densification(iteration, scene, gaussians, None)
+        if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
+                iteration, bsz, args.densification_interval, 0):
+            log_file.write(memory_line(iteration, bsz, gaussians))
+        if not clm:  # train.py:533-578
+            if args.lr_scale_mode != "accumu":
+                for p in gaussians.all_parameters():
+                    if p.grad is not None:
+                        p.grad /= bsz
+            if args.sparse_adam:
+                gaussians.optimizer.step(visibility=visibility)
+            else:
+                gaussians.optimizer.step()
+            gaussians.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+    timer.stop()
+    n_done = ((iterations - 1) // bsz + 1) * bsz + 1
+    timer.print_time(log_file, n_done)
+    log_file.write(memory_line(iteration, bsz, gaussians, what="final"))
+    log_file.write("Max Memory usage: {} GB.\n".format(torch.cuda.max_memory_allocated() / 2 ** 30))
+    return timer

@@ -1,0 +1,83 @@
+"""-m gpu: the trainer loop end to end on a small synthetic scene (scope row f1): LR schedule,
+SH ramp, engine, densification (clone/split/prune + opacity reset), evaluation, and the exact log
+strings release_scripts/log2csv.py:54-102 parses."""
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _parse_like_log2csv(text):
+    """Same string surgery as release_scripts/log2csv.py:54-102 (restated, not imported)."""
+    m = {}
+    for line in reversed(text.splitlines()):
+        if "total_time_s" not in m and "end2end total_time:" in line:
+            m["total_time_s"] = float(line.split("end2end total_time: ")[1].split(" s")[0])
+            m["iterations"] = int(line.split("iterations: ")[1].split(",")[0])
+            m["throughput"] = float(line.split("throughput ")[1].split(" it/s")[0])
+        if "test_psnr" not in m and "Evaluating test:" in line:
+            m["test_psnr"] = float(line.split("PSNR ")[1].strip())
+        if "train_psnr" not in m and "Evaluating train:" in line:
+            m["train_psnr"] = float(line.split("PSNR ")[1].strip())
+        if "num_3dgs" not in m and "Now num of 3dgs:" in line and "Max Memory usage:" in line and "Now Pinned Memory:" in line:
+            m["num_3dgs"] = int(line.split("Now num of 3dgs: ")[1].split(".")[0])
+            m["max_gpu_memory_gb"] = float(line.split("Max Memory usage: ")[1].split(" GB")[0])
+            m["pinned_cpu_memory_gb"] = float(line.split("Now Pinned Memory: ")[1].split(" GB")[0])
+    return m
+
+
+@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("no_offload", "hbm"), ("clm_offload", "host")])
+def test_training_loop_improves_psnr_and_logs(dev, strategy, residency):
+    from clm_gs_amd import trainer, utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
+    from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    N, W, H, bsz = 20000, 160, 128, 4
+    args = utils.default_args(bsz=bsz, sh_residency=residency, densify_from_iter=100, densification_interval=100,
+                              densify_until_iter=300, densify_grad_threshold=0.00005)
+    setattr(args, strategy, True)
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    truth = synth_gaussians(N, seed=7, device="cuda")
+    cams = nadir_cameras(28, N, W, H, 0.3, seed=7, device="cuda")
+    gt_model = GaussianModelCLMOffload(3, only_for_rendering=True)
+    args_gt = utils.default_args(bsz=bsz, sh_residency="hbm")
+    gt_model.args = args_gt
+    gt_model.create_from_tensors(truth["xyz"], truth["shs48"], truth["scaling"], truth["rotation"], truth["opacity"])
+    gt_model.active_sh_degree = 3
+    for c in cams:
+        c.original_image = (clm_offload_eval_one_cam(c, gt_model, None, None).clamp(0, 1) * 255).round().to(torch.uint8)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    noisy_sh = truth["shs48"].clone()
+    noisy_sh[:, :3] += torch.randn((N, 3), generator=g, device="cuda") * 0.6   # wrong base colours
+    model = (GaussianModelCLMOffload if strategy == "clm_offload" else GaussianModelNoOffload)(3)
+    model.create_from_tensors(truth["xyz"] + torch.randn((N, 3), generator=g, device="cuda") * 0.05, noisy_sh,
+                              truth["scaling"], truth["rotation"], truth["opacity"], spatial_lr_scale=truth["extent"])
+    model.training_setup(args)
+    model.split_generator = torch.Generator(device="cuda").manual_seed(5)
+
+    class Scene:
+        cameras_extent = truth["extent"]
+
+    log = io.StringIO()
+    train_cams, test_cams = cams[:24], cams[24:]
+    timer = trainer.training(model, Scene, train_cams, test_cams, log, iterations=400,
+                             test_iterations=(1, 397))
+    text = log.getvalue()
+    m = _parse_like_log2csv(text)
+    for k in ("total_time_s", "iterations", "throughput", "test_psnr", "train_psnr", "num_3dgs",
+              "max_gpu_memory_gb", "pinned_cpu_memory_gb"):
+        assert k in m, (k, text[-800:])
+    assert m["iterations"] == 401 and m["throughput"] > 1
+    first_test = [l for l in text.splitlines() if "Evaluating test:" in l][0]
+    p0 = float(first_test.split("PSNR ")[1])
+    loss_lines = [l.split(" image:")[0] for l in text.splitlines() if " loss: " in l]
+    assert m["test_psnr"] > p0 + 1.0, (p0, m["test_psnr"], loss_lines[:3], loss_lines[-3:])
+    assert m["num_3dgs"] != N, "densification must have changed the model"
+    assert "Number of split gaussians" in text and "Number of cloned gaussians" in text
+    assert model.active_sh_degree == 0  # the first ramp step is at image 1000 (train.py:253-254)
+    if residency == "host":
+        assert m["pinned_cpu_memory_gb"] > 0
