@@ -232,6 +232,62 @@ class BaseGaussianModel(ABC):
         self.xyz_gradient_accum[send2gpu_visibility_filter] += torch.norm(g, dim=-1, keepdim=True)
         self.denom[send2gpu_visibility_filter] += 1
 
+    # ------------------------------------------------------------- checkpoint
+    def capture(self):
+        """Everything needed to resume training bit-for-bit in exact arithmetic: parameters,
+        optimizer moments and step counters, densification statistics (scope row f3; the
+        reference's capture/restore start with `assert False`, no_offload/gaussian_model.py:38-56)."""
+        if getattr(self, "lazy_rows", False):
+            self.flush_lazy_rows()
+        opt = {}
+        for g in self.optimizer.param_groups:
+            st = self.optimizer.state.get(g["params"][0], {})
+            opt[g["name"]] = {
+                "lr": g["lr"],
+                "exp_avg": st["exp_avg"].detach().cpu().clone() if "exp_avg" in st else None,
+                "exp_avg_sq": st["exp_avg_sq"].detach().cpu().clone() if "exp_avg_sq" in st else None,
+                "step": float(st["step"]) if "step" in st else 0.0,
+            }
+        row_adam = getattr(self.optimizer, "cpu_adam", None)
+        return {
+            "xyz": self._xyz.detach().cpu().clone(), "opacity": self._opacity.detach().cpu().clone(),
+            "scaling": self._scaling.detach().cpu().clone(), "rotation": self._rotation.detach().cpu().clone(),
+            "shs48": self._shs48_rows(None).cpu().clone(), "active_sh_degree": self.active_sh_degree,
+            "spatial_lr_scale": self.spatial_lr_scale, "optimizer": opt,
+            "row_global_step": row_adam.global_step if row_adam is not None else None,
+            "xyz_gradient_accum": self.xyz_gradient_accum.cpu().clone(), "denom": self.denom.cpu().clone(),
+            "max_radii2D": self.max_radii2D.cpu().clone(),
+        }
+
+    def restore(self, state, training_args):
+        self.create_from_tensors(state["xyz"], state["shs48"], state["scaling"], state["rotation"],
+                                 state["opacity"], state["spatial_lr_scale"])
+        self.active_sh_degree = state["active_sh_degree"]
+        self.training_setup(training_args)
+        for g in self.optimizer.param_groups:
+            saved = state["optimizer"][g["name"]]
+            p = g["params"][0]
+            g["lr"] = saved["lr"]
+            if saved["exp_avg"] is None:
+                continue
+            st = self.optimizer.state[p]
+            if "exp_avg" in st:  # row optimizer: state lives in the model's capacity buffers
+                st["exp_avg"].copy_(saved["exp_avg"])
+                st["exp_avg_sq"].copy_(saved["exp_avg_sq"])
+                st["step"] = int(saved["step"])
+            else:              # torch Adam creates its state lazily
+                st["step"] = torch.tensor(saved["step"], dtype=torch.float32, device=p.device)
+                st["exp_avg"] = saved["exp_avg"].to(p.device)
+                st["exp_avg_sq"] = saved["exp_avg_sq"].to(p.device)
+        row_adam = getattr(self.optimizer, "cpu_adam", None)
+        if row_adam is not None and state["row_global_step"] is not None:
+            row_adam.global_step = state["row_global_step"]
+            if getattr(self, "lazy_rows", False):
+                self._row_last_step.fill_(row_adam.global_step)
+        self.xyz_gradient_accum = state["xyz_gradient_accum"].cuda()
+        self.denom = state["denom"].cuda()
+        self.max_radii2D = state["max_radii2D"].cuda()
+
     # -------------------------------------------------------------------- I/O
     def save_tensors(self, folder):
         """Five-file .pt layout (clm_offload/gaussian_model.py:236-243)."""
@@ -242,6 +298,20 @@ class BaseGaussianModel(ABC):
         torch.save(self._scaling.detach().cpu(), os.path.join(folder, "scaling.pt"))
         torch.save(self._rotation.detach().cpu(), os.path.join(folder, "rotation.pt"))
         torch.save(self._shs48_rows(None).cpu(), os.path.join(folder, "parameters.pt"))
+
+    def save_ply(self, path):
+        """3DGS .ply (base_gaussian_model.py:189-248 layout), written without plyfile."""
+        import os
+        from ..io_ply import save_ply
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        save_ply(path, self._xyz, self._shs48_rows(None), self._opacity, self._scaling, self._rotation)
+
+    def load_ply(self, path, spatial_lr_scale=1.0):
+        from ..io_ply import load_ply
+        d = load_ply(path)
+        self.create_from_tensors(d["xyz"], d["shs48"], d["scaling"], d["rotation"], d["opacity"],
+                                 spatial_lr_scale)
+        self.active_sh_degree = self.max_sh_degree
 
     def load_tensors(self, folder, spatial_lr_scale=1.0):
         import os

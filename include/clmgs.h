@@ -249,6 +249,15 @@ int clmgs_densify_stats(void* stream, int64_t n, const int64_t* filter, const fl
  * integer distance matrix (greedy nearest neighbour + 2-opt until no improvement). */
 int clmgs_tsp_tour(int n, const int64_t* dist, int32_t* tour);
 
+/* ---- simple_knn._C.distCUDA2  (strategies/clm_offload/gaussian_model.py:60-63; init-time only)
+ * pts_sorted[n,3]: points sorted by grid cell id ((z*gy + y)*gx + x, cell = floor((p - origin)/h)
+ * clamped); cell_start[gx*gy*gz + 1] i32: first sorted index of every cell.  Writes the mean
+ * squared distance to the 3 nearest neighbours, in sorted order.  Exact while the answer lies
+ * within max_ring cells. */
+int clmgs_knn3_mean_dist2(void* stream, int n, const float* pts_sorted, const int32_t* cell_start,
+                          float ox, float oy, float oz, float h, int gx, int gy, int gz,
+                          int max_ring, float* mean_d2_sorted);
+
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);
 

@@ -192,6 +192,46 @@ def test_lazy_dense_adam_equals_eager(dev):
         assert rel_l2(a.cpu(), b.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("no_offload", "hbm")])
+def test_capture_restore_resumes_training(dev, strategy, residency):
+    """Working checkpoint incl. optimizer state (row f3): 2 batches -> capture -> 1 batch  ==
+    restore -> the same 1 batch."""
+    from clm_gs_amd import utils
+
+    def one_batch(m, cams, it):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        if strategy == "clm_offload":
+            from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+            clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None,
+                                        torch.cuda.Stream(), torch.Generator(device="cuda"))
+        else:
+            from clm_gs_amd.strategies.no_offload import baseline_accumGrads_impl
+            baseline_accumGrads_impl(m, _Scene, cams, None)
+            for p in m.all_parameters():
+                p.grad /= BSZ
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+
+    args, sc, cams = _setup(strategy, residency)
+    m = _make(strategy, sc, args)
+    one_batch(m, cams, 1)
+    one_batch(m, cams, 5)
+    state = m.capture()
+    before = m._xyz.detach().clone()
+    one_batch(m, cams, 9)
+    m2 = type(m)(3)
+    m2.restore(state, args)
+    assert torch.equal(m2._xyz.detach(), before)
+    one_batch(m2, cams, 9)
+    sh1 = m._shs48_rows(None)
+    sh2 = m2._shs48_rows(None)
+    for a, b, init in ((m._xyz, m2._xyz, before), (m._opacity, m2._opacity, state["opacity"].cuda()),
+                       (sh1, sh2, state["shs48"].cuda())):
+        assert _frac_differs(a.detach(), b.detach(), init, 0.02) < 0.01
+
+
 def test_order_calculation_invariants(dev):
     from clm_gs_amd.strategies.base_engine import calculate_filters
     from clm_gs_amd.strategies.clm_offload.engine import order_calculation

@@ -432,3 +432,16 @@ def test_two_level_binning_equals_64bit_sort(dev, wh):
     assert torch.equal(f1, f0) and torch.equal(o1, o0) and torch.equal(i1, i0)
     _, ic, fc = O.isect_tiles(m2, radii, d, 16, tw, th)
     assert torch.equal(f1.cpu(), fc) and torch.equal(i1.cpu(), ic)
+
+
+def test_distCUDA2_matches_brute_force(dev):
+    """simple_knn.distCUDA2: mean squared distance to the 3 nearest neighbours (row f3)."""
+    from clm_gs_amd.simple_knn import distCUDA2
+    g = torch.Generator().manual_seed(51)
+    pts = torch.cat([torch.randn(1500, 3, generator=g), torch.rand(700, 3, generator=g) * 10 - 5,
+                     torch.randn(300, 3, generator=g) * 0.01 + 3.0])  # clusters + sparse halo
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    want = d.topk(3, dim=1, largest=False).values.mean(dim=1)
+    got = distCUDA2(pts.to(dev)).cpu().double()
+    assert ((got - want).abs() / (want + 1e-12)).max() < 1e-4
