@@ -2,9 +2,9 @@
 // per-tile start offsets (gfx950).  Replaces gsplat.isect_tiles and
 // gsplat.isect_offset_encode (strategies/base_engine.py:175-186,
 // strategies/no_offload/engine.py:75-84, strategies/clm_offload/engine.py:89-100).
-#include <hipcub/hipcub.hpp>
-
+// Sorting and scanning are the hand-written kernels of radix.h (no rocPRIM / hipCUB).
 #include "common.h"
+#include "radix.h"
 
 namespace clmgs {
 
@@ -95,9 +95,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 using namespace clmgs;
 
 extern "C" size_t clmgs_isect_count_temp_bytes(int CN) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (int64_t*)nullptr, (int64_t*)nullptr, CN);
-  return align_up(bytes, 256) + 256;
+  return scan_scratch_bytes(CN) + 256;
 }
 
 extern "C" int clmgs_isect_count(void* stream, int C, int N, const float* means2d,
@@ -109,29 +107,19 @@ extern "C" int clmgs_isect_count(void* stream, int C, int N, const float* means2
   if (CN == 0) return 0;
   CLMGS_CHECK_ARG(CN < ((int64_t)1 << 31));
   CLMGS_CHECK_ARG(means2d && radii && tiles_per_gauss && cum && temp);
+  CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect_count_temp_bytes((int)CN));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(isect_count_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256), 0, s,
                      CN, means2d, radii, (float)tile_size, tile_width, tile_height,
                      tiles_per_gauss, cum);
   CLMGS_LAUNCH_CHECK();
-  size_t need = 0;
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, need, cum, cum, (int)CN, s);
-  CLMGS_CHECK_ARG(temp_bytes >= need);
-  CLMGS_HIP(hipcub::DeviceScan::InclusiveSum(temp, need, cum, cum, (int)CN, s));
-  return 0;
-}
-
-static size_t sort_scratch_bytes(int64_t n) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (int64_t*)nullptr, (int64_t*)nullptr,
-                                     (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)n, 0, 64);
-  return bytes;
+  return inclusive_scan_i64(s, CN, cum, (int64_t*)temp);
 }
 
 extern "C" size_t clmgs_isect_sort_temp_bytes(int64_t n_isects) {
   if (n_isects <= 0) return 256;
-  return align_up((size_t)n_isects * 8, 256) + align_up((size_t)n_isects * 4, 256) +
-         align_up(sort_scratch_bytes(n_isects), 256) + 256;
+  return align_up((size_t)n_isects * 8, 256) + 2 * align_up((size_t)n_isects * 4, 256) +
+         radix_table_bytes(n_isects) + 256;
 }
 
 extern "C" int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isects,
@@ -150,18 +138,20 @@ extern "C" int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isect
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   const int cam_bits = ilog2_floor((unsigned)C) + 1;
   char* base = (char*)temp;
-  int64_t* keys_in = (int64_t*)base;
-  base += align_up((size_t)n_isects * 8, 256);
-  int32_t* vals_in = (int32_t*)base;
-  base += align_up((size_t)n_isects * 4, 256);
-  size_t scratch = sort_scratch_bytes(n_isects);
+  uint64_t* keys_a = (uint64_t*)base; base += align_up((size_t)n_isects * 8, 256);
+  int32_t* vals_a = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  int32_t* vals_b = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  uint32_t* table = (uint32_t*)base;
   hipLaunchKernelGGL(isect_emit_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256), 0, s,
                      CN, N, means2d, radii, depths, cum, (float)tile_size, tile_width,
-                     tile_height, tile_bits, keys_in, vals_in);
+                     tile_height, tile_bits, (int64_t*)keys_a, vals_a);
   CLMGS_LAUNCH_CHECK();
-  CLMGS_HIP(hipcub::DeviceRadixSort::SortPairs(base, scratch, keys_in, isect_ids, vals_in,
-                                               flatten_ids, (unsigned)n_isects, 0,
-                                               32 + tile_bits + cam_bits, s));
+  uint64_t* sorted = nullptr;  // the caller's isect_ids doubles as the second key buffer
+  int rc = radix_sort_pairs<uint64_t>(s, n_isects, keys_a, (uint64_t*)isect_ids, vals_a, vals_b,
+                                      flatten_ids, 0, 32 + tile_bits + cam_bits, table, &sorted);
+  if (rc) return rc;
+  if (sorted != (uint64_t*)isect_ids)
+    CLMGS_HIP(hipMemcpyAsync(isect_ids, sorted, (size_t)n_isects * 8, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 
@@ -262,27 +252,11 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
   }
 }
 
-static size_t presort_scratch_bytes(int V) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (int32_t*)nullptr, (int32_t*)nullptr, V, 0, 32);
-  size_t scan = 0;
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan, (int64_t*)nullptr, (int64_t*)nullptr, V);
-  return bytes > scan ? bytes : scan;
-}
-
-static size_t tilesort_scratch_bytes(int64_t n) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)n, 0, 32);
-  return bytes;
-}
-
 }  // namespace clmgs
 
 extern "C" size_t clmgs_isect2_order_temp_bytes(int V) {
   if (V <= 0) return 256;
-  return 3 * align_up((size_t)V * 4, 256) + align_up(presort_scratch_bytes(V), 256) + 256;
+  return 4 * align_up((size_t)V * 4, 256) + radix_table_bytes(V) + scan_scratch_bytes(V) + 256;
 }
 
 // order[V] i32 (rows by depth, culled last), cum[V] i64 (inclusive tile counts in that order).
@@ -296,24 +270,27 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_order_temp_bytes(V));
   hipStream_t s = (hipStream_t)stream;
   char* base = (char*)temp;
-  uint32_t* k_in = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
-  uint32_t* k_out = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
-  int32_t* v_in = (int32_t*)base; base += align_up((size_t)V * 4, 256);
-  size_t scratch = presort_scratch_bytes(V);
+  uint32_t* k_a = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
+  uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
+  int32_t* v_a = (int32_t*)base; base += align_up((size_t)V * 4, 256);
+  int32_t* v_b = (int32_t*)base; base += align_up((size_t)V * 4, 256);
+  uint32_t* table = (uint32_t*)base; base += radix_table_bytes(V);
+  int64_t* scan_tmp = (int64_t*)base;
   const int grid = min(ceil_div(V, 256), 256 * 16);
-  hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, k_in, v_in);
+  hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, k_a, v_a);
   CLMGS_LAUNCH_CHECK();
-  CLMGS_HIP(hipcub::DeviceRadixSort::SortPairs(base, scratch, k_in, k_out, v_in, order, V, 0, 32, s));
+  uint32_t* sorted = nullptr;
+  int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
+  if (rc) return rc;
   hipLaunchKernelGGL(isect2_count_kernel, dim3(grid), dim3(256), 0, s, V, order, means2d, radii,
                      (float)tile_size, tile_width, tile_height, cum);
   CLMGS_LAUNCH_CHECK();
-  CLMGS_HIP(hipcub::DeviceScan::InclusiveSum(base, scratch, cum, cum, V, s));
-  return 0;
+  return inclusive_scan_i64(s, V, cum, scan_tmp);
 }
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
   if (n_isects <= 0) return 256;
-  return 3 * align_up((size_t)n_isects * 4, 256) + align_up(tilesort_scratch_bytes(n_isects), 256) + 256;
+  return 4 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
 }
 
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
@@ -335,18 +312,21 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && flatten_ids && temp);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_sort_temp_bytes(n_isects));
   char* base = (char*)temp;
-  uint32_t* k_in = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  uint32_t* k_out = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  int32_t* v_in = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  size_t scratch = tilesort_scratch_bytes(n_isects);
+  uint32_t* k_a = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  int32_t* v_a = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  int32_t* v_b = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  uint32_t* table = (uint32_t*)base;
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
-                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_in, v_in);
+                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a, v_a);
   CLMGS_LAUNCH_CHECK();
-  CLMGS_HIP(hipcub::DeviceRadixSort::SortPairs(base, scratch, k_in, k_out, v_in, flatten_ids,
-                                               (unsigned)n_isects, 0, tile_bits, s));
+  uint32_t* sorted = nullptr;
+  int rc = radix_sort_pairs<uint32_t>(s, n_isects, k_a, k_b, v_a, v_b, flatten_ids, 0, tile_bits, table,
+                                      &sorted);
+  if (rc) return rc;
   hipLaunchKernelGGL(isect2_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0,
-                     s, n_isects, k_out, n_tiles, offsets, flatten_ids, depths, isect_ids);
+                     s, n_isects, sorted, n_tiles, offsets, flatten_ids, depths, isect_ids);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

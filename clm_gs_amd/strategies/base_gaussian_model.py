@@ -233,6 +233,15 @@ class BaseGaussianModel(ABC):
         self.denom[send2gpu_visibility_filter] += 1
 
     # ------------------------------------------------------------- checkpoint
+    def _opt_state(self, p):
+        """State dict of parameter p in the optimizer that OWNS it (UnifiedAdam.state is only a
+        merged snapshot of its two sub-optimizers)."""
+        o = self.optimizer
+        for sub in (getattr(o, "gpu_adam", None), getattr(o, "cpu_adam", None)):
+            if sub is not None and any(p is q for g in sub.param_groups for q in g["params"]):
+                return sub.state[p]
+        return o.state[p]
+
     def capture(self):
         """Everything needed to resume training bit-for-bit in exact arithmetic: parameters,
         optimizer moments and step counters, densification statistics (scope row f3; the
@@ -241,7 +250,7 @@ class BaseGaussianModel(ABC):
             self.flush_lazy_rows()
         opt = {}
         for g in self.optimizer.param_groups:
-            st = self.optimizer.state.get(g["params"][0], {})
+            st = self._opt_state(g["params"][0])
             opt[g["name"]] = {
                 "lr": g["lr"],
                 "exp_avg": st["exp_avg"].detach().cpu().clone() if "exp_avg" in st else None,
@@ -270,7 +279,7 @@ class BaseGaussianModel(ABC):
             g["lr"] = saved["lr"]
             if saved["exp_avg"] is None:
                 continue
-            st = self.optimizer.state[p]
+            st = self._opt_state(p)
             if "exp_avg" in st:  # row optimizer: state lives in the model's capacity buffers
                 st["exp_avg"].copy_(saved["exp_avg"])
                 st["exp_avg_sq"].copy_(saved["exp_avg_sq"])
