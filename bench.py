@@ -137,11 +137,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if os.environ.get("CLMGS_SHARE_GPU") == "1":  # test hook: several ranks on one device
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CLMGS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
 
     from clm_gs_amd import _lib, dp, utils
@@ -202,7 +208,7 @@ def main():
             gaussians.optimizer.step()
             gaussians.optimizer.zero_grad(set_to_none=True)
             sparsity = None
-        state["iteration"] += bsz
+        state["iteration"] += bsz * world
         return losses, sparsity
 
     def fence():

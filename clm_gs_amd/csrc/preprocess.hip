@@ -10,12 +10,14 @@
 // but in 2 kernels instead of ~35 small ones (4 gathers, 3 activations, projection, dirs, SH,
 // clamp, pack | unpack, clamp', SH', dirs', projection', activation', 4 index_add, stats).
 // HBM-bound: 236 B of parameters in + ~100 B of per-row outputs per visible Gaussian.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gs_math.h"
 
 namespace clmgs {
 
-constexpr int PP_ROWS = 256;
+constexpr int PP_ROWS = 64;   // one wavefront owns a chunk of 64 rows; no workgroup barriers
 constexpr int PP_PITCH = 52;  // floats per LDS row (see sh.hip)
 
 struct PreArgs {
@@ -33,63 +35,132 @@ struct PreArgs {
   float eps2d, near_plane, far_plane, radius_clip;
 };
 
+// The SH staging registers are 12 NAMED float4 variables, not an array: an alloca of 192 B is
+// above the backend's promote-to-vector budget at this occupancy and would live in scratch.
+#define CLMGS_FOR12(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+#define CLMGS_DECL_ST(j) float4 st##j = make_float4(0.f, 0.f, 0.f, 0.f);
+#define CLMGS_ELEM(j) const int e = t + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ void __launch_bounds__(PP_ROWS)
+// LDS hand-over between the lanes of ONE wavefront: orders the compiler's memory operations and
+// costs no s_waitcnt (a wave's LDS operations execute in order); unlike __syncthreads() it does
+// not drain vmcnt, so gathers stay in flight across it.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Both kernels are software-pipelined around HBM latency (the row gathers are scattered 64-192 B
+// pieces: latency- not bandwidth-limited at 3 waves/SIMD):
+//   * each wavefront works alone on 64-row chunks (row ids travel by ds_bpermute, LDS rows are
+//     wave private), so nothing ever waits on a workgroup barrier or its vmcnt(0);
+//   * the row id (and radius) of the NEXT chunk is fetched while the current one computes;
+//   * the lane's own small attributes are requested first, the chunk's SH rows second, so the
+//     projection arithmetic runs while the SH rows are still in flight (vmcnt is in-order: the
+//     wait for the attributes does not wait for the rows);
+//   * all gathers are unconditional with clamped / redirected addresses (dead rows re-read row
+//     0): no per-element branches, the staging registers never leave the VGPR file;
+//   * backward: the current values of every read-modify-write target are requested up front
+//     together with the inputs, and the SH gradient rows while the SH VJP computes.
+// OVERLAP = false (no filter: most rows are culled) projects first and stages only live rows.
+template <int DEG, bool OVERLAP>
+__global__ void __launch_bounds__(PP_ROWS, 3)
 preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __restrict__ means2d,
                       float* __restrict__ depths, float* __restrict__ conics,
                       float* __restrict__ colors, float* __restrict__ opacities,
                       float4* __restrict__ packed) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int64_t rowid[PP_ROWS];
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  constexpr int NF4 = (NB * 3 + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float lds[PP_ROWS * PP_PITCH];
   const Cam cam = load_cam(a.viewmat, a.K);
-  const int nb = (a.degree + 1) * (a.degree + 1);
-  const int nf4 = (nb * 3 + 3) / 4;
   const int n_chunks = (V + PP_ROWS - 1) / PP_ROWS;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const int t = threadIdx.x;
+  int chunk = blockIdx.x;
+  int my_row = -1;
+  if (chunk < n_chunks && chunk * PP_ROWS + t < V)
+    my_row = a.filter ? (int)a.filter[chunk * PP_ROWS + t] : chunk * PP_ROWS + t;
+  for (; chunk < n_chunks; chunk += gridDim.x) {
     const int base = chunk * PP_ROWS;
-    const int rows = min(PP_ROWS, V - base);
-    __syncthreads();
-    if (threadIdx.x < rows) rowid[threadIdx.x] = a.filter ? a.filter[base + threadIdx.x] : (int64_t)(base + threadIdx.x);
-    __syncthreads();
-    // stage the SH rows of this chunk (row-granular gather, 16 B per lane, coalesced within rows)
-    for (int i = threadIdx.x; i < rows * nf4; i += PP_ROWS) {
-      const int r = i / nf4, k = i - r * nf4;
-      const int64_t src = a.sh_by_filter ? rowid[r] : (int64_t)(base + r);
-      *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) =
-          *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);
+    const bool mine = my_row >= 0;
+    const int64_t g = mine ? my_row : 0;
+    const float m[3] = {a.xyz[3 * g], a.xyz[3 * g + 1], a.xyz[3 * g + 2]};
+    const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * g);
+    const float s[3] = {a.scaling_raw[3 * g], a.scaling_raw[3 * g + 1], a.scaling_raw[3 * g + 2]};
+    const float oraw = a.opacity_raw[g];
+    CLMGS_FOR12(CLMGS_DECL_ST)
+    if (OVERLAP) {
+#define CLMGS_X(j)                                                                                  \
+  if constexpr (j < NF4) {                                                                          \
+    CLMGS_ELEM(j)                                                                                   \
+    const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, r) : (int64_t)min(base + r, V - 1); \
+    st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
+  }
+      CLMGS_FOR12(CLMGS_X)
+#undef CLMGS_X
     }
-    __syncthreads();
-    if (threadIdx.x < rows) {
-      const int i = base + threadIdx.x;
-      const int64_t g = rowid[threadIdx.x];
-      const float m[3] = {a.xyz[3 * g], a.xyz[3 * g + 1], a.xyz[3 * g + 2]};
-      const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * g);
+    {  // row id of this wave's next chunk
+      const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
+      my_row = -1;
+      if (ni < V) my_row = a.filter ? (int)a.filter[ni] : ni;
+    }
+    Proj p;
+    p.radius = 0; p.mx = p.my = p.depth = p.ca = p.cb = p.cc = 0.f;
+    float o = 0.f;
+    if (mine) {
       const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-      const float s[3] = {__expf(a.scaling_raw[3 * g]), __expf(a.scaling_raw[3 * g + 1]), __expf(a.scaling_raw[3 * g + 2])};
-      const float o = sigmoidf(a.opacity_raw[g]);
-      const Proj p = project_fwd(cam, m, q, s, (float)a.width, (float)a.height, a.eps2d, a.near_plane,
-                                 a.far_plane, a.radius_clip);
+      const float se[3] = {__expf(s[0]), __expf(s[1]), __expf(s[2])};
+      o = sigmoidf(oraw);
+      p = project_fwd(cam, m, q, se, (float)a.width, (float)a.height, a.eps2d, a.near_plane,
+                      a.far_plane, a.radius_clip);
+    }
+    wave_lds_sync();  // the previous chunk's LDS rows are consumed
+    if (OVERLAP) {
+#define CLMGS_X(j)                                                                                  \
+  if constexpr (j < NF4) {                                                                          \
+    CLMGS_ELEM(j)                                                                                   \
+    *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) = st##j;                                 \
+  }
+      CLMGS_FOR12(CLMGS_X)
+#undef CLMGS_X
+    } else {
+      const unsigned long long live = __ballot(p.radius > 0);
+      const int first = live ? (int)__builtin_ctzll(live) : 0;
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < NF4; ++j) {
+          const int e = t + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
+          const int rr = ((live >> r) & 1ull) ? r : first;  // dead rows re-read a live one (cache hit)
+          const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);
+          *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) =
+              *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);
+        }
+      }
+    }
+    wave_lds_sync();
+    if (mine) {
+      const int i = base + t;
       float cr = 0.f, cg = 0.f, cb = 0.f;
       if (p.radius > 0) {
         float x = m[0] - a.campos[0], y = m[1] - a.campos[1], z = m[2] - a.campos[2];
         const float inv = 1.0f / sqrtf(x * x + y * y + z * z);
         x *= inv; y *= inv; z *= inv;
         float B[16];
-        sh_basis(a.degree, x, y, z, B);
-        const float* row = lds + threadIdx.x * PP_PITCH;
+        sh_basis(DEG, x, y, z, B);
+        const float* row = lds + t * PP_PITCH;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < nb) { cr += B[k] * row[3 * k]; cg += B[k] * row[3 * k + 1]; cb += B[k] * row[3 * k + 2]; }
-        }
+        for (int k = 0; k < NB; ++k) { cr += B[k] * row[3 * k]; cg += B[k] * row[3 * k + 1]; cb += B[k] * row[3 * k + 2]; }
         cr = fmaxf(cr + 0.5f, 0.f); cg = fmaxf(cg + 0.5f, 0.f); cb = fmaxf(cb + 0.5f, 0.f);
       }
       radii[i] = p.radius;
       *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(p.mx, p.my);
       depths[i] = p.depth;
-      conics[3 * (size_t)i] = p.ca; conics[3 * (size_t)i + 1] = p.cb; conics[3 * (size_t)i + 2] = p.cc;
-      colors[3 * (size_t)i] = cr; colors[3 * (size_t)i + 1] = cg; colors[3 * (size_t)i + 2] = cb;
-      opacities[i] = o;
+      if (conics) {  // optional: the packed record carries the same values for the tile kernels
+        conics[3 * (size_t)i] = p.ca; conics[3 * (size_t)i + 1] = p.cb; conics[3 * (size_t)i + 2] = p.cc;
+        colors[3 * (size_t)i] = cr; colors[3 * (size_t)i + 1] = cg; colors[3 * (size_t)i + 2] = cb;
+        opacities[i] = o;
+      }
       float4* rec = packed + 4 * (size_t)i;
       rec[0] = make_float4(p.mx, p.my, o, p.ca);
       rec[1] = make_float4(p.cb, p.cc, cr, cg);
@@ -111,113 +182,153 @@ struct PreGrads {
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
 };
 
-__global__ void __launch_bounds__(PP_ROWS)
+template <int DEG, bool EARLY, int WAVES>
+__global__ void __launch_bounds__(PP_ROWS, WAVES)
 preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
                       const float4* __restrict__ packed_grad, PreGrads o) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int64_t rowid[PP_ROWS];
-  __shared__ uint8_t live[PP_ROWS];
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  constexpr int NF4 = (NB * 3 + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float lds[PP_ROWS * PP_PITCH];
   const Cam cam = load_cam(a.viewmat, a.K);
-  const int nb = (a.degree + 1) * (a.degree + 1);
-  const int nf4 = (nb * 3 + 3) / 4;
   const int n_chunks = (V + PP_ROWS - 1) / PP_ROWS;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const int t = threadIdx.x;
+  int chunk = blockIdx.x;
+  int my_row = -1, my_radius = 0;
+  if (chunk < n_chunks && chunk * PP_ROWS + t < V) {
+    const int i = chunk * PP_ROWS + t;
+    my_row = a.filter ? (int)a.filter[i] : i;
+    my_radius = radii[i];
+  }
+  for (; chunk < n_chunks; chunk += gridDim.x) {
     const int base = chunk * PP_ROWS;
-    const int rows = min(PP_ROWS, V - base);
-    __syncthreads();
-    if (threadIdx.x < rows) {
-      rowid[threadIdx.x] = a.filter ? a.filter[base + threadIdx.x] : (int64_t)(base + threadIdx.x);
-      live[threadIdx.x] = radii[base + threadIdx.x] > 0;
+    const int radius = my_radius;
+    const bool mine = my_row >= 0;
+    const bool vis = mine && radius > 0;
+    const bool stat = mine && o.max_radii2D && (radius > 0 || !o.stats_only_visible);
+    const unsigned long long live = __ballot(vis);
+    const int first = live ? (int)__builtin_ctzll(live) : 0;
+    // dead lanes redirect every gather to the chunk's first live row: no branches, cache hits
+    const int64_t g = mine ? my_row : 0;
+    const int64_t gl = vis ? g : (int64_t)__shfl((int)g, first);
+    const int i = mine ? base + t : base;
+    // ---- everything this lane needs from HBM, requested at once
+    const float4 ga = packed_grad[4 * (size_t)i];   // line: x y ca cb | cc r g b | o
+    const float4 gb = packed_grad[4 * (size_t)i + 1];
+    const float go = packed_grad[4 * (size_t)i + 2].x;
+    const float m[3] = {a.xyz[3 * gl], a.xyz[3 * gl + 1], a.xyz[3 * gl + 2]};
+    const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * gl);
+    const float s[3] = {a.scaling_raw[3 * gl], a.scaling_raw[3 * gl + 1], a.scaling_raw[3 * gl + 2]};
+    const float oraw = a.opacity_raw[gl];
+    const float c_xyz[3] = {o.g_xyz[3 * gl], o.g_xyz[3 * gl + 1], o.g_xyz[3 * gl + 2]};
+    const float c_sc[3] = {o.g_scaling[3 * gl], o.g_scaling[3 * gl + 1], o.g_scaling[3 * gl + 2]};
+    const float4 c_rot = *reinterpret_cast<const float4*>(o.g_rotation + 4 * gl);
+    const float c_op = o.g_opacity[gl];
+    float c_mr = 0.f, c_ga = 0.f, c_dn = 0.f;
+    if (o.max_radii2D) { c_mr = o.max_radii2D[g]; c_ga = o.grad_accum[g]; c_dn = o.denom[g]; }
+    CLMGS_FOR12(CLMGS_DECL_ST)
+#define CLMGS_LOAD_SH(j)                                                                            \
+  if constexpr (j < NF4) {                                                                          \
+    CLMGS_ELEM(j)                                                                                   \
+    const int rr = ((live >> r) & 1ull) ? r : first;                                                \
+    const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);        \
+    st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
+  }
+    if (EARLY) { CLMGS_FOR12(CLMGS_LOAD_SH) }
+    {
+      const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
+      my_row = -1; my_radius = 0;
+      if (ni < V) { my_row = a.filter ? (int)a.filter[ni] : ni; my_radius = radii[ni]; }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < rows * nf4; i += PP_ROWS) {
-      const int r = i / nf4, k = i - r * nf4;
-      if (!live[r]) continue;
-      const int64_t src = a.sh_by_filter ? rowid[r] : (int64_t)(base + r);
-      *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) =
-          *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);
+    // ---- statistics + projection VJP while the SH rows are in flight
+    const float v_m2[2] = {ga.x, ga.y};
+    if (mine && o.v_means2d_out) *reinterpret_cast<float2*>(o.v_means2d_out + 2 * (size_t)i) = make_float2(ga.x, ga.y);
+    if (stat) {  // default: every filter row, as gsplat_add_densification_stats_exact_filter;
+      // only_visible = the no_offload mask form
+      const float gx = v_m2[0] * (0.5f * a.width), gy = v_m2[1] * (0.5f * a.height);
+      o.max_radii2D[g] = fmaxf(c_mr, (float)radius);
+      o.grad_accum[g] = c_ga + sqrtf(gx * gx + gy * gy);
+      o.denom[g] = c_dn + 1.f;
     }
-    __syncthreads();
-    if (threadIdx.x < rows) {
-      const int i = base + threadIdx.x;
-      const int64_t g = rowid[threadIdx.x];
-      const int radius = radii[i];
-      const float4 ga = packed_grad[4 * (size_t)i], gb = packed_grad[4 * (size_t)i + 1];
-      const float go = packed_grad[4 * (size_t)i + 2].x;
-      // line: x y ca cb | cc r g b | o
-      const float v_m2[2] = {ga.x, ga.y};
-      if (o.v_means2d_out) *reinterpret_cast<float2*>(o.v_means2d_out + 2 * (size_t)i) = make_float2(ga.x, ga.y);
-      if (o.max_radii2D && (radius > 0 || !o.stats_only_visible)) {  // default: every filter row,
-        // as gsplat_add_densification_stats_exact_filter; only_visible = the no_offload mask form
-        const float gx = v_m2[0] * (0.5f * a.width), gy = v_m2[1] * (0.5f * a.height);
-        o.max_radii2D[g] = fmaxf(o.max_radii2D[g], (float)radius);
-        o.grad_accum[g] += sqrtf(gx * gx + gy * gy);
-        o.denom[g] += 1.f;
+    float vm[3] = {0.f, 0.f, 0.f};
+    if (vis) {
+      const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      const float se[3] = {__expf(s[0]), __expf(s[1]), __expf(s[2])};
+      const float op = sigmoidf(oraw);
+      const float v_con[3] = {ga.z, ga.w, gb.x};
+      float vq[4], vs[3];
+      project_bwd(cam, m, q, se, (float)a.width, (float)a.height, a.eps2d, v_m2, 0.f, v_con, vm, vq, vs);
+      o.g_scaling[3 * g] = c_sc[0] + vs[0] * se[0];
+      o.g_scaling[3 * g + 1] = c_sc[1] + vs[1] * se[1];
+      o.g_scaling[3 * g + 2] = c_sc[2] + vs[2] * se[2];
+      *reinterpret_cast<float4*>(o.g_rotation + 4 * g) =
+          make_float4(c_rot.x + vq[0], c_rot.y + vq[1], c_rot.z + vq[2], c_rot.w + vq[3]);
+      o.g_opacity[g] = c_op + go * op * (1.f - op);
+    }
+    if (!live) continue;  // wave-uniform: nothing of this chunk reached the screen
+    // ---- SH rows -> LDS; their registers then prefetch the gradient rows to accumulate into
+    if (!EARLY) { CLMGS_FOR12(CLMGS_LOAD_SH) }  // register-lean variant: SH rows requested only now
+#undef CLMGS_LOAD_SH
+    wave_lds_sync();  // the previous chunk's LDS rows are consumed
+#define CLMGS_X(j)                                                                                  \
+  if constexpr (j < NF4) {                                                                          \
+    CLMGS_ELEM(j)                                                                                   \
+    *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) = st##j;                                 \
+    const int rr = ((live >> r) & 1ull) ? r : first;                                                \
+    const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);    \
+    st##j = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);                   \
+  }
+    CLMGS_FOR12(CLMGS_X)
+#undef CLMGS_X
+    wave_lds_sync();
+    if (vis) {
+      float* row = lds + t * PP_PITCH;
+      // recompute the pre-clamp colour for the clamp mask, then the VJP
+      float dx = m[0] - a.campos[0], dy = m[1] - a.campos[1], dz = m[2] - a.campos[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      const float x = dx * inv, y = dy * inv, z = dz * inv;
+      float B[16];
+      sh_basis(DEG, x, y, z, B);
+      float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) { pr += B[k] * row[3 * k]; pg += B[k] * row[3 * k + 1]; pb += B[k] * row[3 * k + 2]; }
+      const float vc[3] = {(pr + 0.5f > 0.f) ? gb.y : 0.f, (pg + 0.5f > 0.f) ? gb.z : 0.f,
+                           (pb + 0.5f > 0.f) ? gb.w : 0.f};
+      float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+      if (DEG > 0) {
+        float Bx[16], By[16], Bz[16];
+        sh_basis_grad(DEG, x, y, z, Bx, By, Bz);
+        float ux = 0.f, uy = 0.f, uz = 0.f;
+#pragma unroll
+        for (int k = 1; k < NB; ++k) {
+          const float vB = row[3 * k] * vc[0] + row[3 * k + 1] * vc[1] + row[3 * k + 2] * vc[2];
+          ux += vB * Bx[k]; uy += vB * By[k]; uz += vB * Bz[k];
+        }
+        const float dot = ux * x + uy * y + uz * z;
+        vdx = (ux - dot * x) * inv; vdy = (uy - dot * y) * inv; vdz = (uz - dot * z) * inv;
       }
-      float* row = lds + threadIdx.x * PP_PITCH;
-      if (radius > 0) {
-        const float m[3] = {a.xyz[3 * g], a.xyz[3 * g + 1], a.xyz[3 * g + 2]};
-        const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * g);
-        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float s[3] = {__expf(a.scaling_raw[3 * g]), __expf(a.scaling_raw[3 * g + 1]), __expf(a.scaling_raw[3 * g + 2])};
-        const float op = sigmoidf(a.opacity_raw[g]);
-        // ---- SH: recompute the pre-clamp colour for the clamp mask, then the VJP
-        float dx = m[0] - a.campos[0], dy = m[1] - a.campos[1], dz = m[2] - a.campos[2];
-        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        const float x = dx * inv, y = dy * inv, z = dz * inv;
-        float B[16];
-        sh_basis(a.degree, x, y, z, B);
-        float pr = 0.f, pg = 0.f, pb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < nb) { pr += B[k] * row[3 * k]; pg += B[k] * row[3 * k + 1]; pb += B[k] * row[3 * k + 2]; }
-        }
-        const float vc[3] = {(pr + 0.5f > 0.f) ? gb.y : 0.f, (pg + 0.5f > 0.f) ? gb.z : 0.f,
-                             (pb + 0.5f > 0.f) ? gb.w : 0.f};
-        float vdx = 0.f, vdy = 0.f, vdz = 0.f;
-        if (a.degree > 0) {
-          float Bx[16], By[16], Bz[16];
-          sh_basis_grad(a.degree, x, y, z, Bx, By, Bz);
-          float ux = 0.f, uy = 0.f, uz = 0.f;
-#pragma unroll
-          for (int k = 1; k < 16; ++k) {
-            if (k < nb) {
-              const float vB = row[3 * k] * vc[0] + row[3 * k + 1] * vc[1] + row[3 * k + 2] * vc[2];
-              ux += vB * Bx[k]; uy += vB * By[k]; uz += vB * Bz[k];
-            }
-          }
-          const float dot = ux * x + uy * y + uz * z;
-          vdx = (ux - dot * x) * inv; vdy = (uy - dot * y) * inv; vdz = (uz - dot * z) * inv;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {  // this lane's LDS row becomes its SH gradient row
-          const float bk = (k < nb) ? B[k] : 0.f;
-          row[3 * k] = bk * vc[0]; row[3 * k + 1] = bk * vc[1]; row[3 * k + 2] = bk * vc[2];
-        }
-        // ---- projection VJP (quaternion normalisation is inside; scale through exp)
-        const float v_con[3] = {ga.z, ga.w, gb.x};
-        float vm[3], vq[4], vs[3];
-        project_bwd(cam, m, q, s, (float)a.width, (float)a.height, a.eps2d, v_m2, 0.f, v_con, vm, vq, vs);
-        o.g_xyz[3 * g] += vm[0] + vdx; o.g_xyz[3 * g + 1] += vm[1] + vdy; o.g_xyz[3 * g + 2] += vm[2] + vdz;
-        o.g_scaling[3 * g] += vs[0] * s[0]; o.g_scaling[3 * g + 1] += vs[1] * s[1]; o.g_scaling[3 * g + 2] += vs[2] * s[2];
-        float4* gq = reinterpret_cast<float4*>(o.g_rotation + 4 * g);
-        float4 cur = *gq;
-        cur.x += vq[0]; cur.y += vq[1]; cur.z += vq[2]; cur.w += vq[3];
-        *gq = cur;
-        o.g_opacity[g] += go * op * (1.f - op);
+      for (int k = 0; k < 4 * NF4 / 3 + 1 && k < 16; ++k) {  // this lane's LDS row becomes its SH gradient row
+        const float bk = (k < NB) ? B[k] : 0.f;
+        row[3 * k] = bk * vc[0]; row[3 * k + 1] = bk * vc[1]; row[3 * k + 2] = bk * vc[2];
       }
+      o.g_xyz[3 * g] = c_xyz[0] + vm[0] + vdx;
+      o.g_xyz[3 * g + 1] = c_xyz[1] + vm[1] + vdy;
+      o.g_xyz[3 * g + 2] = c_xyz[2] + vm[2] + vdz;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < rows * nf4; i += PP_ROWS) {
-      const int r = i / nf4, k = i - r * nf4;
-      if (!live[r]) continue;
-      const int64_t dst_row = a.sh_by_filter ? rowid[r] : (int64_t)(base + r);
-      float4* dst = reinterpret_cast<float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);
-      const float4 v = *reinterpret_cast<const float4*>(lds + r * PP_PITCH + 4 * k);
-      float4 c = *dst;
-      c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
-      *dst = c;
-    }
+    wave_lds_sync();
+#define CLMGS_X(j)                                                                                  \
+  if constexpr (j < NF4) {                                                                          \
+    CLMGS_ELEM(j)                                                                                   \
+    const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl((int)g, r) : (int64_t)(base + r);      \
+    if ((live >> r) & 1ull) {                                                                       \
+      const float4 v = *reinterpret_cast<const float4*>(lds + r * PP_PITCH + 4 * k);                \
+      float4 c = st##j;                                                                             \
+      c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;                                               \
+      *reinterpret_cast<float4*>(o.g_sh_rows + dst_row * 48 + 4 * k) = c;                           \
+    }                                                                                               \
+  }
+    CLMGS_FOR12(CLMGS_X)
+#undef CLMGS_X
   }
 }
 
@@ -248,19 +359,29 @@ extern "C" int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, 
                                     float far_plane, float radius_clip, int32_t* radii,
                                     float* means2d, float* depths, float* conics, float* colors,
                                     float* opacities, void* packed) {
-  CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);
+  CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && opacity_raw && scaling_raw && rotation_raw && sh_rows && viewmat_host &&
-                  K_host && campos_host && radii && means2d && depths && conics && colors &&
-                  opacities && packed);
+                  K_host && campos_host && radii && means2d && depths && packed);
+  CLMGS_CHECK_ARG(!conics || (colors && opacities));
   PreArgs a;
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, near_plane, far_plane,
             radius_clip);
-  const size_t lds = PP_ROWS * PP_PITCH * sizeof(float);
-  const int grid = min(ceil_div(V, PP_ROWS), 256 * 3);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(grid), dim3(PP_ROWS), lds, (hipStream_t)stream, V, a,
-                     radii, means2d, depths, conics, colors, opacities, (float4*)packed);
+  const size_t lds = 0;
+  const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
+#define CLMGS_PRE_FWD(D, O)                                                                        \
+  hipLaunchKernelGGL((preprocess_fwd_kernel<D, O>), dim3(grid), dim3(PP_ROWS), lds,                \
+                     (hipStream_t)stream, V, a, radii, means2d, depths, conics, colors, opacities, \
+                     (float4*)packed)
+  const bool ov = filter != nullptr;  // a filter means (almost) every row is visible
+  switch (degree) {
+    case 0: if (ov) CLMGS_PRE_FWD(0, true); else CLMGS_PRE_FWD(0, false); break;
+    case 1: if (ov) CLMGS_PRE_FWD(1, true); else CLMGS_PRE_FWD(1, false); break;
+    case 2: if (ov) CLMGS_PRE_FWD(2, true); else CLMGS_PRE_FWD(2, false); break;
+    default: if (ov) CLMGS_PRE_FWD(3, true); else CLMGS_PRE_FWD(3, false); break;
+  }
+#undef CLMGS_PRE_FWD
   CLMGS_LAUNCH_CHECK();
   return 0;
 }
@@ -275,7 +396,7 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     float* g_scaling, float* g_rotation, float* g_sh_rows,
                                     float* max_radii2D, float* grad_accum, float* denom,
                                     float* v_means2d_out, int stats_only_visible) {
-  CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);
+  CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && opacity_raw && scaling_raw && rotation_raw && sh_rows && viewmat_host &&
                   K_host && campos_host && radii && packed_grad && g_xyz && g_opacity &&
@@ -286,10 +407,23 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
              v_means2d_out, stats_only_visible};
-  const size_t lds = PP_ROWS * PP_PITCH * sizeof(float);
-  const int grid = min(ceil_div(V, PP_ROWS), 256 * 3);
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(PP_ROWS), lds, (hipStream_t)stream, V, a,
-                     radii, (const float4*)packed_grad, o);
+  const size_t lds = 0;
+  const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
+#define CLMGS_PRE_BWD(D, E, W)                                                                    \
+  hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W>), dim3(grid), dim3(PP_ROWS), lds,             \
+                     (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o)
+  static const int variant = getenv("CLMGS_PRE_VARIANT") ? atoi(getenv("CLMGS_PRE_VARIANT")) : 0;
+  switch (degree) {
+    case 0: CLMGS_PRE_BWD(0, false, 3); break;
+    case 1: CLMGS_PRE_BWD(1, false, 3); break;
+    case 2: CLMGS_PRE_BWD(2, false, 2); break;
+    default:
+      if (variant == 1) CLMGS_PRE_BWD(3, true, 2);
+      else if (variant == 2) CLMGS_PRE_BWD(3, false, 3);
+      else CLMGS_PRE_BWD(3, false, 2);
+      break;
+  }
+#undef CLMGS_PRE_BWD
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

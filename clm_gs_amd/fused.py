@@ -64,9 +64,6 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     radii = torch.empty((1, V), dtype=I32, device=dev)
     means2d = torch.empty((1, V, 2), dtype=F32, device=dev)
     depths = torch.empty((1, V), dtype=F32, device=dev)
-    conics = torch.empty((V, 3), dtype=F32, device=dev)
-    colors = torch.empty((V, 3), dtype=F32, device=dev)
-    opac = torch.empty((V,), dtype=F32, device=dev)
     packed = torch.empty((V, 16), dtype=F32, device=dev)
     filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
     s = stream()
@@ -74,7 +71,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         s, V, dptr(filt, torch.int64, True), dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32),
         dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
-        dptr(depths), dptr(conics), dptr(colors), dptr(opac), dptr(packed)))
+        dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
     fids, offsets, _ = isect_tiles_two_level(means2d, radii, depths, TILE, tw, th)
     out = torch.empty((H, W, 3), dtype=F32, device=dev)

@@ -115,8 +115,10 @@ class BaseGaussianModel(ABC):
         ...
 
     def _scale_groups_for_bsz(self, training_args):
-        """bsz scaling of lr / eps / betas (no_offload/gaussian_model.py:223-246)."""
-        bsz = self.args.bsz
+        """bsz scaling of lr / eps / betas (no_offload/gaussian_model.py:223-246).  Under camera-DP the
+        optimizer sees the GLOBAL batch (bsz per rank x ranks), so that is what scales."""
+        from .. import dp
+        bsz = self.args.bsz * dp.world_size()
         mode = training_args.lr_scale_mode
         if mode == "linear":
             lr_scale = bsz

@@ -1,0 +1,96 @@
+"""Worker for tests/test_gpu_dp.py (run under torch.distributed.run, 2 ranks sharing cuda:0).
+
+Both ranks hold a replica and train `STEPS` batches of `BSZ` cameras each (rank r takes cameras
+r, r+2, ... of every global batch).  Rank 0 then also trains a fresh replica alone on the same
+global batches (bsz = 2*BSZ) and the three parameter sets are compared.  The process group is
+gloo so that two ranks can share the one GPU of the test box (RCCL refuses duplicate devices);
+the exchange code is backend agnostic.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+W, H, N, BSZ, STEPS = 96, 64, 4000, 4, 3
+
+
+class _Scene:
+    cameras_extent = 30.0
+
+
+def _model(sc, args):
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload
+    m = GaussianModelCLMOffload(3)
+    m.create_from_tensors(sc["xyz"].clone(), sc["shs48"].clone(), sc["scaling"].clone(),
+                          sc["rotation"].clone(), sc["opacity"].clone(), spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(args)
+    return m
+
+
+def _train(m, batches, args, world=1):
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    comm = torch.cuda.Stream()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    it = 1
+    for batch in batches:
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        clm_offload_train_one_batch(m, _Scene, batch, m.parameters_grad_buffer, None, None, comm, gen)
+        it += len(batch) * world  # the image counter strides by the global batch
+    torch.cuda.synchronize()
+    return [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
+            m._rotation.detach().clone(), m._parameters.detach().clone()]
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    from clm_gs_amd import dp, utils
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+
+    args = utils.default_args(bsz=BSZ, sh_residency="hbm")
+    args.clm_offload = True
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    sc = synth_gaussians(N, seed=0, device="cuda")
+    cams = nadir_cameras(STEPS * BSZ * world, N, W, H, 0.35, seed=0, device="cuda")
+    g = torch.Generator().manual_seed(5)
+    for c in cams:
+        c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+    G = BSZ * world
+    global_batches = [cams[s * G:(s + 1) * G] for s in range(STEPS)]
+
+    mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
+    # replicas identical bit for bit (same reduced gradients, same optimizer arithmetic)
+    same = True
+    for t in mine:
+        other = t.clone()
+        dist.broadcast(other, src=0)
+        same &= bool(torch.equal(other, t))
+    flags = [None] * world
+    dist.all_gather_object(flags, same)
+    dist.barrier()
+    dist.destroy_process_group()
+    assert dp.world_size() == 1
+    if rank != 0:
+        return
+    args1 = utils.default_args(bsz=G, sh_residency="hbm")
+    args1.clm_offload = True
+    utils.set_args(args1)
+    solo = _train(_model(sc, args1), global_batches, args1)
+    err = []
+    for a, b in zip(mine, solo):
+        err.append(float((a - b).norm() / b.norm().clamp_min(1e-12)))
+    print("DPRESULT " + json.dumps({"replicas_equal": all(flags), "rel_l2_vs_single": err}))
+
+
+if __name__ == "__main__":
+    main()
