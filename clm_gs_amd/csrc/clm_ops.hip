@@ -137,28 +137,50 @@ __global__ void set_signal_kernel(int32_t* signal, int idx, int32_t value) {
 }
 
 // --------------------------------------------------------------------- Adam
-template <typename IdxT>
+// VEC = 4 when cols % 4 == 0 (the [N,48] SH rows): one 16 B access per array per thread, the
+// per-step scalars are computed once per thread instead of once per element.
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<4> { using type = float4; };
+template <int VEC> __device__ __forceinline__ void vload(const float* a, float (&x)[VEC]) {
+  if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(a); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+  else x[0] = *a;
+}
+template <int VEC> __device__ __forceinline__ void vstore(float* a, const float (&x)[VEC]) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(a) = make_float4(x[0], x[1], x[2], x[3]);
+  else *a = x[0];
+}
+
+template <typename IdxT, int VEC>
 __global__ void __launch_bounds__(256)
 adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, const void* __restrict__ rows,
                  const uint8_t* __restrict__ mask, int64_t n_rows, int cols,
                  const float* __restrict__ col_lr, float beta1, float beta2, float ob1, float ob2,
                  float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale, int zero_grad) {
-  const int64_t total = n_rows * cols;
+  const int cv = cols / VEC;
+  const int64_t total = n_rows * cv;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cols;
-    const int k = (int)(i - r * cols);
+    const int64_t r = i / cv;
+    const int k = (int)(i - r * cv) * VEC;
     const int64_t row = row_of<IdxT>(rows, r);
     if (mask && !mask[row]) continue;
     const int64_t o = row * cols + k;
-    const float gg = g ? g[o] * grad_scale : 0.f;  // g == NULL: rows known to have zero gradient
-    const float mm = beta1 * m[o] + ob1 * gg;
-    const float vv = beta2 * v[o] + ob2 * gg * gg;
-    m[o] = mm; v[o] = vv;
-    const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-    p[o] -= (col_lr[k] * inv_bc1) * (mm / denom);
-    if (zero_grad && g) g[o] = 0.f;
+    float gg[VEC], mm[VEC], vv[VEC], pp[VEC], lr[VEC];
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
+    if (g) vload<VEC>(g + o, gg);  // g == NULL: rows known to have zero gradient
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float gs = g ? gg[c] * grad_scale : 0.f;
+      mm[c] = beta1 * mm[c] + ob1 * gs;
+      vv[c] = beta2 * vv[c] + ob2 * gs * gs;
+      const float denom = sqrtf(vv[c]) * inv_sqrt_bc2 + eps;
+      pp[c] -= (lr[c] * inv_bc1) * (mm[c] / denom);
+      gg[c] = 0.f;
+    }
+    vstore<VEC>(m + o, mm); vstore<VEC>(v + o, vv); vstore<VEC>(p + o, pp);
+    if (zero_grad && g) vstore<VEC>(g + o, gg);
   }
 }
 
@@ -170,44 +192,49 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
 // (bias corrections come from a running product in float instead of a double pow: ~1e-7 relative).
 // Steps older than max_replay are folded analytically (m *= b1^d, v *= b2^d): their parameter
 // increments are below half an ulp of p by then.
-template <typename IdxT>
+template <typename IdxT, int VEC>
 __global__ void __launch_bounds__(256)
 adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                      const int32_t* __restrict__ last_step, const void* __restrict__ rows,
                      int64_t n_rows, int cols, const float* __restrict__ col_lr, float beta1,
                      float beta2, float eps, int to_step, int bias_correction, int max_replay) {
-  const int64_t total = n_rows * cols;
+  const int cv = cols / VEC;
+  const int64_t total = n_rows * cv;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cols;
-    const int k = (int)(i - r * cols);
+    const int64_t r = i / cv;
+    const int k = (int)(i - r * cv) * VEC;
     const int64_t row = row_of<IdxT>(rows, r);
     int a = last_step[row];
     int missed = to_step - a;
     if (missed <= 0) continue;
     const int64_t o = row * cols + k;
-    float mm = m[o], vv = v[o], pp = p[o];
+    float mm[VEC], vv[VEC], pp[VEC], lr[VEC];
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
     if (missed > max_replay) {
       const int d = missed - max_replay;
-      mm *= powf(beta1, (float)d);
-      vv *= powf(beta2, (float)d);
+      const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
       a += d;
       missed = max_replay;
     }
-    const float lr = col_lr[k];
     float pw1 = powf(beta1, (float)(a + 1)), pw2 = powf(beta2, (float)(a + 1));
     for (int j = 0; j < missed; ++j) {
-      mm *= beta1;
-      vv *= beta2;
       float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
       if (bias_correction) {
         inv_bc1 = 1.f / (1.f - pw1);
         inv_sqrt_bc2 = 1.f / sqrtf(1.f - pw2);
       }
-      pp -= (lr * inv_bc1) * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        mm[c] *= beta1;
+        vv[c] *= beta2;
+        pp[c] -= (lr[c] * inv_bc1) * (mm[c] / (sqrtf(vv[c]) * inv_sqrt_bc2 + eps));
+      }
       pw1 *= beta1; pw2 *= beta2;
     }
-    m[o] = mm; v[o] = vv; p[o] = pp;
+    vstore<VEC>(m + o, mm); vstore<VEC>(v + o, vv); vstore<VEC>(p + o, pp);
   }
 }
 
@@ -313,17 +340,16 @@ extern "C" int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float
   }
   // 1 - beta in double on the host: (1.f - 0.999f) alone is off by 1.3e-5 relative
   const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
-  const int grid = min(ceil_div(n_rows * cols, 256), 256 * 8);
-  if (idx_is_64)
-    hipLaunchKernelGGL(adam_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1, ob2,
-                       (float)eps,
-                       inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad);
-  else
-    hipLaunchKernelGGL(adam_rows_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1, ob2,
-                       (float)eps,
-                       inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad);
+  const bool v4 = (cols % 4 == 0) && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g |
+                                        (uintptr_t)col_lr) & 15) == 0;
+  const int grid = (int)min(ceil_div(n_rows * (cols / (v4 ? 4 : 1)), 256), (int64_t)256 * 16);
+#define CLMGS_ADAM_ROWS(I, VEC)                                                                    \
+  hipLaunchKernelGGL((adam_rows_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, \
+                     g, m, v, rows, mask, n_rows, cols, col_lr, (float)beta1, (float)beta2, ob1,   \
+                     ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, zero_grad)
+  if (idx_is_64) { if (v4) CLMGS_ADAM_ROWS(int64_t, 4); else CLMGS_ADAM_ROWS(int64_t, 1); }
+  else { if (v4) CLMGS_ADAM_ROWS(int32_t, 4); else CLMGS_ADAM_ROWS(int32_t, 1); }
+#undef CLMGS_ADAM_ROWS
   CLMGS_LAUNCH_CHECK();
   return 0;
 }
@@ -336,15 +362,15 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
   CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && to_step >= 0 && max_replay >= 1);
   if (n_rows == 0) return 0;
   CLMGS_CHECK_ARG(p && m && v && last_step && col_lr);
-  const int grid = min(ceil_div(n_rows * cols, 256), 256 * 8);
-  if (idx_is_64)
-    hipLaunchKernelGGL(adam_catch_up_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,
-                       (float)eps, to_step, bias_correction, max_replay);
-  else
-    hipLaunchKernelGGL(adam_catch_up_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p,
-                       m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,
-                       (float)eps, to_step, bias_correction, max_replay);
+  const bool v4 = (cols % 4 == 0) && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)col_lr) & 15) == 0;
+  const int grid = (int)min(ceil_div(n_rows * (cols / (v4 ? 4 : 1)), 256), (int64_t)256 * 16);
+#define CLMGS_CATCH_UP(I, VEC)                                                                     \
+  hipLaunchKernelGGL((adam_catch_up_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                     p, m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,   \
+                     (float)eps, to_step, bias_correction, max_replay)
+  if (idx_is_64) { if (v4) CLMGS_CATCH_UP(int64_t, 4); else CLMGS_CATCH_UP(int64_t, 1); }
+  else { if (v4) CLMGS_CATCH_UP(int32_t, 4); else CLMGS_CATCH_UP(int32_t, 1); }
+#undef CLMGS_CATCH_UP
   CLMGS_LAUNCH_CHECK();
   return 0;
 }
