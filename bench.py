@@ -159,7 +159,10 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=", 1)
         cur = getattr(args, k)
-        setattr(args, k, (v.lower() in ("1", "true", "yes")) if isinstance(cur, bool) else type(cur)(v))
+        if isinstance(cur, bool) and v.lower() in ("1", "true", "yes", "0", "false", "no"):
+            setattr(args, k, v.lower() in ("1", "true", "yes"))
+        else:
+            setattr(args, k, v if isinstance(cur, bool) else type(cur)(v))
     utils.set_args(args)
     utils.set_img_size(H, W)
     torch.manual_seed(0)

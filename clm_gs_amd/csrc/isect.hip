@@ -211,30 +211,39 @@ isect2_count_kernel(int V, const int32_t* __restrict__ order, const float* __res
   }
 }
 
+// gid_tab != NULL ("slot mode"): the sort payload is the EMIT index p itself and gid_tab[p] keeps
+// the row id; row_start/row_cnt give every row its contiguous emit range.  The backward tile
+// kernel then stores its per-(row, tile) partial gradients at p with plain stores and a per-row
+// pass sums the contiguous range: no float atomics, deterministic.
 __global__ void __launch_bounds__(256)
 isect2_emit_kernel(int V, const int32_t* __restrict__ order, const float* __restrict__ means2d,
                    const int32_t* __restrict__ radii, const int64_t* __restrict__ cum,
                    float tile_size, int tile_w, int tile_h, uint32_t* __restrict__ tkeys,
-                   int32_t* __restrict__ vals) {
+                   int32_t* __restrict__ vals, int32_t* __restrict__ gid_tab,
+                   int32_t* __restrict__ row_start, int32_t* __restrict__ row_cnt) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
     const int i = order[j];
     const int r = radii[i];
+    int64_t cur = (j == 0) ? 0 : cum[j - 1];
+    if (row_start) { row_start[i] = (int32_t)cur; row_cnt[i] = (int32_t)(cum[j] - cur); }
     if (r <= 0) continue;
     const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
     const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
-    int64_t cur = (j == 0) ? 0 : cum[j - 1];
     for (int ty = b.y0; ty < b.y1; ++ty)
       for (int tx = b.x0; tx < b.x1; ++tx) {
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
-        vals[cur] = i;
+        if (gid_tab) { vals[cur] = (int32_t)cur; gid_tab[cur] = i; }
+        else vals[cur] = i;
         ++cur;
       }
   }
 }
 
+// slot mode: sorted_vals holds emit indices; flatten_ids is produced here from gid_tab.
 __global__ void __launch_bounds__(256)
 isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int n_tiles,
-                      int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+                      int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids,
+                      const int32_t* __restrict__ emit_slot, const int32_t* __restrict__ gid_tab,
                       const float* __restrict__ depths, int64_t* __restrict__ isect_ids) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_isects;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -247,8 +256,11 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
     }
     if (i == n_isects - 1)
       for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
+    int gid;
+    if (gid_tab) { gid = gid_tab[emit_slot[i]]; flatten_ids[i] = gid; }
+    else gid = flatten_ids[i];
     if (isect_ids)
-      isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[flatten_ids[i]]);
+      isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[gid]);
   }
 }
 
@@ -290,22 +302,30 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
   if (n_isects <= 0) return 256;
-  return 4 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
+  return 5 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
 }
 
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
-// isect_ids[I] i64 optional (NULL to skip).
+// isect_ids[I] i64 optional (NULL to skip).  emit_slot[I] / row_start[V] / row_cnt[V] optional
+// (all or none): the emit index of every sorted intersection and each row's emit range, consumed
+// by clmgs_rasterize_bwd's atomic-free accumulation.
 extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* means2d,
                                       const int32_t* radii, const float* depths,
                                       const int32_t* order, const int64_t* cum, int tile_size,
                                       int tile_width, int tile_height, int32_t* flatten_ids,
-                                      int32_t* offsets, int64_t* isect_ids, void* temp,
+                                      int32_t* offsets, int64_t* isect_ids, int32_t* emit_slot,
+                                      int32_t* row_start, int32_t* row_cnt, void* temp,
                                       size_t temp_bytes) {
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
+  CLMGS_CHECK_ARG((emit_slot && row_start && row_cnt) || (!emit_slot && !row_start && !row_cnt));
   if (n_isects == 0) {
     CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
+    if (row_cnt && V > 0) {
+      CLMGS_HIP(hipMemsetAsync(row_cnt, 0, sizeof(int32_t) * (size_t)V, s));
+      CLMGS_HIP(hipMemsetAsync(row_start, 0, sizeof(int32_t) * (size_t)V, s));
+    }
     return 0;
   }
   CLMGS_CHECK_ARG(n_isects < ((int64_t)1 << 31));
@@ -316,17 +336,21 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
   int32_t* v_a = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
   int32_t* v_b = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  int32_t* gid_tab = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
   uint32_t* table = (uint32_t*)base;
+  if (!emit_slot) gid_tab = nullptr;
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
-                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a, v_a);
+                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a, v_a,
+                     gid_tab, row_start, row_cnt);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
-  int rc = radix_sort_pairs<uint32_t>(s, n_isects, k_a, k_b, v_a, v_b, flatten_ids, 0, tile_bits, table,
-                                      &sorted);
+  int rc = radix_sort_pairs<uint32_t>(s, n_isects, k_a, k_b, v_a, v_b,
+                                      emit_slot ? emit_slot : flatten_ids, 0, tile_bits, table, &sorted);
   if (rc) return rc;
   hipLaunchKernelGGL(isect2_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0,
-                     s, n_isects, sorted, n_tiles, offsets, flatten_ids, depths, isect_ids);
+                     s, n_isects, sorted, n_tiles, offsets, flatten_ids, emit_slot, gid_tab, depths,
+                     isect_ids);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -222,8 +222,8 @@ struct TileLdsBwd {
   float4 b[64];
   float c[64];
   int meta[64];
-  int id[64];        // Gaussian id (cam*N + g) of the compacted slot
-  float acc[64][9];  // reduced per-Gaussian gradient of this tile
+  int id[64];        // Gaussian id (cam*N + g) of the compacted slot, or its emit slot (PART)
+  __attribute__((aligned(16))) float acc[64][12];  // reduced per-Gaussian sums of this tile (9 used)
 };
 
 // DBG: profiling-only variants (1 = skip the atomics flush, 2 = skip the reduction too, 3 = phase
@@ -234,7 +234,11 @@ __device__ unsigned long long g_dbg[16];
 #ifndef CLMGS_BWD_WAVES
 #define CLMGS_BWD_WAVES 4  // 5 spills (96 VGPRs): scratch reloads force vmcnt(0) and kill the prefetch
 #endif
-template <int DBG>
+// PART: atomic-free accumulation.  Every sorted intersection owns the 64 B line partials[slot]
+// (slot = its emit index, see isect2_emit_kernel); the tile's wave STORES the reduced sums there
+// (zeros for culled / unreached entries, so every line is written exactly once per launch) and
+// raster_partials_sum_kernel adds each row's contiguous range.
+template <int DBG, bool PART>
 __global__ void __launch_bounds__(64, CLMGS_BWD_WAVES)
 rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ packed,
                      const float* __restrict__ backgrounds,
@@ -242,7 +246,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
                      const int32_t* __restrict__ flatten_ids,
                      const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
                      const float* __restrict__ v_render_colors,
-                     const float* __restrict__ v_render_alphas, float* __restrict__ packed_grad) {
+                     const float* __restrict__ v_render_alphas, float* __restrict__ packed_grad,
+                     const int32_t* __restrict__ emit_slot, float4* __restrict__ partials) {
   __shared__ TileLdsBwd sm;
   const int n_tiles = tile_w * tile_h;
   const int n_tiles_total = C * n_tiles;
@@ -260,8 +265,10 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
 
   // per-pixel state kept lean (VGPR budget decides waves/SIMD): pixel centres are recomputed from
   // the lane, "inside" is bin < 0, and T_final * v_alpha' is pre-multiplied.
-  float T[PPL], tfva[PPL], vr[PPL], vg[PPL], vb[PPL];
-  float br[PPL], bg_[PPL], bb[PPL];  // running sum of colour behind the current Gaussian
+  // Bk = (colour accumulated behind the current Gaussian) . v_rgb  -  T_final * v_alpha': the
+  // behind-colour only ever appears dotted with the pixel's colour cotangent, so ONE running
+  // scalar replaces three buffers and the alpha-cotangent term (fewer VGPRs, 7 fewer VALU/pair).
+  float T[PPL], Bk[PPL], vr[PPL], vg[PPL], vb[PPL];
   int bin[PPL];
   int max_bin = -1;
   float bgr = 0.f, bgg = 0.f, bgb = 0.f;
@@ -271,7 +278,6 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   for (int k = 0; k < PPL; ++k) {
     const int j = tx * TILE + 8 * (k & 1) + qx;
     const int i = ty * TILE + 8 * (k >> 1) + qy;
-    br[k] = bg_[k] = bb[k] = 0.f;
     if ((i < H) && (j < W)) {
       const size_t pix = ((size_t)cam * H + i) * W + j;
       const float Tf = 1.f - render_alphas[pix];
@@ -280,11 +286,11 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       float va = v_render_alphas ? v_render_alphas[pix] : 0.f;
       // d(out)/d(T_final) through the background term folds into the alpha cotangent
       va -= (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]);
-      tfva[k] = Tf * va;
+      Bk[k] = -Tf * va;
       T[k] = Tf;
       max_bin = max(max_bin, bin[k]);
     } else {
-      T[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = tfva[k] = 0.f;
+      T[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = Bk[k] = 0.f;
     }
   }
   max_bin = wave_max_i32(max_bin);
@@ -299,6 +305,16 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   float nblue = 0.f;
   int cur_g = (hi - lane >= rs) ? flatten_ids[hi - lane] : -1;
   int nxt_g = (hi - 64 - lane >= rs) ? flatten_ids[hi - 64 - lane] : -1;
+  int cur_p = 0, nxt_p = 0;
+  if (PART) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx = max(hi + 1, rs) + lane; idx < re; idx += 64) {  // behind the deepest contributor: zeros
+      float4* dst = partials + 4 * (size_t)emit_slot[idx];
+      dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
+    }
+    cur_p = (hi - lane >= rs) ? emit_slot[hi - lane] : 0;
+    nxt_p = (hi - 64 - lane >= rs) ? emit_slot[hi - 64 - lane] : 0;
+  }
   if (cur_g >= 0) {
     const float4* rec = packed + REC_F4 * (size_t)cur_g;
     nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
@@ -308,8 +324,10 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const float4 A = nA, B = nB;
     const float blue = nblue;
     const int gid = cur_g;
+    const int pid = cur_p;
     const int mask = (gid >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
     cur_g = nxt_g;
+    cur_p = nxt_p;
     if (cur_g >= 0) {
       const float4* rec = packed + REC_F4 * (size_t)cur_g;
       nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
@@ -317,6 +335,12 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     {
       const int nidx = bh - 128 - lane;
       nxt_g = (nidx >= rs) ? flatten_ids[nidx] : -1;
+      if (PART) nxt_p = (nidx >= rs) ? emit_slot[nidx] : 0;
+    }
+    if (PART && gid >= 0 && mask == 0) {  // culled for this tile: its line is all zeros
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4* dst = partials + 4 * (size_t)pid;
+      dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
     }
     const unsigned long long bal = __ballot(mask != 0);
     const int pos = __popcll(bal & ((1ull << lane) - 1ull));
@@ -324,7 +348,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     __syncthreads();
     if (mask) {
       sm.a[pos] = A; sm.b[pos] = B; sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
-      sm.id[pos] = gid;
+      sm.id[pos] = PART ? pid : gid;
     }
     __syncthreads();
     const unsigned long long tB = DBG_CLK();
@@ -336,8 +360,10 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       const float rblue = sm.c[t];
       const int gi = bh - (meta >> 4);
       if (DBG == 3) { n_ent++; n_quad += __popc(meta & 15); }
-      float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_x = 0.f,
-            g_y = 0.f, g_o = 0.f;
+      // moments of w = v_sigma over the tile: the five screen-space gradients are linear in them
+      // (g_x = a Sx + b Sy, g_y = b Sx + c Sy, g_conic = Sxx/2, Sxy, Syy/2), applied at the flush
+      float g_r = 0.f, g_g = 0.f, g_b = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f,
+            g_o = 0.f;
       bool any_valid = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
@@ -346,7 +372,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
           const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
           const float gex = __expf(-sigma);
-          const float alpha = fminf(0.999f, RA.z * gex);
+          const float oa = RA.z * gex;
+          const float alpha = fminf(0.999f, oa);
           const bool valid = (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           if (valid) {
             any_valid = true;
@@ -354,19 +381,16 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
             T[k] *= ra;
             const float fac = alpha * T[k];
             g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
-            float v_alpha = (RB.z * T[k] - br[k] * ra) * vr[k] + (RB.w * T[k] - bg_[k] * ra) * vg[k] +
-                            (rblue * T[k] - bb[k] * ra) * vb[k];
-            v_alpha += tfva[k] * ra;
-            if (RA.z * gex <= 0.999f) {
-              const float v_sigma = -RA.z * gex * v_alpha;
-              g_ca += 0.5f * v_sigma * dx * dx;
-              g_cb += v_sigma * dx * dy;
-              g_cc += 0.5f * v_sigma * dy * dy;
-              g_x += v_sigma * (RA.w * dx + RB.x * dy);
-              g_y += v_sigma * (RB.x * dx + RB.y * dy);
+            const float cv = RB.z * vr[k] + RB.w * vg[k] + rblue * vb[k];
+            const float v_alpha = T[k] * cv - ra * Bk[k];
+            if (oa <= 0.999f) {
+              const float w = -oa * v_alpha;  // v_sigma
+              const float wdx = w * dx, wdy = w * dy;
+              Sx += wdx; Sy += wdy;
+              Sxx += wdx * dx; Sxy += wdx * dy; Syy += wdy * dy;
               g_o += gex * v_alpha;
             }
-            br[k] += RB.z * fac; bg_[k] += RB.w * fac; bb[k] += rblue * fac;
+            Bk[k] += fac * cv;
           }
         }
       }
@@ -374,13 +398,13 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       if (DBG == 3) n_valid++;
       if (DBG != 2) {
         // 9 wave-wide sums: two 4-packs on the permlane-swap butterfly + one plain DPP chain
-        const float u1 = wave_sum4_rows(g_x, g_y, g_ca, g_cb);   // lanes 15/31/47/63: x, ca, y, cb
-        const float u2 = wave_sum4_rows(g_cc, g_r, g_g, g_b);    //                    cc, g, r, b
+        const float u1 = wave_sum4_rows(Sx, Sy, Sxx, Sxy);       // lanes 15/31/47/63: Sx, Sxx, Sy, Sxy
+        const float u2 = wave_sum4_rows(Syy, g_r, g_g, g_b);     //                    Syy, g, r, b
         g_o = wave_sum_to_lane63(g_o);
         if ((lane & 15) == 15) {
           const int r = lane >> 4;
           const int m = ((r & 1) << 1) | (r >> 1);               // row -> slot {0,2,1,3}
-          float* a = sm.acc[t];                                   // x y ca cb | cc r g b | o
+          float* a = sm.acc[t];                                   // Sx Sy Sxx Sxy | Syy r g b | o
           a[m] = u1;
           a[4 + m] = u2;
           if (lane == 63) a[8] = g_o;
@@ -392,12 +416,28 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const unsigned long long tC = DBG_CLK();
     if (DBG == 1 || DBG == 2) {
       if (((touched >> lane) & 1ull) && sm.acc[lane][0] == 1.2345e30f) packed_grad[0] = 1.f;
+    } else if (PART) {
+      if (lane < bn) {  // one full 64 B line per entry of the round, zeros if no pixel was valid
+        const bool hit = (touched >> lane) & 1ull;
+        const float4* a = reinterpret_cast<const float4*>(sm.acc[lane]);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r0 = z4, r1 = z4, r2 = z4;
+        if (hit) { r0 = a[0]; r1 = a[1]; r2 = a[2]; r2.y = r2.z = r2.w = 0.f; }
+        float4* dst = partials + 4 * (size_t)sm.id[lane];
+        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = z4;
+      }
     } else if ((touched >> lane) & 1ull) {
       // all nine atomics of a Gaussian land in its one 64 B gradient line
       float* dst = packed_grad + 4 * REC_F4 * (size_t)sm.id[lane];
       const float* a = sm.acc[lane];
+      const float ca = sm.a[lane].w, cb = sm.b[lane].x, cc = sm.b[lane].y;
+      atomicAdd(dst + 0, ca * a[0] + cb * a[1]);  // x
+      atomicAdd(dst + 1, cb * a[0] + cc * a[1]);  // y
+      atomicAdd(dst + 2, 0.5f * a[2]);            // conic a
+      atomicAdd(dst + 3, a[3]);                   // conic b
+      atomicAdd(dst + 4, 0.5f * a[4]);            // conic c
 #pragma unroll
-      for (int c = 0; c < 9; ++c) atomicAdd(dst + c, a[c]);
+      for (int c = 5; c < 9; ++c) atomicAdd(dst + c, a[c]);
     }
     if (DBG == 3) {
       const unsigned long long tD = DBG_CLK();
@@ -412,9 +452,44 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   }
 }
 
+// Per-row sum of the tile partials (fixed order: ascending emit index) -> the row's gradient line.
+// partials line: Sx Sy Sxx Sxy | Syy r g b | o - - - | -   (moments of v_sigma, see the tile kernel)
+__global__ void __launch_bounds__(256)
+raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ row_start,
+                           const int32_t* __restrict__ row_cnt,
+                           const float4* __restrict__ partials, const float4* __restrict__ packed,
+                           float4* __restrict__ packed_grad) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int cnt = row_cnt[r];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    float o = 0.f;
+    if (cnt > 0) {
+      const float4* src = partials + 4 * (size_t)row_start[r];
+      for (int j = 0; j < cnt; ++j) {
+        const float4 pa = src[4 * j], pb = src[4 * j + 1];
+        const float po = src[4 * j + 2].x;
+        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        o += po;
+      }
+    }
+    const float4 ra = packed[REC_F4 * r], rb = packed[REC_F4 * r + 1];
+    const float ca = ra.w, cb = rb.x, cc = rb.y;
+    float4* dst = packed_grad + REC_F4 * r;
+    dst[0] = make_float4(ca * a.x + cb * a.y, cb * a.x + cc * a.y, 0.5f * a.z, a.w);
+    dst[1] = make_float4(0.5f * b.x, b.y, b.z, b.w);
+    dst[2] = make_float4(o, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace clmgs
 
 using namespace clmgs;
+
+extern "C" size_t clmgs_rasterize_partials_bytes(int64_t n_isects) {
+  return (size_t)(n_isects > 0 ? n_isects : 1) * 64;
+}
 
 // Profiling aid (CLMGS_BWD_DEBUG=3): stage / loop / flush / total cycles, entries, entries with a
 // valid pixel, quadrant passes, staging rounds, tiles, list length.  out[16]; reset != 0 clears.
@@ -453,7 +528,8 @@ extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
     CLMGS_LAUNCH_CHECK();
   }
   const int n_blocks = C * tile_width * tile_height;
-  hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), 0, s, C, N, n_isects,
+  static const int fwd_pad = getenv("CLMGS_FWD_LDS_PAD") ? atoi(getenv("CLMGS_FWD_LDS_PAD")) : 0;
+  hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), fwd_pad, s, C, N, n_isects,
                      (const float4*)packed, backgrounds, width, height, tile_width, tile_height,
                      offsets, flatten_ids, render_colors, render_alphas, last_ids);
   CLMGS_LAUNCH_CHECK();
@@ -467,29 +543,46 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
                                    const int32_t* last_ids, const float* v_render_colors,
                                    const float* v_render_alphas, void* packed_grad,
                                    float* v_means2d, float* v_conics, float* v_colors,
-                                   float* v_opacities) {
+                                   float* v_opacities, const int32_t* emit_slot,
+                                   const int32_t* row_start, const int32_t* row_cnt,
+                                   void* partials) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
   CLMGS_CHECK_ARG(!v_means2d || (v_conics && v_colors && v_opacities));
+  const bool part = emit_slot != nullptr;
+  CLMGS_CHECK_ARG(!part || (C == 1 && row_start && row_cnt && partials && (((uintptr_t)partials & 63) == 0)));
   hipStream_t s = (hipStream_t)stream;
   const int64_t CN = (int64_t)C * N;
   if (CN == 0) return 0;
   CLMGS_CHECK_ARG(packed_grad && (((uintptr_t)packed_grad & 63) == 0));
-  CLMGS_HIP(hipMemsetAsync(packed_grad, 0, clmgs_rasterize_pack_bytes(C, N), s));
+  if (!part || n_isects == 0)
+    CLMGS_HIP(hipMemsetAsync(packed_grad, 0, clmgs_rasterize_pack_bytes(C, N), s));
   if (n_isects > 0) {
     CLMGS_CHECK_ARG(packed && offsets && flatten_ids && render_alphas && last_ids && v_render_colors);
     const int n_blocks = C * tile_width * tile_height;
     static const int dbg = getenv("CLMGS_BWD_DEBUG") ? atoi(getenv("CLMGS_BWD_DEBUG")) : 0;
-#define CLMGS_LAUNCH_BWD(D)                                                                        \
-  hipLaunchKernelGGL(rasterize_bwd_kernel<D>, dim3(n_blocks), dim3(64), 0, s, C, N, n_isects,      \
-                     (const float4*)packed, backgrounds, width, height, tile_width, tile_height,   \
-                     offsets, flatten_ids, render_alphas, last_ids, v_render_colors,               \
-                     v_render_alphas, (float*)packed_grad)
-    if (dbg == 1) CLMGS_LAUNCH_BWD(1); else if (dbg == 2) CLMGS_LAUNCH_BWD(2);
-    else if (dbg == 3) CLMGS_LAUNCH_BWD(3); else CLMGS_LAUNCH_BWD(0);
+    static const int bwd_pad = getenv("CLMGS_BWD_LDS_PAD") ? atoi(getenv("CLMGS_BWD_LDS_PAD")) : 0;
+#define CLMGS_LAUNCH_BWD(D, P)                                                                     \
+  hipLaunchKernelGGL((rasterize_bwd_kernel<D, P>), dim3(n_blocks), dim3(64), bwd_pad, s, C, N,     \
+                     n_isects, (const float4*)packed, backgrounds, width, height, tile_width,      \
+                     tile_height, offsets, flatten_ids, render_alphas, last_ids, v_render_colors,  \
+                     v_render_alphas, (float*)packed_grad, emit_slot, (float4*)partials)
+    if (part) {
+      if (dbg == 1) CLMGS_LAUNCH_BWD(1, true); else if (dbg == 3) CLMGS_LAUNCH_BWD(3, true);
+      else CLMGS_LAUNCH_BWD(0, true);
+    } else {
+      if (dbg == 1) CLMGS_LAUNCH_BWD(1, false); else if (dbg == 2) CLMGS_LAUNCH_BWD(2, false);
+      else if (dbg == 3) CLMGS_LAUNCH_BWD(3, false); else CLMGS_LAUNCH_BWD(0, false);
+    }
 #undef CLMGS_LAUNCH_BWD
     CLMGS_LAUNCH_CHECK();
+    if (part) {
+      hipLaunchKernelGGL(raster_partials_sum_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256),
+                         0, s, CN, row_start, row_cnt, (const float4*)partials,
+                         (const float4*)packed, (float4*)packed_grad);
+      CLMGS_LAUNCH_CHECK();
+    }
   }
   if (v_means2d) {  // NULL: the caller consumes the packed gradient lines directly
     hipLaunchKernelGGL(raster_unpack_grad_kernel, dim3(min(ceil_div(CN, 256), 256 * 8)), dim3(256), 0,

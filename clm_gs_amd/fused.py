@@ -43,7 +43,8 @@ def _np(a):
 
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
-                     return_event=False, stats_only_visible=False, visibility_out=None):
+                     return_event=False, stats_only_visible=False, visibility_out=None,
+                     raster_stream=None):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -51,7 +52,10 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     Returns the detached loss (0-dim tensor).  `keep`, if a list, receives tensors that must stay
     alive until the stream has consumed them.  Everything is enqueued on the CURRENT torch stream;
     `accumulate_after` (an event) gates the gradient-accumulating kernel so two cameras can be in
-    flight on two streams while their read-modify-write accumulations stay ordered."""
+    flight on two streams while their read-modify-write accumulations stay ordered.
+    `raster_stream`: if given, the two ALU-bound tile kernels are enqueued there (event-chained
+    with the current stream) so that a shared low-priority stream carries all cameras' tile work
+    while the latency-bound kernels of the other camera get CU slots first."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -73,15 +77,23 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
         dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
-    fids, offsets, _ = isect_tiles_two_level(means2d, radii, depths, TILE, tw, th)
+    fids, offsets, _, (emit_slot, row_start, row_cnt) = isect_tiles_two_level(
+        means2d, radii, depths, TILE, tw, th, want_slots=True)
     out = torch.empty((H, W, 3), dtype=F32, device=dev)
     alphas = torch.empty((H, W), dtype=F32, device=dev)
     last_ids = torch.empty((H, W), dtype=I32, device=dev)
     bg = background.reshape(1, 3).to(F32).contiguous() if background is not None else None
     n_isects = fids.numel()
-    check(L.clmgs_rasterize_fwd(s, 1, V, n_isects, None, None, None, None, dptr(bg, F32, True), W, H,
+    cur = torch.cuda.current_stream()
+    s_r = s
+    if raster_stream is not None:
+        raster_stream.wait_stream(cur)
+        s_r = ctypes.c_void_p(raster_stream.cuda_stream)
+    check(L.clmgs_rasterize_fwd(s_r, 1, V, n_isects, None, None, None, None, dptr(bg, F32, True), W, H,
                                 TILE, tw, th, dptr(offsets), dptr(fids), dptr(packed), dptr(out),
                                 dptr(alphas), dptr(last_ids)))
+    if raster_stream is not None:
+        cur.wait_stream(raster_stream)
     # loss forward + backward straight on the [H,W,3] buffer viewed as [3,H,W]
     slots = L.clmgs_loss_slots()
     partials = torch.zeros((slots, 2), dtype=F32, device=dev)
@@ -98,9 +110,16 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
                                    float(lambda_dssim), dptr(maps[0]), dptr(maps[1]), dptr(maps[2]),
                                    dptr(v_out)))
     packed_grad = torch.empty_like(packed)
-    check(L.clmgs_rasterize_bwd(s, 1, V, n_isects, dptr(packed), dptr(bg, F32, True), W, H, TILE, tw,
+    # atomic-free accumulation: one 64 B line per intersection, summed per row afterwards
+    partials = torch.empty((max(n_isects, 1), 16), dtype=F32, device=dev)
+    if raster_stream is not None:
+        raster_stream.wait_stream(cur)
+    check(L.clmgs_rasterize_bwd(s_r, 1, V, n_isects, dptr(packed), dptr(bg, F32, True), W, H, TILE, tw,
                                 th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
-                                dptr(v_out), None, dptr(packed_grad), None, None, None, None))
+                                dptr(v_out), None, dptr(packed_grad), None, None, None, None,
+                                dptr(emit_slot), dptr(row_start), dptr(row_cnt), dptr(partials)))
+    if raster_stream is not None:
+        cur.wait_stream(raster_stream)
     stats = update_stats and (not args.disable_auto_densification) and \
         utils.get_cur_iter() <= args.densify_until_iter
     if accumulate_after is not None:
@@ -117,7 +136,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
         dptr(gaussians.denom if stats else None, F32, True), None, int(bool(stats_only_visible))))
     if keep is not None:
-        keep += [packed, packed_grad, radii, filt]
+        keep += [packed, packed_grad, radii, filt, partials, emit_slot, row_start, row_cnt]
     if return_event:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

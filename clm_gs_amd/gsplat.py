@@ -204,10 +204,11 @@ def isect_offset_encode(isect_ids, n_cameras, tile_width, tile_height):
 
 @torch.no_grad()
 def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_height,
-                          want_isect_ids=False):
+                          want_isect_ids=False, want_slots=False):
     """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
     sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
-    identical to isect_tiles + isect_offset_encode for C = 1."""
+    identical to isect_tiles + isect_offset_encode for C = 1.  want_slots: a 4th result
+    (emit_slot[I], row_start[V], row_cnt[V]) i32 for the atomic-free rasterize backward."""
     L = _lib.lib()
     V = radii.numel()
     dev = radii.device
@@ -215,7 +216,9 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     offsets = torch.empty((1, tile_height, tile_width), dtype=I32, device=dev)
     if V == 0:
         offsets.zero_()
-        return torch.empty(0, dtype=I32, device=dev), offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None)
+        e = torch.empty(0, dtype=I32, device=dev)
+        res = (e, offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
+        return res + ((e, e.clone(), e.clone()),) if want_slots else res
     order = torch.empty((V,), dtype=I32, device=dev)
     cum = torch.empty((V,), dtype=I64, device=dev)
     tb = L.clmgs_isect2_order_temp_bytes(V)
@@ -231,11 +234,16 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     ids = torch.empty((n_isects,), dtype=I64, device=dev) if want_isect_ids else None
     sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
     temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
+    slots = None
+    if want_slots:
+        slots = (torch.empty((n_isects,), dtype=I32, device=dev), torch.empty((V,), dtype=I32, device=dev),
+                 torch.empty((V,), dtype=I32, device=dev))
     check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(means2d), dptr(radii), dptr(depths),
                                    dptr(order), dptr(cum), int(tile_size), int(tile_width),
                                    int(tile_height), dptr(fids), dptr(offsets), dptr(ids, I64, True),
-                                   dptr(temp2), sb))
-    return fids, offsets, ids
+                                   dptr(slots[0]) if slots else None, dptr(slots[1]) if slots else None,
+                                   dptr(slots[2]) if slots else None, dptr(temp2), sb))
+    return (fids, offsets, ids, slots) if want_slots else (fids, offsets, ids)
 
 
 # ---------------------------------------------------------------------- rasterize
@@ -286,7 +294,7 @@ class _Rasterize(torch.autograd.Function):
             stream(), C, N, fids.numel(), dptr(packed), dptr(bg, F32, True), width, height,
             tile_size, tw, th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
             dptr(v_out, F32), dptr(v_alphas, F32, True), dptr(packed_grad), dptr(v_means2d),
-            dptr(v_conics), dptr(v_colors), dptr(v_opacities)))
+            dptr(v_conics), dptr(v_colors), dptr(v_opacities), None, None, None, None))
         return v_means2d, v_conics, v_colors, v_opacities, None, None, None, None, None, None
 
 

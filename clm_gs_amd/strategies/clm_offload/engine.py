@@ -283,20 +283,43 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
         # events so the read-modify-write gradient sums stay ordered.
         from ...fused import train_one_camera
-        aux = getattr(gaussians, "_clmgs_aux_stream", None)
-        if aux is None:
-            aux = gaussians._clmgs_aux_stream = torch.cuda.Stream()
-        lanes = [default_stream, aux] if getattr(args, "overlap_cameras", True) else [default_stream]
-        aux.wait_stream(default_stream)
+        mode = getattr(args, "overlap_cameras", True)
+        mode = {True: "typed", False: "off"}.get(mode, mode)
+        sts = getattr(gaussians, "_clmgs_streams", None)
+        if sts is None:
+            try:
+                lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
+            except AttributeError:
+                lo, hi = 0, -1
+            sts = gaussians._clmgs_streams = {
+                "aux": torch.cuda.Stream(),
+                "mem": [torch.cuda.Stream(priority=hi), torch.cuda.Stream(priority=hi)],
+                "raster": torch.cuda.Stream(priority=lo)}
+        raster = None
+        if mode == "typed":
+            # streams by kernel TYPE: every camera's ALU-bound tile kernels share one low-priority
+            # stream (they gain nothing from overlapping each other), the latency-bound rest of
+            # camera i / i+1 runs on two high-priority streams and is dispatched first whenever it
+            # has work -- it fills the memory system while the tile kernels fill the VALUs
+            lanes, raster = sts["mem"], sts["raster"]
+        elif mode == "camera":
+            lanes = [default_stream, sts["aux"]]
+        else:
+            lanes = [default_stream]
+        for ln in lanes:
+            if ln is not default_stream:
+                ln.wait_stream(default_stream)
         prev = None
         for micro_idx in range(bsz):
             with torch.cuda.stream(lanes[micro_idx % len(lanes)]):
                 loss, prev = train_one_camera(
                     gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
                     background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
-                    return_event=True)
+                    return_event=True, raster_stream=raster)
             losses.append(loss)
-        default_stream.wait_stream(aux)
+        for ln in lanes:
+            if ln is not default_stream:
+                default_stream.wait_stream(ln)
     for micro_idx in range(0 if fused else bsz):  # op-by-op path (fused_front_end=False)
         this_filter = filters[micro_idx]
         with torch.no_grad():

@@ -445,3 +445,68 @@ def test_distCUDA2_matches_brute_force(dev):
     want = d.topk(3, dim=1, largest=False).values.mean(dim=1)
     got = distCUDA2(pts.to(dev)).cpu().double()
     assert ((got - want).abs() / (want + 1e-12)).max() < 1e-4
+
+
+@pytest.mark.parametrize("opaque", [False, True])
+def test_rasterize_bwd_atomic_free_path(dev, opaque):
+    """clmgs_rasterize_bwd with emit slots (plain stores + per-row sum) == the float-atomic path
+    == autograd of the oracle; the slot path is bitwise reproducible; slots are a consistent
+    permutation.  `opaque` saturates pixels so that entries behind the deepest contributor and
+    culled entries (zero lines) are exercised."""
+    from clm_gs_amd import _lib, gsplat as G
+    from clm_gs_amd._lib import check, dptr, stream
+    L = _lib.lib()
+    w, h, n = 70, 53, 1200
+    s = small_scene(n=n, width=w, height=h, seed=61, spread=0.7 if opaque else 1.0, log_scale=-0.7 if opaque else -1.1)
+    if opaque:
+        s["opac"] = torch.full_like(s["opac"], 0.95)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    g = torch.Generator().manual_seed(3)
+    colors = torch.rand(1, n, 3, generator=g)
+    opac = s["opac"].reshape(1, -1)
+    f0, o0, _ = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th)
+    fids, off, _, (slot, rstart, rcnt) = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th,
+                                                                 want_slots=True)
+    assert torch.equal(fids, f0) and torch.equal(off, o0)
+    I = fids.numel()
+    assert torch.equal(torch.sort(slot.long()).values.cpu(), torch.arange(I))  # a permutation of the emit order
+    assert int(rcnt.sum()) == I
+    owner = torch.empty(I, dtype=torch.int64)
+    owner[slot.long().cpu()] = fids.long().cpu()  # row id stored at each emit slot
+    rs, rc = rstart.long().cpu(), rcnt.long().cpu()
+    for r in torch.nonzero(rc).flatten()[:200].tolist():
+        assert bool((owner[rs[r]:rs[r] + rc[r]] == r).all())
+    assert bool((rc[radii[0] <= 0] == 0).all())
+
+    t = [x.to(dev).contiguous() for x in (m2, cn, colors, opac)]
+    out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
+    last = torch.empty(1, h, w, dtype=torch.int32, device=dev)
+    packed = torch.empty(n, 16, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, n, I, dptr(t[0]), dptr(t[1]), dptr(t[2]), dptr(t[3]), None, w, h, 16,
+                                tw, th, dptr(off), dptr(fids), dptr(packed), dptr(out), dptr(al), dptr(last)))
+    vi = torch.randn(1, h, w, 3, generator=g).to(dev)
+    va = torch.randn(1, h, w, generator=g).to(dev)
+
+    def bwd(slots):
+        pg = torch.full((n, 16), float("nan"), device=dev)
+        parts = torch.full((max(I, 1), 16), float("nan"), device=dev)  # every line must be overwritten
+        outs = [torch.empty(n, 2, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev),
+                torch.empty(n, device=dev)]
+        assert L.clmgs_rasterize_partials_bytes(I) == parts.numel() * 4
+        check(L.clmgs_rasterize_bwd(stream(), 1, n, I, dptr(packed), None, w, h, 16, tw, th, dptr(off), dptr(fids),
+                                    dptr(al), dptr(last), dptr(vi), dptr(va), dptr(pg), *[dptr(x) for x in outs],
+                                    *((dptr(slot), dptr(rstart), dptr(rcnt), dptr(parts)) if slots else (None,) * 4)))
+        torch.cuda.synchronize()
+        return [x.cpu() for x in outs]
+
+    ga, gs1, gs2 = bwd(False), bwd(True), bwd(True)
+    for x, y in zip(gs1, gs2):
+        assert torch.equal(x, y), "slot path must be bitwise reproducible"
+    a = [x.clone().double().requires_grad_() for x in (m2, cn, colors, opac)]
+    img0, al0 = O.rasterize_to_pixels(*a, w, h, 16, off.cpu(), fids.cpu())
+    ((img0 * vi.cpu().double()).sum() + (al0[..., 0] * va.cpu().double()).sum()).backward()
+    for name, x, y, ref in zip(("means2d", "conics", "colors", "opacities"), gs1, ga, a):
+        assert torch.isfinite(x).all(), name
+        assert rel_l2(x, y) < 1e-5, name
+        assert rel_l2(x.reshape(ref.grad.shape), ref.grad) < GRAD_TOL, name

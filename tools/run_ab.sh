@@ -1,5 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -12
 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt overlap_cameras=false > gpurun_out/ab0.log 2>&1
 python profiles/show_bench.py gpurun_out/ab0.log 2>&1 | tail -20
 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/ab1.log 2>&1
