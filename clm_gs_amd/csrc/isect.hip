@@ -211,15 +211,15 @@ isect2_count_kernel(int V, const int32_t* __restrict__ order, const float* __res
   }
 }
 
-// gid_tab != NULL ("slot mode"): the sort payload is the EMIT index p itself and gid_tab[p] keeps
-// the row id; row_start/row_cnt give every row its contiguous emit range.  The backward tile
+// vals2 != NULL ("slot mode"): the sort payload is the pair (row id, EMIT index p);
+// row_start/row_cnt give every row its contiguous emit range.  The backward tile
 // kernel then stores its per-(row, tile) partial gradients at p with plain stores and a per-row
 // pass sums the contiguous range: no float atomics, deterministic.
 __global__ void __launch_bounds__(256)
 isect2_emit_kernel(int V, const int32_t* __restrict__ order, const float* __restrict__ means2d,
                    const int32_t* __restrict__ radii, const int64_t* __restrict__ cum,
                    float tile_size, int tile_w, int tile_h, uint32_t* __restrict__ tkeys,
-                   int32_t* __restrict__ vals, int32_t* __restrict__ gid_tab,
+                   int32_t* __restrict__ vals, int2* __restrict__ vals2,
                    int32_t* __restrict__ row_start, int32_t* __restrict__ row_cnt) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
     const int i = order[j];
@@ -232,18 +232,18 @@ isect2_emit_kernel(int V, const int32_t* __restrict__ order, const float* __rest
     for (int ty = b.y0; ty < b.y1; ++ty)
       for (int tx = b.x0; tx < b.x1; ++tx) {
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
-        if (gid_tab) { vals[cur] = (int32_t)cur; gid_tab[cur] = i; }
+        if (vals2) vals2[cur] = make_int2(i, (int)cur);
         else vals[cur] = i;
         ++cur;
       }
   }
 }
 
-// slot mode: sorted_vals holds emit indices; flatten_ids is produced here from gid_tab.
+// slot mode: the sorted (row id, emit index) pairs are split into flatten_ids / emit_slot here.
 __global__ void __launch_bounds__(256)
 isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int n_tiles,
                       int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids,
-                      const int32_t* __restrict__ emit_slot, const int32_t* __restrict__ gid_tab,
+                      int32_t* __restrict__ emit_slot, const int2* __restrict__ sorted2,
                       const float* __restrict__ depths, int64_t* __restrict__ isect_ids) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_isects;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -257,7 +257,7 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
     if (i == n_isects - 1)
       for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
     int gid;
-    if (gid_tab) { gid = gid_tab[emit_slot[i]]; flatten_ids[i] = gid; }
+    if (sorted2) { const int2 v = sorted2[i]; gid = v.x; flatten_ids[i] = gid; emit_slot[i] = v.y; }
     else gid = flatten_ids[i];
     if (isect_ids)
       isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[gid]);
@@ -302,7 +302,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
   if (n_isects <= 0) return 256;
-  return 5 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
+  return 8 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
 }
 
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
@@ -332,25 +332,31 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && flatten_ids && temp);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_sort_temp_bytes(n_isects));
   char* base = (char*)temp;
-  uint32_t* k_a = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  int32_t* v_a = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  int32_t* v_b = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
-  int32_t* gid_tab = (int32_t*)base; base += align_up((size_t)n_isects * 4, 256);
+  const size_t a4 = align_up((size_t)n_isects * 4, 256);
+  uint32_t* k_a = (uint32_t*)base; base += a4;
+  uint32_t* k_b = (uint32_t*)base; base += a4;
+  char* v_a = base; base += 2 * a4;   // int32 payload (plain) or int2 payload (slot mode)
+  char* v_b = base; base += 2 * a4;
+  char* v_f = base; base += 2 * a4;
   uint32_t* table = (uint32_t*)base;
-  if (!emit_slot) gid_tab = nullptr;
+  const bool slots = emit_slot != nullptr;
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
-                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a, v_a,
-                     gid_tab, row_start, row_cnt);
+                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a,
+                     (int32_t*)v_a, slots ? (int2*)v_a : nullptr, row_start, row_cnt);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
-  int rc = radix_sort_pairs<uint32_t>(s, n_isects, k_a, k_b, v_a, v_b,
-                                      emit_slot ? emit_slot : flatten_ids, 0, tile_bits, table, &sorted);
+  int rc;
+  if (slots)
+    rc = radix_sort_pairs<uint32_t, int2>(s, n_isects, k_a, k_b, (int2*)v_a, (int2*)v_b, (int2*)v_f, 0,
+                                          tile_bits, table, &sorted);
+  else
+    rc = radix_sort_pairs<uint32_t, int32_t>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b,
+                                             flatten_ids, 0, tile_bits, table, &sorted);
   if (rc) return rc;
   hipLaunchKernelGGL(isect2_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0,
-                     s, n_isects, sorted, n_tiles, offsets, flatten_ids, emit_slot, gid_tab, depths,
-                     isect_ids);
+                     s, n_isects, sorted, n_tiles, offsets, flatten_ids, emit_slot,
+                     slots ? (const int2*)v_f : nullptr, depths, isect_ids);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -88,10 +88,10 @@ radix_scan_digits_kernel(uint32_t* __restrict__ row_tot) {
   row_tot[threadIdx.x] = woff + x - v;
 }
 
-template <typename KeyT>
+template <typename KeyT, typename ValT>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
-                     KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int shift,
+radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
+                     KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, int shift,
                      int n_blocks, const uint32_t* __restrict__ table,
                      const uint32_t* __restrict__ digit_base) {
   // cnt[round][wave][digit]: first the number of keys of that digit in that (round, wave), then
@@ -108,13 +108,13 @@ radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const int32_t*
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
   KeyT key[RS_ITEMS];
-  int32_t val[RS_ITEMS];
+  ValT val[RS_ITEMS];
   int meta[RS_ITEMS];  // digit | rank << 8 | have << 16
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
     const int64_t i = base + it * RS_THREADS + threadIdx.x;
     const bool have = i < n;
-    key[it] = 0; val[it] = 0;
+    key[it] = 0; val[it] = ValT{};
     if (have) { key[it] = keys_in[i]; val[it] = vals_in[i]; }
     const unsigned digit = (unsigned)((key[it] >> shift) & 0xFF);
     unsigned long long peers = __ballot(have);  // lanes of this wave holding the same digit
@@ -159,7 +159,7 @@ radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const int32_t*
   // consecutive addresses (lanes next to each other hold neighbours of the same digit bucket)
   // instead of 64 unrelated 4-byte writes per instruction.
   __shared__ KeyT skey[RS_CHUNK];
-  __shared__ int32_t sval[RS_CHUNK];
+  __shared__ ValT sval[RS_CHUNK];
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
     if (meta[it] >> 16) {
@@ -193,29 +193,29 @@ static inline size_t radix_table_bytes(int64_t n) {
 // scratch of the same size; `table` is radix_table_bytes(n) of scratch.  The sorted VALUES are
 // written to vals_final (distinct from valsA / valsB); *keys_sorted tells which key buffer holds
 // the sorted keys.
-template <typename KeyT>
-static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, int32_t* valsA,
-                            int32_t* valsB, int32_t* vals_final, int begin_bit, int end_bit,
+template <typename KeyT, typename ValT = int32_t>
+static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
+                            ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
                             uint32_t* table, KeyT** keys_sorted) {
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
   uint32_t* digit_base = table + (size_t)n_blocks * 256;
   KeyT* ksrc = keysA;
-  int32_t* vsrc = valsA;
+  ValT* vsrc = valsA;
   if (passes == 0) {
-    CLMGS_HIP(hipMemcpyAsync(vals_final, valsA, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    CLMGS_HIP(hipMemcpyAsync(vals_final, valsA, sizeof(ValT) * (size_t)n, hipMemcpyDeviceToDevice, s));
     *keys_sorted = keysA;
     return 0;
   }
   for (int p = 0; p < passes; ++p) {
     const int shift = begin_bit + 8 * p;
     KeyT* kdst = (ksrc == keysA) ? keysB : keysA;
-    int32_t* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
+    ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
     hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
                        n_blocks, table);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, s, n_blocks, table, digit_base);
     hipLaunchKernelGGL(radix_scan_digits_kernel, dim3(1), dim3(256), 0, s, digit_base);
-    hipLaunchKernelGGL((radix_scatter_kernel<KeyT>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
+    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
                        kdst, vdst, shift, n_blocks, table, digit_base);
     CLMGS_LAUNCH_CHECK();
     ksrc = kdst;
