@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="rubble28m", choices=sorted(CONFIGS))
-    ap.add_argument("--strategy", default="clm_offload", choices=["clm_offload", "no_offload"])
+    ap.add_argument("--strategy", default="clm_offload", choices=["clm_offload", "no_offload", "naive_offload"])
     ap.add_argument("--residency", default="hbm", choices=["hbm", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
@@ -177,6 +177,9 @@ def main():
     if a.strategy == "clm_offload":
         from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
         gaussians = GaussianModelCLMOffload(3)
+    elif a.strategy == "naive_offload":
+        from clm_gs_amd.strategies.naive_offload import GaussianModelNaiveOffload, naive_offload_train_one_batch
+        gaussians = GaussianModelNaiveOffload(3)
     else:
         from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload, baseline_accumGrads_impl
         gaussians = GaussianModelNoOffload(3)
@@ -203,6 +206,9 @@ def main():
             losses, _, sparsity = clm_offload_train_one_batch(
                 gaussians, _Scene, batch, gaussians.parameters_grad_buffer, None, None, comm_stream,
                 perm_generator)
+        elif a.strategy == "naive_offload":
+            losses, _ = naive_offload_train_one_batch(gaussians, _Scene, batch, None)
+            sparsity = None
         else:
             losses, _ = baseline_accumGrads_impl(gaussians, _Scene, batch, None)
             for p in gaussians.all_parameters():

@@ -42,12 +42,15 @@ def pinned_empty(shape, dtype=torch.float32):
     itemsize = torch.empty((), dtype=dtype).element_size()
     block = _PinnedBlock(n * itemsize)
     buf = (ctypes.c_char * max(n * itemsize, 16)).from_address(block.ptr)
+    # ownership rides on the STORAGE, not on one tensor object: torch keeps `arr` alive for as long
+    # as any tensor / view / Parameter shares the storage, `arr.base` is `buf`, `buf` owns the block
+    buf._clmgs_block = block
     arr = np.frombuffer(buf, dtype=_NP[dtype], count=n).reshape(tuple(int(s) for s in shape))
     t = torch.from_numpy(arr)
-    t._clmgs_block = block  # keep the allocation alive with the tensor
     t._clmgs_pinned = True
     return t
 
 
 def is_pinned(t):
+    """True for pinned_empty() tensors (and views made through this module's users) or torch-pinned."""
     return bool(getattr(t, "_clmgs_pinned", False)) or t.is_pinned()

@@ -306,3 +306,71 @@ def test_densify_and_prune_keeps_state_aligned(dev, strategy, residency):
         from clm_gs_amd.strategies.no_offload import baseline_accumGrads_impl
         losses, _ = baseline_accumGrads_impl(m, _Scene, cams, None)
     assert all(torch.isfinite(l) for l in losses)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_naive_offload_equals_clm_offload_after_two_steps(dev, sparse):
+    """Row f4: everything on the host, whole-model copies per batch -> same losses and the same
+    parameters as clm_offload (hbm) after two optimizer steps; eval renders agree.  sparse_adam:
+    the reference's strategies differ by construction (clm updates the small attributes with
+    SelectiveAdam = no bias correction, naive with the bias-corrected host Adam), so there only the
+    SH rows, the first losses and the untouched rows are compared."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_eval_one_cam, clm_offload_train_one_batch
+    from clm_gs_amd.strategies.naive_offload import (GaussianModelNaiveOffload, naive_offload_eval_one_cam,
+                                                     naive_offload_train_one_batch, render_single_image)
+    args, sc, cams = _setup("clm_offload", "hbm", sparse)
+    ref = _make("clm_offload", sc, args)
+    comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+    ref_losses = []
+    for it in (1, 1 + BSZ):
+        utils.set_cur_iter(it)
+        ref.update_learning_rate(it)
+        l, order, _ = clm_offload_train_one_batch(ref, _Scene, cams, ref.parameters_grad_buffer, None, None, comm, gen)
+        lo = [0.0] * BSZ
+        for k, v in zip(order, l):
+            lo[k] = v.item()
+        ref_losses.append(lo)
+        if it == 1:
+            ref_shs_step1 = ref._parameters.detach().clone()
+
+    args2 = utils.default_args(bsz=BSZ, sparse_adam=sparse)
+    args2.naive_offload = True
+    utils.set_args(args2)
+    m = GaussianModelNaiveOffload(3)
+    m.create_from_tensors(sc["xyz"].clone(), sc["shs48"].clone(), sc["scaling"].clone(), sc["rotation"].clone(),
+                          sc["opacity"].clone(), spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(args2)
+    assert not m._small.is_cuda and m._small.is_pinned() and m._parameters.is_pinned()
+    assert m._xyz.shape == (N, 3) and m._features_rest.shape == (N, 15, 3)
+    for step, it in enumerate((1, 1 + BSZ)):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        losses, vis = naive_offload_train_one_batch(m, _Scene, cams, None, sparse_adam=sparse)
+        assert (vis is not None) == sparse
+        if step == 0 or not sparse:
+            for u, v in zip(ref_losses[step], [x.item() for x in losses]):
+                assert abs(u - v) < 2e-5
+        if sparse and step == 0:
+            untouched = ~vis.cpu()
+            assert untouched.any() and torch.equal(m._small.detach()[untouched][:, :11],
+                                                   torch.cat((sc["xyz"], sc["opacity"], sc["scaling"], sc["rotation"]), 1).cpu()[untouched])
+            assert torch.equal(m._parameters.detach()[untouched], sc["shs48"].cpu()[untouched])
+            frac = _frac_differs(m._parameters.detach().cuda(), ref_shs_step1, sc["shs48"].cuda(), 0.02)
+            assert frac < 0.01, frac
+    ref.flush_lazy_rows() if getattr(ref, "lazy_rows", False) else None
+    torch.cuda.synchronize()
+    init = sc
+    names = () if sparse else (
+        ("xyz", m._xyz, ref._xyz), ("opacity", m._opacity, ref._opacity), ("scaling", m._scaling, ref._scaling),
+        ("rotation", m._rotation, ref._rotation), ("shs48", m._parameters, ref._parameters))
+    for name, a, b in names:
+        frac = _frac_differs(a.detach().cuda(), b.detach().cuda().reshape(a.shape), init[name].cuda().reshape(a.shape), 0.02)
+        assert frac < 0.01, (name, frac)
+    img_n = naive_offload_eval_one_cam(m, _Scene, cams[0], None)
+    img_c = clm_offload_eval_one_cam(cams[0], ref, None, _Scene)
+    assert sparse or (img_n - img_c).abs().max() < 5e-3
+    assert torch.equal(render_single_image(m, _Scene, cams[0]), torch.clamp(img_n, 0, 1))
+    with pytest.raises(NotImplementedError):
+        m.prune_points(torch.zeros(N, dtype=torch.bool, device=dev))
