@@ -63,6 +63,46 @@ class UnifiedAdam(torch.optim.Optimizer):
         self.param_groups = self.gpu_adam.param_groups + self.cpu_adam.param_groups
         self.state = self.gpu_adam.state | self.cpu_adam.state
 
+    @torch.no_grad()
+    def gpu_step_scaled(self, grad_scale=1.0):
+        """Dense Adam of the GPU-resident groups through clmgs_adam_rows: gradient scale (the
+        engine's `grad /= bsz`), update and gradient zeroing in ONE pass per tensor instead of
+        torch's three (div, fused Adam, fresh zeros next batch).  State stays in
+        torch.optim.Adam's own layout (step / exp_avg / exp_avg_sq per parameter), so the
+        densification surgery, capture / restore and a later torch .step() keep working; same
+        bias-corrected formula as torch (step_size = lr / bc1, denom = sqrt(v) / sqrt(bc2) + eps)."""
+        from .clm_kernels import adam_rows
+        assert not isinstance(self.gpu_adam, SelectiveAdam)
+        for group in self.gpu_adam.param_groups:
+            p = group["params"][0]
+            if p.grad is None:
+                continue
+            st = self.gpu_adam.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            cache = self.__dict__.setdefault("_gpu_steps", {})
+            if id(st["step"]) not in cache:  # one host read per (re)created state, then counted here
+                cache.clear() if len(cache) > 64 else None
+                cache[id(st["step"])] = int(st["step"].item())
+            cache[id(st["step"])] += 1
+            step = cache[id(st["step"])]
+            st["step"] += 1
+            # one learning rate per tensor -> the [N,d] layout is irrelevant: stream it as float4 rows
+            cols = 4 if p.numel() % 4 == 0 else 1
+            key = (cols, float(group["lr"]))
+            lrs = self.__dict__.setdefault("_col_lr_cache", {})
+            if key not in lrs:
+                if len(lrs) > 256:
+                    lrs.clear()
+                lrs[key] = torch.full((cols,), float(group["lr"]), dtype=torch.float32, device=p.device)
+            b1, b2 = group["betas"]
+            adam_rows(p.data.view(-1, cols), p.grad.view(-1, cols), st["exp_avg"].view(-1, cols),
+                      st["exp_avg_sq"].view(-1, cols), None, lrs[key], b1, b2, group["eps"], step, True,
+                      float(grad_scale), True)
+        self.state = self.gpu_adam.state | self.cpu_adam.state
+
     def get_all_states(self):
         return [self.gpu_adam.state, self.cpu_adam.state]
 

@@ -198,22 +198,31 @@ def _render_and_backward(gaussians, scene, camera, background, pipe_args, this_f
 
 
 def _zero_small_grads(gaussians):
-    gaussians._xyz.grad = torch.zeros_like(gaussians._xyz)
-    gaussians._opacity.grad = torch.zeros_like(gaussians._opacity)
-    gaussians._scaling.grad = torch.zeros_like(gaussians._scaling)
-    gaussians._rotation.grad = torch.zeros_like(gaussians._rotation)
+    """Full-size gradient accumulators of the four GPU-resident tensors.  The dense Adam pass
+    (_gpu_adam_step) leaves them zeroed and marks them clean, so they are reused batch after
+    batch; anything else (first batch, densification replaced the parameter, sparse / frozen
+    modes) gets fresh zeros."""
+    clean = getattr(gaussians, "_clean_grad_ptrs", ())
+    for p in (gaussians._xyz, gaussians._opacity, gaussians._scaling, gaussians._rotation):
+        g = p.grad
+        if g is None or g.shape != p.shape or g.data_ptr() not in clean:
+            p.grad = torch.zeros_like(p)
+    gaussians._clean_grad_ptrs = ()
 
 
 def _gpu_adam_step(gaussians, args, visibility_mask):
-    for param in gaussians.all_parameters()[:4]:
-        if param.grad is not None:
-            param.grad /= args.bsz
-    if not args.stop_update_param:
-        if args.sparse_adam:
+    small = gaussians.all_parameters()[:4]
+    if args.stop_update_param or args.sparse_adam:
+        for param in small:
+            if param.grad is not None:
+                param.grad /= args.bsz
+        if not args.stop_update_param:
             gaussians.optimizer.gpu_adam.step(visibility=visibility_mask)
-        else:
-            gaussians.optimizer.gpu_adam.step()
-    gaussians.optimizer.gpu_adam.zero_grad(set_to_none=True)
+        gaussians.optimizer.gpu_adam.zero_grad(set_to_none=True)
+        return
+    # dense: grad / bsz, Adam and gradient zeroing fused into one pass per tensor
+    gaussians.optimizer.gpu_step_scaled(1.0 / args.bsz)
+    gaussians._clean_grad_ptrs = tuple(p.grad.data_ptr() for p in small if p.grad is not None)
 
 
 # ----------------------------------------------------------------------- HBM-resident
