@@ -28,6 +28,8 @@ CONFIGS = {
     "rubble28m": (28_000_000, 4608, 3456, 4, 0.10, "Rubble-4K 28M Gaussians, clm_offload, 1xMI355X (paper headline row)"),
     "rubble10m": (10_000_000, 4608, 3456, 4, 0.15, "Rubble-4K 10M Gaussians, clm_offload"),
     "bicycle6m": (6_000_000, 1237, 822, 4, 0.25, "MipNeRF360 Bicycle ~6M Gaussians"),
+    "bigcity102m": (102_231_360, 1920, 1080, 8, 0.02, "BigCity Aerial 102M Gaussians, clm_offload, sparse Adam, "
+                    "no densification; bsz 64 = 8 GPUs x 8 cameras (bigcity.sh:54-85)"),
     "small": (200_000, 640, 480, 4, 0.3, "CI-size smoke configuration"),
 }
 
@@ -155,6 +157,9 @@ def main():
 
     N, W, H, bsz, vis_frac, desc = CONFIGS[a.config]
     args = utils.default_args(bsz=bsz, sh_residency=a.residency)
+    if a.config == "bigcity102m":  # as scripted by the reference: sparse Adam, densification off
+        args.sparse_adam = True
+        args.disable_auto_densification = True
     setattr(args, a.strategy, True)
     for kv in a.opt:
         k, v = kv.split("=", 1)

@@ -9,8 +9,9 @@
 //     and reused for up to 4 pixels per lane: LDS traffic per pixel-Gaussian pair is 1/4 of a
 //     thread-per-pixel kernel, there is no multi-wave barrier, and the independent pixels give
 //     the exp/fma chain ILP;
-//   * exact sub-tile culling: the staging lane computes the pixel bounding box of
-//     {alpha >= 1/255} from the conic and opacity and a 4-bit quadrant mask.  Records whose box
+//   * exact sub-tile culling: the staging lane computes, from the conic and opacity, the exact
+//     minimum of sigma over each 8x8 quadrant and a 4-bit mask of the quadrants where
+//     alpha >= 1/255 is reachable.  Records whose box
 //     misses the tile are compacted away with a ballot/popcount prefix (depth order kept),
 //     quadrants it misses are skipped with wave-uniform branches.  Only pairs the reference
 //     itself skips (alpha < 1/255) are dropped, so results are unchanged;
@@ -81,25 +82,52 @@ __device__ __forceinline__ void tile_range(const int32_t* __restrict__ offsets, 
   e = (tile == n_tiles_total - 1) ? (int)n_isects : offsets[tile + 1];
 }
 
-// Quadrant mask of the pixels (centres) where alpha can reach 1/255:
-// sigma <= L = ln(255 o)  =>  |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
+// min over t in [lo, hi] of  q = 0.5 * (Af * f^2 + 2 * B * f * t + Ct * t^2)   (f fixed, Ct > 0)
+__device__ __forceinline__ float edge_min_sigma(float Af, float B, float Ct, float rcpCt, float f,
+                                                float lo, float hi) {
+  const float t = fminf(fmaxf(-B * f * rcpCt, lo), hi);
+  return 0.5f * (Af * f * f + (2.f * B * f + Ct * t) * t);
+}
+
+// Exact minimum of sigma(d) = 0.5 (a dx^2 + 2 b dx dy + c dy^2) over the rectangle
+// [ux0, ux1] x [vy0, vy1] of offsets from the Gaussian centre (convex: 0 if the centre is inside,
+// otherwise attained on one of the four edges).
+__device__ __forceinline__ float rect_min_sigma(float ca, float cb, float cc, float rca, float rcc,
+                                                float ux0, float ux1, float vy0, float vy1) {
+  if (ux0 <= 0.f && ux1 >= 0.f && vy0 <= 0.f && vy1 >= 0.f) return 0.f;
+  const float e0 = edge_min_sigma(ca, cb, cc, rcc, ux0, vy0, vy1);
+  const float e1 = edge_min_sigma(ca, cb, cc, rcc, ux1, vy0, vy1);
+  const float e2 = edge_min_sigma(cc, cb, ca, rca, vy0, ux0, ux1);
+  const float e3 = edge_min_sigma(cc, cb, ca, rca, vy1, ux0, ux1);
+  return fminf(fminf(e0, e1), fminf(e2, e3));
+}
+
+// Quadrant mask of the pixels (centres) where alpha can reach 1/255, i.e. sigma <= L = ln(255 o).
+// Exact: the minimum of sigma over each quadrant's rectangle of pixel centres is compared with L
+// (a small margin absorbs rounding), so a quadrant is skipped only if EVERY pixel in it fails the
+// reference's own alpha >= 1/255 test -- results are unchanged.  The test costs ~150 VALU but
+// runs once per entry on the staging lane (64 entries per instruction): ~2.5 VALU per entry to
+// save whole 64-lane blend passes.
 __device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, float ca, float cb,
                                              float cc, float tile_x0, float tile_y0) {
   if (!(opac >= ALPHA_MIN)) return 0;
   const float L = __logf(255.f * opac);
   const float det = ca * cc - cb * cb;
-  if (!(det > 0.f)) return 15;  // degenerate conic: never cull
-  const float s = 2.f * L * __builtin_amdgcn_rcpf(det);
-  const float ex = sqrtf(fmaxf(s * cc, 0.f)) * 1.0001f + 1e-3f;
-  const float ey = sqrtf(fmaxf(s * ca, 0.f)) * 1.0001f + 1e-3f;
-  if (!(ex == ex) || !(ey == ey)) return 15;
-  const float xl = mx - ex, xh = mx + ex, yl = my - ey, yh = my + ey;
-  // quadrant q covers pixel centres [q0 + 0.5, q0 + 7.5]
-  const bool x0 = (xh >= tile_x0 + 0.5f) && (xl <= tile_x0 + 7.5f);
-  const bool x1 = (xh >= tile_x0 + 8.5f) && (xl <= tile_x0 + 15.5f);
-  const bool y0 = (yh >= tile_y0 + 0.5f) && (yl <= tile_y0 + 7.5f);
-  const bool y1 = (yh >= tile_y0 + 8.5f) && (yl <= tile_y0 + 15.5f);
-  return (int)(x0 && y0) | ((int)(x1 && y0) << 1) | ((int)(x0 && y1) << 2) | ((int)(x1 && y1) << 3);
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 15;  // degenerate conic: never cull
+  const float Lm = L * 1.0001f + 1e-4f;
+  if (!(Lm == Lm)) return 15;
+  const float rca = __builtin_amdgcn_rcpf(ca), rcc = __builtin_amdgcn_rcpf(cc);
+  // quadrant q covers pixel centres [q0 + 0.5, q0 + 7.5]; offsets are pixel - centre
+  const float xa0 = tile_x0 + 0.5f - mx, xa1 = tile_x0 + 7.5f - mx;
+  const float xb0 = tile_x0 + 8.5f - mx, xb1 = tile_x0 + 15.5f - mx;
+  const float ya0 = tile_y0 + 0.5f - my, ya1 = tile_y0 + 7.5f - my;
+  const float yb0 = tile_y0 + 8.5f - my, yb1 = tile_y0 + 15.5f - my;
+  int m = 0;
+  if (rect_min_sigma(ca, cb, cc, rca, rcc, xa0, xa1, ya0, ya1) <= Lm) m |= 1;
+  if (rect_min_sigma(ca, cb, cc, rca, rcc, xb0, xb1, ya0, ya1) <= Lm) m |= 2;
+  if (rect_min_sigma(ca, cb, cc, rca, rcc, xa0, xa1, yb0, yb1) <= Lm) m |= 4;
+  if (rect_min_sigma(ca, cb, cc, rca, rcc, xb0, xb1, yb0, yb1) <= Lm) m |= 8;
+  return m;
 }
 
 __global__ void __launch_bounds__(64)

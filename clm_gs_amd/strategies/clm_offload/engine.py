@@ -294,23 +294,28 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         from ...fused import train_one_camera
         mode = getattr(args, "overlap_cameras", True)
         mode = {True: "typed", False: "off"}.get(mode, mode)
+        n_lanes = max(1, int(getattr(args, "overlap_lanes", 2)))
         sts = getattr(gaussians, "_clmgs_streams", None)
-        if sts is None:
+        if sts is None or len(sts["mem"]) < n_lanes:
             try:
                 lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
             except AttributeError:
                 lo, hi = 0, -1
             sts = gaussians._clmgs_streams = {
                 "aux": torch.cuda.Stream(),
-                "mem": [torch.cuda.Stream(priority=hi), torch.cuda.Stream(priority=hi)],
-                "raster": torch.cuda.Stream(priority=lo)}
-        raster = None
+                "mem": [torch.cuda.Stream(priority=hi) for _ in range(n_lanes)],
+                "raster": [torch.cuda.Stream(priority=lo) for _ in range(n_lanes)]}
+        rasters = None
         if mode == "typed":
-            # streams by kernel TYPE: every camera's ALU-bound tile kernels share one low-priority
-            # stream (they gain nothing from overlapping each other), the latency-bound rest of
-            # camera i / i+1 runs on two high-priority streams and is dispatched first whenever it
-            # has work -- it fills the memory system while the tile kernels fill the VALUs
-            lanes, raster = sts["mem"], sts["raster"]
+            # streams by kernel TYPE: the ALU-bound tile kernels run on low-priority streams, the
+            # latency-bound rest of the cameras in flight on high-priority streams and is dispatched
+            # first whenever it has work -- it fills the memory system while the tile kernels fill
+            # the VALUs.  Large images: ONE tile stream (a 4K image has 62 k tiles, tile kernels gain
+            # nothing from overlapping each other); small images (a 1080p image has 8 k one-wave
+            # tiles for 1024 SIMDs x 5 waves): one tile stream per camera in flight.
+            lanes = sts["mem"][:n_lanes]
+            n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
+            rasters = sts["raster"][:n_lanes] if n_tiles < 20000 else [sts["raster"][0]] * n_lanes
         elif mode == "camera":
             lanes = [default_stream, sts["aux"]]
         else:
@@ -324,7 +329,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 loss, prev = train_one_camera(
                     gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
                     background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
-                    return_event=True, raster_stream=raster)
+                    return_event=True,
+                    raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None)
             losses.append(loss)
         for ln in lanes:
             if ln is not default_stream:
