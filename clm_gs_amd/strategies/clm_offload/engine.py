@@ -210,18 +210,21 @@ def _zero_small_grads(gaussians):
     gaussians._clean_grad_ptrs = ()
 
 
-def _gpu_adam_step(gaussians, args, visibility_mask):
+def _gpu_adam_step(gaussians, args, visibility_mask, grad_div=None):
+    """grad_div: what the accumulated gradients are divided by (bsz, or bsz x ranks when camera-DP
+    summed them over ranks)."""
+    grad_div = float(grad_div or args.bsz)
     small = gaussians.all_parameters()[:4]
     if args.stop_update_param or args.sparse_adam:
         for param in small:
             if param.grad is not None:
-                param.grad /= args.bsz
+                param.grad /= grad_div
         if not args.stop_update_param:
             gaussians.optimizer.gpu_adam.step(visibility=visibility_mask)
         gaussians.optimizer.gpu_adam.zero_grad(set_to_none=True)
         return
     # dense: grad / bsz, Adam and gradient zeroing fused into one pass per tensor
-    gaussians.optimizer.gpu_step_scaled(1.0 / args.bsz)
+    gaussians.optimizer.gpu_step_scaled(1.0 / grad_div)
     gaussians._clean_grad_ptrs = tuple(p.grad.data_ptr() for p in small if p.grad is not None)
 
 
@@ -265,7 +268,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         clm_kernels.adam_rows(params.data, None if zero_grad_rows else grad_buf, st["exp_avg"],
                               st["exp_avg_sq"], rows, col_lr,
                               group["betas"][0], group["betas"][1], group["eps"], step,
-                              group["bias_correction"], 1.0 / bsz, True)
+                              group["bias_correction"], 1.0 / (bsz * dp.world_size()), True)
 
     touched_rows = torch.nonzero(touched).flatten().to(torch.int32)
     lazy = gaussians.lazy_rows and not args.stop_update_param
@@ -347,11 +350,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
-    if dp.world_size() > 1:  # camera-DP: the one exchange of the batch
+    if dp.world_size() > 1:  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
+        # the Adam gradient scale, so no tensor is touched just to be divided)
         dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
-                                  gaussians._scaling.grad, gaussians._rotation.grad])
-        dp.allreduce_rows(grad_buf, touched)
-    _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None)
+                                  gaussians._scaling.grad, gaussians._rotation.grad], average=False)
+        dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
+    _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
+                   grad_div=bsz * dp.world_size())
     if not args.stop_update_param:
         row_update(touched_rows)
         if lazy:
@@ -374,6 +379,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
     dev = gaussians._xyz.device
+    assert dp.world_size() == 1, "camera-DP is built for sh_residency='hbm' (every rank holds a full replica)"
     with torch.no_grad():
         filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
                                           gaussians.get_scaling, gaussians.get_rotation)
