@@ -238,6 +238,105 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
   }
 }
 
+// Dense Adam of the 11 GPU-resident attributes when the engine keeps the packed [N,12] mirror
+// (xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad) and accumulates their gradients in a packed
+// [N,12] table: one pass reads the gradient row, updates p / m / v of the four parameter tensors
+// (torch.optim.Adam's own state tensors), refreshes the mirror row and zeroes the gradient row.
+struct SmallAdam {
+  float* p[4]; float* m[4]; float* v[4];  // xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]
+  float lr[4];
+};
+
+// One block = 256 rows.  The packed gradient rows are staged in LDS with coalesced 16 B loads;
+// each of the four tensors is then walked as a FLAT float4 stream (its [256, w] slab is contiguous),
+// the gradient of element (row, e) comes from LDS, the new parameter goes back to LDS, and the
+// mirror rows leave with coalesced 16 B stores: every global access is a full-wave 16 B/lane run.
+constexpr int SA_ROWS = 256;
+
+__device__ __forceinline__ float adam_elem(float& m, float& v, float p, float g, float lr_bc, float beta1,
+                                           float beta2, float ob1, float ob2, float eps,
+                                           float inv_sqrt_bc2) {
+  m = beta1 * m + ob1 * g;
+  v = beta2 * v + ob2 * g * g;
+  return p - lr_bc * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+
+__global__ void __launch_bounds__(SA_ROWS)
+adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
+                         float4* __restrict__ packed_g, float beta1, float beta2, float ob1,
+                         float ob2, float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
+  __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
+  __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
+  const int tid = threadIdx.x;
+  const int64_t n_blocks = (n + SA_ROWS - 1) / SA_ROWS;
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int64_t row0 = blk * SA_ROWS;
+    const int rows = (int)min((int64_t)SA_ROWS, n - row0);
+    __syncthreads();
+    for (int i = tid; i < rows * 3; i += SA_ROWS)
+      reinterpret_cast<float4*>(sg)[i] = packed_g[row0 * 3 + i];
+    if (tid < rows) sp[tid * 12 + 11] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int w = ti == 0 ? 3 : (ti == 1 ? 1 : (ti == 2 ? 3 : 4));
+      const int co = ti == 0 ? 0 : (ti == 1 ? 3 : (ti == 2 ? 4 : 7));
+      const int n_el = rows * w;
+      float* P = t.p[ti] + row0 * w;
+      float* M = t.m[ti] + row0 * w;
+      float* V = t.v[ti] + row0 * w;
+      const float lr_bc = t.lr[ti] * inv_bc1;
+      for (int i = tid * 4; i < n_el; i += SA_ROWS * 4) {
+        if (i + 3 < n_el) {
+          float4 p4 = *reinterpret_cast<float4*>(P + i), m4 = *reinterpret_cast<float4*>(M + i),
+                 v4 = *reinterpret_cast<float4*>(V + i);
+          float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+                vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = i + k, row = idx / w, e = idx - row * w;
+            pp[k] = adam_elem(mm[k], vv[k], pp[k], sg[row * 12 + co + e] * grad_scale, lr_bc, beta1, beta2,
+                              ob1, ob2, eps, inv_sqrt_bc2);
+            sp[row * 12 + co + e] = pp[k];
+          }
+          *reinterpret_cast<float4*>(P + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+          *reinterpret_cast<float4*>(M + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+          *reinterpret_cast<float4*>(V + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+          for (int idx = i; idx < n_el; ++idx) {  // ragged tail of the last block
+            const int row = idx / w, e = idx - row * w;
+            float mm = M[idx], vv = V[idx];
+            const float pn = adam_elem(mm, vv, P[idx], sg[row * 12 + co + e] * grad_scale, lr_bc, beta1,
+                                       beta2, ob1, ob2, eps, inv_sqrt_bc2);
+            P[idx] = pn; M[idx] = mm; V[idx] = vv;
+            sp[row * 12 + co + e] = pn;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < rows * 3; i += SA_ROWS) {
+      packed_p[row0 * 3 + i] = reinterpret_cast<const float4*>(sp)[i];
+      packed_g[row0 * 3 + i] = z;
+    }
+  }
+}
+
+// [N,12] mirror from the four parameter tensors
+__global__ void __launch_bounds__(256)
+pack_small_kernel(int64_t n, const float* __restrict__ xyz, const float* __restrict__ opa,
+                  const float* __restrict__ sca, const float* __restrict__ rot,
+                  float4* __restrict__ packed_p) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const float4 q = *reinterpret_cast<const float4*>(rot + 4 * r);
+    packed_p[3 * r] = make_float4(xyz[3 * r], xyz[3 * r + 1], xyz[3 * r + 2], opa[r]);
+    packed_p[3 * r + 1] = make_float4(sca[3 * r], sca[3 * r + 1], sca[3 * r + 2], q.x);
+    packed_p[3 * r + 2] = make_float4(q.y, q.z, q.w, 0.f);
+  }
+}
+
 // ------------------------------------------------------- densification stats
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(int64_t n, const int64_t* __restrict__ filter,
@@ -371,6 +470,44 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
   if (idx_is_64) { if (v4) CLMGS_CATCH_UP(int64_t, 4); else CLMGS_CATCH_UP(int64_t, 1); }
   else { if (v4) CLMGS_CATCH_UP(int32_t, 4); else CLMGS_CATCH_UP(int32_t, 1); }
 #undef CLMGS_CATCH_UP
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_pack_small(void* stream, int64_t n, const float* xyz, const float* opacity,
+                                const float* scaling, const float* rotation, void* packed_p) {
+  CLMGS_CHECK_ARG(n >= 0);
+  if (n == 0) return 0;
+  CLMGS_CHECK_ARG(xyz && opacity && scaling && rotation && packed_p && (((uintptr_t)packed_p & 15) == 0));
+  hipLaunchKernelGGL(pack_small_kernel, dim3(min(ceil_div(n, 256), 256 * 16)), dim3(256), 0,
+                     (hipStream_t)stream, n, xyz, opacity, scaling, rotation, (float4*)packed_p);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_adam_small_packed(void* stream, int64_t n, float* const* params,
+                                       float* const* exp_avg, float* const* exp_avg_sq,
+                                       const double* lr4, void* packed_p, void* packed_g,
+                                       double beta1, double beta2, double eps, int step,
+                                       int bias_correction, float grad_scale) {
+  CLMGS_CHECK_ARG(n >= 0 && step >= 1);
+  if (n == 0) return 0;
+  CLMGS_CHECK_ARG(params && exp_avg && exp_avg_sq && lr4 && packed_p && packed_g &&
+                  (((uintptr_t)packed_p | (uintptr_t)packed_g) & 15) == 0);
+  SmallAdam t;
+  for (int i = 0; i < 4; ++i) {
+    CLMGS_CHECK_ARG(params[i] && exp_avg[i] && exp_avg_sq[i]);
+    t.p[i] = params[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.lr[i] = (float)lr4[i];
+  }
+  float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+  if (bias_correction) {
+    inv_bc1 = (float)(1.0 / (1.0 - pow(beta1, (double)step)));
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+  }
+  const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
+  hipLaunchKernelGGL(adam_small_packed_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
+                     (hipStream_t)stream, n, t, (float4*)packed_p, (float4*)packed_g, (float)beta1,
+                     (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,7 @@ struct PreArgs {
   const float* rotation_raw;    // [N,4]
   const float* sh_rows;         // [N,48] indexed by row id, or [V,48] indexed by i (sh_by_filter=0)
   int sh_by_filter;
+  int packed_small;             // 1: `xyz` is the [N,12] table xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad
   float viewmat[16];
   float K[9];
   float campos[3];
@@ -42,6 +43,27 @@ struct PreArgs {
 #define CLMGS_ELEM(j) const int e = t + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// The 11 small attributes of row g: from four arrays (four scattered 4-16 B pieces, each costing a
+// 64 B line) or from one 48 B row of the packed table (1.5 lines on average).
+struct SmallRow { float m[3]; float4 q4; float s[3]; float oraw; };
+template <bool PK>
+__device__ __forceinline__ SmallRow load_small(const PreArgs& a, int64_t g) {
+  SmallRow r;
+  if (PK) {
+    const float4* row = reinterpret_cast<const float4*>(a.xyz) + 3 * g;
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    r.m[0] = r0.x; r.m[1] = r0.y; r.m[2] = r0.z; r.oraw = r0.w;
+    r.s[0] = r1.x; r.s[1] = r1.y; r.s[2] = r1.z;
+    r.q4 = make_float4(r1.w, r2.x, r2.y, r2.z);
+  } else {
+    r.m[0] = a.xyz[3 * g]; r.m[1] = a.xyz[3 * g + 1]; r.m[2] = a.xyz[3 * g + 2];
+    r.q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * g);
+    r.s[0] = a.scaling_raw[3 * g]; r.s[1] = a.scaling_raw[3 * g + 1]; r.s[2] = a.scaling_raw[3 * g + 2];
+    r.oraw = a.opacity_raw[g];
+  }
+  return r;
+}
 
 // LDS hand-over between the lanes of ONE wavefront: orders the compiler's memory operations and
 // costs no s_waitcnt (a wave's LDS operations execute in order); unlike __syncthreads() it does
@@ -65,7 +87,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   * backward: the current values of every read-modify-write target are requested up front
 //     together with the inputs, and the SH gradient rows while the SH VJP computes.
 // OVERLAP = false (no filter: most rows are culled) projects first and stages only live rows.
-template <int DEG, bool OVERLAP>
+template <int DEG, bool OVERLAP, bool PK>
 __global__ void __launch_bounds__(PP_ROWS, 3)
 preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __restrict__ means2d,
                       float* __restrict__ depths, float* __restrict__ conics,
@@ -85,10 +107,11 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
     const int base = chunk * PP_ROWS;
     const bool mine = my_row >= 0;
     const int64_t g = mine ? my_row : 0;
-    const float m[3] = {a.xyz[3 * g], a.xyz[3 * g + 1], a.xyz[3 * g + 2]};
-    const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * g);
-    const float s[3] = {a.scaling_raw[3 * g], a.scaling_raw[3 * g + 1], a.scaling_raw[3 * g + 2]};
-    const float oraw = a.opacity_raw[g];
+    const SmallRow sr = load_small<PK>(a, g);
+    const float m[3] = {sr.m[0], sr.m[1], sr.m[2]};
+    const float4 q4 = sr.q4;
+    const float s[3] = {sr.s[0], sr.s[1], sr.s[2]};
+    const float oraw = sr.oraw;
     CLMGS_FOR12(CLMGS_DECL_ST)
     if (OVERLAP) {
 #define CLMGS_X(j)                                                                                  \
@@ -178,11 +201,12 @@ struct PreGrads {
   float* max_radii2D;    // [N] or NULL (no statistics)
   float* grad_accum;     // [N]
   float* denom;          // [N]
+  int packed_grads;      // 1: g_xyz is the [N,12] gradient table laid out like the packed parameters
   float* v_means2d_out;  // [V,2] or NULL: copy of the screen-space gradient (API parity)
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
 };
 
-template <int DEG, bool EARLY, int WAVES>
+template <int DEG, bool EARLY, int WAVES, bool PK>
 __global__ void __launch_bounds__(PP_ROWS, WAVES)
 preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
                       const float4* __restrict__ packed_grad, PreGrads o) {
@@ -215,14 +239,25 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const float4 ga = packed_grad[4 * (size_t)i];   // line: x y ca cb | cc r g b | o
     const float4 gb = packed_grad[4 * (size_t)i + 1];
     const float go = packed_grad[4 * (size_t)i + 2].x;
-    const float m[3] = {a.xyz[3 * gl], a.xyz[3 * gl + 1], a.xyz[3 * gl + 2]};
-    const float4 q4 = *reinterpret_cast<const float4*>(a.rotation_raw + 4 * gl);
-    const float s[3] = {a.scaling_raw[3 * gl], a.scaling_raw[3 * gl + 1], a.scaling_raw[3 * gl + 2]};
-    const float oraw = a.opacity_raw[gl];
-    const float c_xyz[3] = {o.g_xyz[3 * gl], o.g_xyz[3 * gl + 1], o.g_xyz[3 * gl + 2]};
-    const float c_sc[3] = {o.g_scaling[3 * gl], o.g_scaling[3 * gl + 1], o.g_scaling[3 * gl + 2]};
-    const float4 c_rot = *reinterpret_cast<const float4*>(o.g_rotation + 4 * gl);
-    const float c_op = o.g_opacity[gl];
+    const SmallRow sr = load_small<PK>(a, gl);
+    const float m[3] = {sr.m[0], sr.m[1], sr.m[2]};
+    const float4 q4 = sr.q4;
+    const float s[3] = {sr.s[0], sr.s[1], sr.s[2]};
+    const float oraw = sr.oraw;
+    float c_xyz[3], c_sc[3], c_op;
+    float4 c_rot;
+    if (PK) {  // the row's 11 accumulated gradients: one 48 B row
+      const float4* grow = reinterpret_cast<const float4*>(o.g_xyz) + 3 * gl;
+      const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2];
+      c_xyz[0] = g0.x; c_xyz[1] = g0.y; c_xyz[2] = g0.z; c_op = g0.w;
+      c_sc[0] = g1.x; c_sc[1] = g1.y; c_sc[2] = g1.z;
+      c_rot = make_float4(g1.w, g2.x, g2.y, g2.z);
+    } else {
+      c_xyz[0] = o.g_xyz[3 * gl]; c_xyz[1] = o.g_xyz[3 * gl + 1]; c_xyz[2] = o.g_xyz[3 * gl + 2];
+      c_sc[0] = o.g_scaling[3 * gl]; c_sc[1] = o.g_scaling[3 * gl + 1]; c_sc[2] = o.g_scaling[3 * gl + 2];
+      c_rot = *reinterpret_cast<const float4*>(o.g_rotation + 4 * gl);
+      c_op = o.g_opacity[gl];
+    }
     float c_mr = 0.f, c_ga = 0.f, c_dn = 0.f;
     if (o.max_radii2D) { c_mr = o.max_radii2D[g]; c_ga = o.grad_accum[g]; c_dn = o.denom[g]; }
     CLMGS_FOR12(CLMGS_DECL_ST)
@@ -250,6 +285,8 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       o.denom[g] = c_dn + 1.f;
     }
     float vm[3] = {0.f, 0.f, 0.f};
+    float n_sc[3] = {0.f, 0.f, 0.f}, n_op = 0.f;
+    float4 n_rot = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vis) {
       const float q[4] = {q4.x, q4.y, q4.z, q4.w};
       const float se[3] = {__expf(s[0]), __expf(s[1]), __expf(s[2])};
@@ -257,12 +294,14 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       const float v_con[3] = {ga.z, ga.w, gb.x};
       float vq[4], vs[3];
       project_bwd(cam, m, q, se, (float)a.width, (float)a.height, a.eps2d, v_m2, 0.f, v_con, vm, vq, vs);
-      o.g_scaling[3 * g] = c_sc[0] + vs[0] * se[0];
-      o.g_scaling[3 * g + 1] = c_sc[1] + vs[1] * se[1];
-      o.g_scaling[3 * g + 2] = c_sc[2] + vs[2] * se[2];
-      *reinterpret_cast<float4*>(o.g_rotation + 4 * g) =
-          make_float4(c_rot.x + vq[0], c_rot.y + vq[1], c_rot.z + vq[2], c_rot.w + vq[3]);
-      o.g_opacity[g] = c_op + go * op * (1.f - op);
+      n_sc[0] = c_sc[0] + vs[0] * se[0]; n_sc[1] = c_sc[1] + vs[1] * se[1]; n_sc[2] = c_sc[2] + vs[2] * se[2];
+      n_rot = make_float4(c_rot.x + vq[0], c_rot.y + vq[1], c_rot.z + vq[2], c_rot.w + vq[3]);
+      n_op = c_op + go * op * (1.f - op);
+      if (!PK) {
+        o.g_scaling[3 * g] = n_sc[0]; o.g_scaling[3 * g + 1] = n_sc[1]; o.g_scaling[3 * g + 2] = n_sc[2];
+        *reinterpret_cast<float4*>(o.g_rotation + 4 * g) = n_rot;
+        o.g_opacity[g] = n_op;
+      }
     }
     if (!live) continue;  // wave-uniform: nothing of this chunk reached the screen
     // ---- SH rows -> LDS; their registers then prefetch the gradient rows to accumulate into
@@ -311,9 +350,16 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
         const float bk = (k < NB) ? B[k] : 0.f;
         row[3 * k] = bk * vc[0]; row[3 * k + 1] = bk * vc[1]; row[3 * k + 2] = bk * vc[2];
       }
-      o.g_xyz[3 * g] = c_xyz[0] + vm[0] + vdx;
-      o.g_xyz[3 * g + 1] = c_xyz[1] + vm[1] + vdy;
-      o.g_xyz[3 * g + 2] = c_xyz[2] + vm[2] + vdz;
+      if (PK) {
+        float4* grow = reinterpret_cast<float4*>(o.g_xyz) + 3 * g;
+        grow[0] = make_float4(c_xyz[0] + vm[0] + vdx, c_xyz[1] + vm[1] + vdy, c_xyz[2] + vm[2] + vdz, n_op);
+        grow[1] = make_float4(n_sc[0], n_sc[1], n_sc[2], n_rot.x);
+        grow[2] = make_float4(n_rot.y, n_rot.z, n_rot.w, 0.f);
+      } else {
+        o.g_xyz[3 * g] = c_xyz[0] + vm[0] + vdx;
+        o.g_xyz[3 * g + 1] = c_xyz[1] + vm[1] + vdy;
+        o.g_xyz[3 * g + 2] = c_xyz[2] + vm[2] + vdz;
+      }
     }
     wave_lds_sync();
 #define CLMGS_X(j)                                                                                  \
@@ -343,6 +389,7 @@ static void fill_args(PreArgs& a, const int64_t* filter, const float* xyz, const
                       float far_plane, float radius_clip) {
   a.filter = filter; a.xyz = xyz; a.opacity_raw = opacity_raw; a.scaling_raw = scaling_raw;
   a.rotation_raw = rotation_raw; a.sh_rows = sh_rows; a.sh_by_filter = sh_by_filter;
+  a.packed_small = (!opacity_raw && !scaling_raw && !rotation_raw) ? 1 : 0;
   for (int i = 0; i < 16; ++i) a.viewmat[i] = viewmat[i];
   for (int i = 0; i < 9; ++i) a.K[i] = K[i];
   for (int i = 0; i < 3; ++i) a.campos[i] = campos[i];
@@ -361,8 +408,10 @@ extern "C" int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, 
                                     float* opacities, void* packed) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
-  CLMGS_CHECK_ARG(xyz && opacity_raw && scaling_raw && rotation_raw && sh_rows && viewmat_host &&
-                  K_host && campos_host && radii && means2d && depths && packed);
+  CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && means2d &&
+                  depths && packed);
+  CLMGS_CHECK_ARG((opacity_raw && scaling_raw && rotation_raw) ||
+                  (!opacity_raw && !scaling_raw && !rotation_raw && (((uintptr_t)xyz & 15) == 0)));
   CLMGS_CHECK_ARG(!conics || (colors && opacities));
   PreArgs a;
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
@@ -371,9 +420,16 @@ extern "C" int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, 
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_FWD(D, O)                                                                        \
-  hipLaunchKernelGGL((preprocess_fwd_kernel<D, O>), dim3(grid), dim3(PP_ROWS), lds,                \
-                     (hipStream_t)stream, V, a, radii, means2d, depths, conics, colors, opacities, \
-                     (float4*)packed)
+  do {                                                                                             \
+    if (a.packed_small)                                                                            \
+      hipLaunchKernelGGL((preprocess_fwd_kernel<D, O, true>), dim3(grid), dim3(PP_ROWS), lds,      \
+                         (hipStream_t)stream, V, a, radii, means2d, depths, conics, colors,        \
+                         opacities, (float4*)packed);                                              \
+    else                                                                                           \
+      hipLaunchKernelGGL((preprocess_fwd_kernel<D, O, false>), dim3(grid), dim3(PP_ROWS), lds,     \
+                         (hipStream_t)stream, V, a, radii, means2d, depths, conics, colors,        \
+                         opacities, (float4*)packed);                                              \
+  } while (0)
   const bool ov = filter != nullptr;  // a filter means (almost) every row is visible
   switch (degree) {
     case 0: if (ov) CLMGS_PRE_FWD(0, true); else CLMGS_PRE_FWD(0, false); break;
@@ -398,20 +454,31 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     float* v_means2d_out, int stats_only_visible) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
-  CLMGS_CHECK_ARG(xyz && opacity_raw && scaling_raw && rotation_raw && sh_rows && viewmat_host &&
-                  K_host && campos_host && radii && packed_grad && g_xyz && g_opacity &&
-                  g_scaling && g_rotation && g_sh_rows);
+  CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && packed_grad &&
+                  g_xyz && g_sh_rows);
+  CLMGS_CHECK_ARG((opacity_raw && scaling_raw && rotation_raw) ||
+                  (!opacity_raw && !scaling_raw && !rotation_raw && (((uintptr_t)xyz & 15) == 0)));
+  const bool pg = !g_opacity && !g_scaling && !g_rotation;
+  CLMGS_CHECK_ARG(pg || (g_opacity && g_scaling && g_rotation));
+  // packed parameters and packed gradients go together (one kernel variant)
+  CLMGS_CHECK_ARG(pg == (!opacity_raw && !scaling_raw && !rotation_raw) && (!pg || (((uintptr_t)g_xyz & 15) == 0)));
   CLMGS_CHECK_ARG(!max_radii2D || (grad_accum && denom));
   PreArgs a;
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
-             v_means2d_out, stats_only_visible};
+             pg ? 1 : 0, v_means2d_out, stats_only_visible};
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_BWD(D, E, W)                                                                    \
-  hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W>), dim3(grid), dim3(PP_ROWS), lds,             \
-                     (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o)
+  do {                                                                                             \
+    if (pg)                                                                                        \
+      hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W, true>), dim3(grid), dim3(PP_ROWS), lds,   \
+                         (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o);         \
+    else                                                                                           \
+      hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W, false>), dim3(grid), dim3(PP_ROWS), lds,  \
+                         (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o);         \
+  } while (0)
   static const int variant = getenv("CLMGS_PRE_VARIANT") ? atoi(getenv("CLMGS_PRE_VARIANT")) : 0;
   switch (degree) {
     case 0: CLMGS_PRE_BWD(0, false, 3); break;

@@ -44,7 +44,7 @@ def _np(a):
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
                      return_event=False, stats_only_visible=False, visibility_out=None,
-                     raster_stream=None):
+                     raster_stream=None, small_packed=None, small_grad=None):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -55,7 +55,10 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     flight on two streams while their read-modify-write accumulations stay ordered.
     `raster_stream`: if given, the two ALU-bound tile kernels are enqueued there (event-chained
     with the current stream) so that a shared low-priority stream carries all cameras' tile work
-    while the latency-bound kernels of the other camera get CU slots first."""
+    while the latency-bound kernels of the other camera get CU slots first.
+    `small_packed` / `small_grad`: the [N,12] mirror of the four small parameter tensors and the
+    packed [N,12] gradient table (GaussianModelCLMOffload.small_packed / small_grad); the kernels
+    then gather one 48 B row per Gaussian and accumulate into one, instead of four pieces each."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -71,8 +74,16 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     packed = torch.empty((V, 16), dtype=F32, device=dev)
     filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
     s = stream()
+    if small_packed is not None:
+        assert small_grad is not None
+        small_in = (dptr(small_packed, F32), None, None, None)
+        small_out = (dptr(small_grad, F32), None, None, None)
+    else:
+        small_in = (dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32))
+        small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
+                     dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
     check(L.clmgs_preprocess_fwd(
-        s, V, dptr(filt, torch.int64, True), dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32),
+        s, V, dptr(filt, torch.int64, True), *small_in,
         dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
         dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
@@ -127,11 +138,9 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     if visibility_out is not None:
         visibility_out |= (radii.reshape(-1) > 0)
     check(L.clmgs_preprocess_bwd(
-        s, V, dptr(filt, torch.int64, True), dptr(xyz), dptr(opa), dptr(sca), dptr(rot), dptr(sh_rows, F32, allow_host=True),
+        s, V, dptr(filt, torch.int64, True), *small_in, dptr(sh_rows, F32, allow_host=True),
         int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
-        dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
-        dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32),
-        dptr(g_sh_rows, F32, allow_host=True),
+        *small_out, dptr(g_sh_rows, F32, allow_host=True),
         dptr(gaussians.max_radii2D if stats else None, F32, True),
         dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
         dptr(gaussians.denom if stats else None, F32, True), None, int(bool(stats_only_visible))))

@@ -103,6 +103,45 @@ class UnifiedAdam(torch.optim.Optimizer):
                       float(grad_scale), True)
         self.state = self.gpu_adam.state | self.cpu_adam.state
 
+    @torch.no_grad()
+    def gpu_step_packed(self, packed_p, packed_g, grad_scale=1.0):
+        """Dense Adam of the four GPU-resident tensors from the packed [N,12] gradient table
+        (clmgs_adam_small_packed): updates p / exp_avg / exp_avg_sq of every group in place,
+        refreshes the packed parameter mirror and zeroes the gradient table, all in one pass."""
+        import ctypes
+        from . import _lib
+        assert not isinstance(self.gpu_adam, SelectiveAdam)
+        groups = {g["name"]: g for g in self.gpu_adam.param_groups}
+        order = [groups[n] for n in ("xyz", "opacity", "scaling", "rotation")]
+        ps, ms, vs, lrs = [], [], [], []
+        step = None
+        cache = self.__dict__.setdefault("_gpu_steps", {})
+        for group in order:
+            p = group["params"][0]
+            st = self.gpu_adam.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if id(st["step"]) not in cache:
+                cache.clear() if len(cache) > 64 else None
+                cache[id(st["step"])] = int(st["step"].item())
+            cache[id(st["step"])] += 1
+            st["step"] += 1
+            step = cache[id(st["step"])] if step is None else step
+            assert cache[id(st["step"])] == step, "the four groups step together"
+            assert p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()
+            ps.append(p.data_ptr()); ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
+            lrs.append(float(group["lr"]))
+        g0 = order[0]
+        arr = lambda xs: (ctypes.c_void_p * 4)(*xs)
+        L = _lib.lib()
+        _lib.check(L.clmgs_adam_small_packed(
+            _lib.stream(), int(packed_p.shape[0]), arr(ps), arr(ms), arr(vs), (ctypes.c_double * 4)(*lrs),
+            _lib.dptr(packed_p), _lib.dptr(packed_g), float(g0["betas"][0]), float(g0["betas"][1]),
+            float(g0["eps"]), int(step), 1, float(grad_scale)))
+        self.state = self.gpu_adam.state | self.cpu_adam.state
+
     def get_all_states(self):
         return [self.gpu_adam.state, self.cpu_adam.state]
 

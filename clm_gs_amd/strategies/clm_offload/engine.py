@@ -287,9 +287,16 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             side_event.record(comm_stream)
         untouched_rows.record_stream(comm_stream)
 
-    _zero_small_grads(gaussians)
-    losses = []
     fused = getattr(args, "fused_front_end", True)
+    # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
+    use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
+                  and not args.stop_update_param)
+    small_pk = small_gk = None
+    if use_packed:
+        small_pk, small_gk = gaussians.small_packed(), gaussians.small_grad()
+    else:
+        _zero_small_grads(gaussians)
+    losses = []
     if fused:
         # Two cameras in flight on two streams: the ALU-bound tile kernels of one overlap with the
         # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
@@ -333,7 +340,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                     gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
                     background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
                     return_event=True,
-                    raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None)
+                    raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
+                    small_packed=small_pk, small_grad=small_gk)
             losses.append(loss)
         for ln in lanes:
             if ln is not default_stream:
@@ -352,11 +360,18 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
 
     if dp.world_size() > 1:  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
-        dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
-                                  gaussians._scaling.grad, gaussians._rotation.grad], average=False)
+        if use_packed:
+            dp.allreduce_small_grads([small_gk], average=False)  # one 48 B/Gaussian collective
+        else:
+            dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
+                                      gaussians._scaling.grad, gaussians._rotation.grad], average=False)
         dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
-    _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
-                   grad_div=bsz * dp.world_size())
+    if use_packed:
+        gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()))
+    else:
+        _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
+                       grad_div=bsz * dp.world_size())
+        gaussians.invalidate_small_packed()
     if not args.stop_update_param:
         row_update(touched_rows)
         if lazy:
@@ -472,6 +487,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     assert args.lr_scale_mode == "sqrt", "Overlap CPUAdam only supports sqrt lr scaling"
     assert not args.stop_update_param, "Overlap CPUAdam does not support stop_update_param"
     _gpu_adam_step(gaussians, args, visibility_mask)
+    gaussians.invalidate_small_packed()
     worker.join()
     torch.cuda.synchronize()
     del keep_alive

@@ -102,6 +102,38 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if (not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True):
             self._row_last_step = torch.zeros((cap,), dtype=torch.int32, device="cuda")
 
+    # ------------------------------------------- packed mirror of the small attributes
+    def _small_tensors(self):
+        return (self._xyz, self._opacity, self._scaling, self._rotation)
+
+    def small_packed(self):
+        """[N,12] mirror  xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad  of the four GPU-resident
+        parameter tensors for the per-camera gathers (one 48 B row instead of four scattered
+        pieces).  The parameter tensors stay the source of truth: the mirror is rebuilt whenever
+        one of them was replaced or modified by torch (data_ptr / version), and refreshed in place
+        by the packed dense Adam (UnifiedAdam.gpu_step_packed)."""
+        from ... import _lib
+        key = tuple((p.data_ptr(), p._version) for p in self._small_tensors())
+        n = self._xyz.shape[0]
+        pk = getattr(self, "_small_pk", None)
+        if pk is None or pk.shape[0] != n or getattr(self, "_small_key", None) != key:
+            pk = torch.empty((n, 12), dtype=torch.float32, device=self._xyz.device)
+            t = [p.detach().contiguous() for p in self._small_tensors()]
+            _lib.check(_lib.lib().clmgs_pack_small(_lib.stream(), n, *[_lib.dptr(x) for x in t], _lib.dptr(pk)))
+            self._small_pk, self._small_key = pk, key
+        return pk
+
+    def small_grad(self):
+        """Persistent zero-initialised [N,12] gradient table (the packed Adam zeroes what it eats)."""
+        n = self._xyz.shape[0]
+        g = getattr(self, "_small_gk", None)
+        if g is None or g.shape[0] != n:
+            g = self._small_gk = torch.zeros((n, 12), dtype=torch.float32, device=self._xyz.device)
+        return g
+
+    def invalidate_small_packed(self):
+        self._small_key = None
+
     # ---------------------------------------------------- deferred dense Adam
     @property
     def lazy_rows(self):

@@ -152,6 +152,11 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * g_rotation[N,4] (raw-parameter gradients) and g_sh_rows (indexed like sh_rows), and, if
  * max_radii2D != NULL, updates the densification statistics of every filter row (or, with
  * stats_only_visible, of the rows with radius > 0: densification.py:105-147). */
+/* Packed small attributes: opacity_raw == scaling_raw == rotation_raw == NULL means `xyz` is the
+ * 16 B-aligned [N,12] table  xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad  (one 48 B row per
+ * Gaussian instead of four scattered pieces, each of which costs a 64 B line); in the backward the
+ * gradient outputs follow the same convention (g_opacity == g_scaling == g_rotation == NULL:
+ * g_xyz is the packed [N,12] gradient table), and packed parameters go with packed gradients. */
 int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,
@@ -238,6 +243,17 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
  * operations as clmgs_adam_rows with g == NULL, bias corrections from a running product).  The
  * caller then sets last_step[rows] = to_step.  Steps older than max_replay are folded into the
  * moments analytically (their parameter increments are below float resolution). */
+/* The packed [N,12] mirror of the four GPU-resident parameter tensors, and their dense Adam when the
+ * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
+ * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a
+ * host array of their 4 learning rates.  One pass: grad * grad_scale -> Adam (torch.optim.Adam's
+ * bias-corrected formula) -> p / m / v written back, mirror row refreshed, gradient row zeroed. */
+int clmgs_pack_small(void* stream, int64_t n, const float* xyz, const float* opacity,
+                     const float* scaling, const float* rotation, void* packed_p);
+int clmgs_adam_small_packed(void* stream, int64_t n, float* const* params, float* const* exp_avg,
+                            float* const* exp_avg_sq, const double* lr4, void* packed_p,
+                            void* packed_g, double beta1, double beta2, double eps, int step,
+                            int bias_correction, float grad_scale);
 int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v, const int32_t* last_step,
                         const void* rows, int idx_is_64, int64_t n_rows, int cols,
                         const float* col_lr, double beta1, double beta2, double eps, int to_step,
