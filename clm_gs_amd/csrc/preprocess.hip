@@ -202,6 +202,7 @@ struct PreGrads {
   float* grad_accum;     // [N]
   float* denom;          // [N]
   int packed_grads;      // 1: g_xyz is the [N,12] gradient table laid out like the packed parameters
+  int packed_stats;      // 1: max_radii2D is a [N,4] table  max radius | grad accum | count | pad
   float* v_means2d_out;  // [V,2] or NULL: copy of the screen-space gradient (API parity)
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
 };
@@ -259,7 +260,14 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       c_op = o.g_opacity[gl];
     }
     float c_mr = 0.f, c_ga = 0.f, c_dn = 0.f;
-    if (o.max_radii2D) { c_mr = o.max_radii2D[g]; c_ga = o.grad_accum[g]; c_dn = o.denom[g]; }
+    if (o.max_radii2D) {
+      if (o.packed_stats) {  // one 16 B row instead of three 4 B pieces (= three 64 B lines)
+        const float4 st4 = reinterpret_cast<const float4*>(o.max_radii2D)[g];
+        c_mr = st4.x; c_ga = st4.y; c_dn = st4.z;
+      } else {
+        c_mr = o.max_radii2D[g]; c_ga = o.grad_accum[g]; c_dn = o.denom[g];
+      }
+    }
     CLMGS_FOR12(CLMGS_DECL_ST)
 #define CLMGS_LOAD_SH(j)                                                                            \
   if constexpr (j < NF4) {                                                                          \
@@ -280,9 +288,14 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     if (stat) {  // default: every filter row, as gsplat_add_densification_stats_exact_filter;
       // only_visible = the no_offload mask form
       const float gx = v_m2[0] * (0.5f * a.width), gy = v_m2[1] * (0.5f * a.height);
-      o.max_radii2D[g] = fmaxf(c_mr, (float)radius);
-      o.grad_accum[g] = c_ga + sqrtf(gx * gx + gy * gy);
-      o.denom[g] = c_dn + 1.f;
+      if (o.packed_stats) {
+        reinterpret_cast<float4*>(o.max_radii2D)[g] =
+            make_float4(fmaxf(c_mr, (float)radius), c_ga + sqrtf(gx * gx + gy * gy), c_dn + 1.f, 0.f);
+      } else {
+        o.max_radii2D[g] = fmaxf(c_mr, (float)radius);
+        o.grad_accum[g] = c_ga + sqrtf(gx * gx + gy * gy);
+        o.denom[g] = c_dn + 1.f;
+      }
     }
     float vm[3] = {0.f, 0.f, 0.f};
     float n_sc[3] = {0.f, 0.f, 0.f}, n_op = 0.f;
@@ -462,12 +475,14 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   CLMGS_CHECK_ARG(pg || (g_opacity && g_scaling && g_rotation));
   // packed parameters and packed gradients go together (one kernel variant)
   CLMGS_CHECK_ARG(pg == (!opacity_raw && !scaling_raw && !rotation_raw) && (!pg || (((uintptr_t)g_xyz & 15) == 0)));
-  CLMGS_CHECK_ARG(!max_radii2D || (grad_accum && denom));
+  const bool ps = max_radii2D && !grad_accum && !denom;  // [N,4] statistics table
+  CLMGS_CHECK_ARG(!max_radii2D || ps || (grad_accum && denom));
+  CLMGS_CHECK_ARG(!ps || (((uintptr_t)max_radii2D & 15) == 0));
   PreArgs a;
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
-             pg ? 1 : 0, v_means2d_out, stats_only_visible};
+             pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible};
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_BWD(D, E, W)                                                                    \

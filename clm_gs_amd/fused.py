@@ -44,7 +44,7 @@ def _np(a):
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
                      return_event=False, stats_only_visible=False, visibility_out=None,
-                     raster_stream=None, small_packed=None, small_grad=None):
+                     raster_stream=None, small_packed=None, small_grad=None, stats_delta=None):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -133,6 +133,12 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         cur.wait_stream(raster_stream)
     stats = update_stats and (not args.disable_auto_densification) and \
         utils.get_cur_iter() <= args.densify_until_iter
+    if stats and stats_delta is not None:  # [N,4] delta table (see GaussianModelCLMOffload.stats_delta)
+        stat_ptrs = (dptr(stats_delta, F32), None, None)
+    else:
+        stat_ptrs = (dptr(gaussians.max_radii2D if stats else None, F32, True),
+                     dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
+                     dptr(gaussians.denom if stats else None, F32, True))
     if accumulate_after is not None:
         torch.cuda.current_stream().wait_event(accumulate_after)
     if visibility_out is not None:
@@ -141,9 +147,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         s, V, dptr(filt, torch.int64, True), *small_in, dptr(sh_rows, F32, allow_host=True),
         int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
         *small_out, dptr(g_sh_rows, F32, allow_host=True),
-        dptr(gaussians.max_radii2D if stats else None, F32, True),
-        dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
-        dptr(gaussians.denom if stats else None, F32, True), None, int(bool(stats_only_visible))))
+        *stat_ptrs, None, int(bool(stats_only_visible))))
     if keep is not None:
         keep += [packed, packed_grad, radii, filt, partials, emit_slot, row_start, row_cnt]
     if return_event:

@@ -291,9 +291,12 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
     use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
                   and not args.stop_update_param)
-    small_pk = small_gk = None
+    small_pk = small_gk = stats_d = None
     if use_packed:
         small_pk, small_gk = gaussians.small_packed(), gaussians.small_grad()
+        if (getattr(args, "packed_stats", True) and (not args.disable_auto_densification)
+                and utils.get_cur_iter() <= args.densify_until_iter):
+            stats_d = gaussians.stats_delta()
     else:
         _zero_small_grads(gaussians)
     losses = []
@@ -341,7 +344,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                     background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
                     return_event=True,
                     raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
-                    small_packed=small_pk, small_grad=small_gk)
+                    small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d)
             losses.append(loss)
         for ln in lanes:
             if ln is not default_stream:

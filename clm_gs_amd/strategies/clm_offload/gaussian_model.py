@@ -134,6 +134,40 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def invalidate_small_packed(self):
         self._small_key = None
 
+    # ---- densification statistics: the fused path accumulates them in ONE [N,4] delta table
+    # (max radius | grad accum | count | pad); the three model tensors are brought up to date
+    # lazily, whenever anybody reads them (every 100 images for densification, capture, DP).
+    def stats_delta(self):
+        n = self._xyz.shape[0]
+        d = getattr(self, "_stats_d", None)
+        if d is None or d.shape[0] != n:
+            self.merge_stats()
+            d = self._stats_d = torch.zeros((n, 4), dtype=torch.float32, device=self._xyz.device)
+        self._stats_dirty = True
+        return d
+
+    def merge_stats(self):
+        d = getattr(self, "_stats_d", None)
+        if d is None or not getattr(self, "_stats_dirty", False):
+            return
+        self._stats_dirty = False
+        if self._max_radii2D.shape[0] == d.shape[0]:
+            self._max_radii2D = torch.maximum(self._max_radii2D, d[:, 0])
+            self._xyz_gradient_accum = self._xyz_gradient_accum + d[:, 1:2]
+            self._denom = self._denom + d[:, 2:3]
+        d.zero_()
+
+    def _stat_get(self, name):
+        self.merge_stats()
+        return getattr(self, name)
+
+    max_radii2D = property(lambda self: self._stat_get("_max_radii2D"),
+                           lambda self, v: (self.merge_stats(), setattr(self, "_max_radii2D", v))[0])
+    xyz_gradient_accum = property(lambda self: self._stat_get("_xyz_gradient_accum"),
+                                  lambda self, v: (self.merge_stats(), setattr(self, "_xyz_gradient_accum", v))[0])
+    denom = property(lambda self: self._stat_get("_denom"),
+                     lambda self, v: (self.merge_stats(), setattr(self, "_denom", v))[0])
+
     # ---------------------------------------------------- deferred dense Adam
     @property
     def lazy_rows(self):

@@ -156,7 +156,9 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * 16 B-aligned [N,12] table  xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad  (one 48 B row per
  * Gaussian instead of four scattered pieces, each of which costs a 64 B line); in the backward the
  * gradient outputs follow the same convention (g_opacity == g_scaling == g_rotation == NULL:
- * g_xyz is the packed [N,12] gradient table), and packed parameters go with packed gradients. */
+ * g_xyz is the packed [N,12] gradient table), and packed parameters go with packed gradients.
+ * Statistics: grad_accum == denom == NULL with max_radii2D != NULL means max_radii2D is a 16 B-aligned
+ * [N,4] table  max radius | grad accum | count | pad  (one row instead of three scattered floats). */
 int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,

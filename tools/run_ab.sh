@@ -1,9 +1,6 @@
 cd /root/repo
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -12
-for pk in false true; do
-echo "== packed_small $pk"
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt overlap_cameras=false --opt packed_small=$pk > gpurun_out/pk_$pk.log 2>&1
-python profiles/show_bench.py gpurun_out/pk_$pk.log 2>&1 | grep "img/s\|preprocess\|adam"
+for ps in true false true false; do
+echo "== packed_stats $ps"
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt overlap_cameras=false --opt packed_stats=$ps > gpurun_out/ab0.log 2>&1
+python profiles/show_bench.py gpurun_out/ab0.log 2>&1 | grep "img/s\|preprocess_bwd" | cut -c1-90
 done
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/ab1.log 2>&1
-python profiles/show_bench.py gpurun_out/ab1.log 2>&1 | head -1
