@@ -17,6 +17,12 @@
 
 namespace clmgs {
 
+#ifndef CLMGS_PRE_PREFETCH_GSH
+#define CLMGS_PRE_PREFETCH_GSH 0  // 1: prefetch the SH gradient rows across the SH VJP (+48 VGPRs; measured slower)
+#endif
+#ifndef CLMGS_PRE_SCHED_BARRIER
+#define CLMGS_PRE_SCHED_BARRIER 0
+#endif
 constexpr int PP_ROWS = 64;   // one wavefront owns a chunk of 64 rows; no workgroup barriers
 constexpr int PP_PITCH = 52;  // floats per LDS row (see sh.hip)
 
@@ -40,7 +46,12 @@ struct PreArgs {
 // above the backend's promote-to-vector budget at this occupancy and would live in scratch.
 #define CLMGS_FOR12(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
 #define CLMGS_DECL_ST(j) float4 st##j = make_float4(0.f, 0.f, 0.f, 0.f);
-#define CLMGS_ELEM(j) const int e = t + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
+// (row, piece) of staging element j of this lane.  `tl` is a LAUNDERED copy of the lane id made at
+// the top of every staging phase (CLMGS_LAUNDER_LANE): the index math (row, piece, LDS offset,
+// 64-bit row mask, 64-bit base pointers: ~7 values x 12 elements) is loop-invariant, and LICM would
+// otherwise keep all ~84 of them in VGPRs across the whole chunk loop (measured: 256 VGPRs + spills).
+#define CLMGS_ELEM(j) const int e = tl + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
+#define CLMGS_LAUNDER_LANE int tl = t; asm volatile("" : "+v"(tl));
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -62,6 +73,22 @@ __device__ __forceinline__ SmallRow load_small(const PreArgs& a, int64_t g) {
     r.s[0] = a.scaling_raw[3 * g]; r.s[1] = a.scaling_raw[3 * g + 1]; r.s[2] = a.scaling_raw[3 * g + 2];
     r.oraw = a.opacity_raw[g];
   }
+  return r;
+}
+
+// Camera constants live in SGPRs.  Without this, LICM hoists every camera-derived subexpression of
+// the projection (limits, reciprocals, products of view-matrix entries ...) out of the chunk loop
+// into ~80 long-lived VGPRs -- measured: 256 VGPRs plus scratch spills.  Laundering the SGPR copies
+// inside the loop makes those subexpressions loop-variant: they are recomputed per chunk (a few
+// dozen VALU) in short-lived registers.
+__device__ __forceinline__ Cam launder_cam(const Cam& c) {
+  Cam r = c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) asm volatile("" : "+s"(r.R[i]));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) asm volatile("" : "+s"(r.t[i]));
+  asm volatile("" : "+s"(r.fx)); asm volatile("" : "+s"(r.fy));
+  asm volatile("" : "+s"(r.cx)); asm volatile("" : "+s"(r.cy));
   return r;
 }
 
@@ -120,7 +147,9 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
     const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, r) : (int64_t)min(base + r, V - 1); \
     st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
   }
+      { CLMGS_LAUNDER_LANE
       CLMGS_FOR12(CLMGS_X)
+      }
 #undef CLMGS_X
     }
     {  // row id of this wave's next chunk
@@ -145,7 +174,9 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
     CLMGS_ELEM(j)                                                                                   \
     *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) = st##j;                                 \
   }
+      { CLMGS_LAUNDER_LANE
       CLMGS_FOR12(CLMGS_X)
+      }
 #undef CLMGS_X
     } else {
       const unsigned long long live = __ballot(p.radius > 0);
@@ -276,7 +307,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);        \
     st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
   }
-    if (EARLY) { CLMGS_FOR12(CLMGS_LOAD_SH) }
+    if (EARLY) { CLMGS_LAUNDER_LANE CLMGS_FOR12(CLMGS_LOAD_SH) }
     {
       const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
       my_row = -1; my_radius = 0;
@@ -306,7 +337,8 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       const float op = sigmoidf(oraw);
       const float v_con[3] = {ga.z, ga.w, gb.x};
       float vq[4], vs[3];
-      project_bwd(cam, m, q, se, (float)a.width, (float)a.height, a.eps2d, v_m2, 0.f, v_con, vm, vq, vs);
+      const Cam camL = launder_cam(cam);
+      project_bwd(camL, m, q, se, (float)a.width, (float)a.height, a.eps2d, v_m2, 0.f, v_con, vm, vq, vs);
       n_sc[0] = c_sc[0] + vs[0] * se[0]; n_sc[1] = c_sc[1] + vs[1] * se[1]; n_sc[2] = c_sc[2] + vs[2] * se[2];
       n_rot = make_float4(c_rot.x + vq[0], c_rot.y + vq[1], c_rot.z + vq[2], c_rot.w + vq[3]);
       n_op = c_op + go * op * (1.f - op);
@@ -318,7 +350,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     }
     if (!live) continue;  // wave-uniform: nothing of this chunk reached the screen
     // ---- SH rows -> LDS; their registers then prefetch the gradient rows to accumulate into
-    if (!EARLY) { CLMGS_FOR12(CLMGS_LOAD_SH) }  // register-lean variant: SH rows requested only now
+    if (!EARLY) { CLMGS_LAUNDER_LANE CLMGS_FOR12(CLMGS_LOAD_SH) }  // register-lean variant: SH rows requested only now
 #undef CLMGS_LOAD_SH
     wave_lds_sync();  // the previous chunk's LDS rows are consumed
 #define CLMGS_X(j)                                                                                  \
@@ -327,11 +359,15 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) = st##j;                                 \
     const int rr = ((live >> r) & 1ull) ? r : first;                                                \
     const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);    \
-    st##j = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);                   \
+    if (CLMGS_PRE_PREFETCH_GSH)                                                                     \
+      st##j = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);                 \
   }
+    { CLMGS_LAUNDER_LANE
     CLMGS_FOR12(CLMGS_X)
+    }
 #undef CLMGS_X
     wave_lds_sync();
+    if (CLMGS_PRE_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
     if (vis) {
       float* row = lds + t * PP_PITCH;
       // recompute the pre-clamp colour for the clamp mask, then the VJP
@@ -340,21 +376,33 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       const float x = dx * inv, y = dy * inv, z = dz * inv;
       float B[16];
       sh_basis(DEG, x, y, z, B);
-      float pr = 0.f, pg = 0.f, pb = 0.f;
+      // ONE pass over the row, band by band: colour P_c = sum_k B_k r_kc and, per channel, the
+      // un-clamped direction cotangent U_c = sum_k r_kc grad B_k; the clamp mask is applied to
+      // the three U_c afterwards.  Each coefficient is consumed as soon as it is read (the
+      // two-pass form kept all 48 row values + 64 basis values live: 256 VGPRs and spills).
+      float P[3] = {0.f, 0.f, 0.f};
+      float U[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      {
+        float Bx[16], By[16], Bz[16];
+        if (DEG > 0) sh_basis_grad(DEG, x, y, z, Bx, By, Bz);
 #pragma unroll
-      for (int k = 0; k < NB; ++k) { pr += B[k] * row[3 * k]; pg += B[k] * row[3 * k + 1]; pb += B[k] * row[3 * k + 2]; }
-      const float vc[3] = {(pr + 0.5f > 0.f) ? gb.y : 0.f, (pg + 0.5f > 0.f) ? gb.z : 0.f,
-                           (pb + 0.5f > 0.f) ? gb.w : 0.f};
+        for (int k = 0; k < NB; ++k) {
+          if (k == 1 || k == 4 || k == 9) __builtin_amdgcn_sched_barrier(0);  // band boundary
+          const float rk[3] = {row[3 * k], row[3 * k + 1], row[3 * k + 2]};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            P[c] += B[k] * rk[c];
+            if (DEG > 0 && k > 0) { U[c][0] += rk[c] * Bx[k]; U[c][1] += rk[c] * By[k]; U[c][2] += rk[c] * Bz[k]; }
+          }
+        }
+      }
+      const float vc[3] = {(P[0] + 0.5f > 0.f) ? gb.y : 0.f, (P[1] + 0.5f > 0.f) ? gb.z : 0.f,
+                           (P[2] + 0.5f > 0.f) ? gb.w : 0.f};
       float vdx = 0.f, vdy = 0.f, vdz = 0.f;
       if (DEG > 0) {
-        float Bx[16], By[16], Bz[16];
-        sh_basis_grad(DEG, x, y, z, Bx, By, Bz);
-        float ux = 0.f, uy = 0.f, uz = 0.f;
-#pragma unroll
-        for (int k = 1; k < NB; ++k) {
-          const float vB = row[3 * k] * vc[0] + row[3 * k + 1] * vc[1] + row[3 * k + 2] * vc[2];
-          ux += vB * Bx[k]; uy += vB * By[k]; uz += vB * Bz[k];
-        }
+        const float ux = vc[0] * U[0][0] + vc[1] * U[1][0] + vc[2] * U[2][0];
+        const float uy = vc[0] * U[0][1] + vc[1] * U[1][1] + vc[2] * U[2][1];
+        const float uz = vc[0] * U[0][2] + vc[1] * U[1][2] + vc[2] * U[2][2];
         const float dot = ux * x + uy * y + uz * z;
         vdx = (ux - dot * x) * inv; vdy = (uy - dot * y) * inv; vdz = (uz - dot * z) * inv;
       }
@@ -375,18 +423,26 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       }
     }
     wave_lds_sync();
+    // launder the row id: the addresses below are RE-computed here instead of 12 64-bit
+    // pointers staying live across the SH VJP
+    int g_l = (int)g;
+    asm volatile("" : "+v"(g_l));
 #define CLMGS_X(j)                                                                                  \
   if constexpr (j < NF4) {                                                                          \
     CLMGS_ELEM(j)                                                                                   \
-    const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl((int)g, r) : (int64_t)(base + r);      \
+    const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl(g_l, r) : (int64_t)(base + r);         \
     if ((live >> r) & 1ull) {                                                                       \
       const float4 v = *reinterpret_cast<const float4*>(lds + r * PP_PITCH + 4 * k);                \
-      float4 c = st##j;                                                                             \
+      float4 c = CLMGS_PRE_PREFETCH_GSH                                                             \
+                     ? st##j                                                                        \
+                     : *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);        \
       c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;                                               \
       *reinterpret_cast<float4*>(o.g_sh_rows + dst_row * 48 + 4 * k) = c;                           \
     }                                                                                               \
   }
+    { CLMGS_LAUNDER_LANE
     CLMGS_FOR12(CLMGS_X)
+    }
 #undef CLMGS_X
   }
 }
