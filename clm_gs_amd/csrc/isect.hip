@@ -185,52 +185,64 @@ extern "C" int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t
 // ======================================================================================
 namespace clmgs {
 
+// Tile box of a row packed in one word (x0 | y0 << 16 | x1 << 32 | y1 << 48; tile counts < 65536).
+__device__ __forceinline__ unsigned long long pack_box(const TileBox& b) {
+  return (unsigned long long)b.x0 | ((unsigned long long)b.y0 << 16) |
+         ((unsigned long long)b.x1 << 32) | ((unsigned long long)b.y1 << 48);
+}
+
+// Row order (coalesced): depth key, identity payload and the row's tile box -- the only place the
+// means / radii are read; count and emit then work from 8 B boxes (one gather in depth order,
+// afterwards sequential) instead of re-gathering two arrays each.
 __global__ void __launch_bounds__(256)
 isect2_keys_kernel(int V, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                   uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                   const float* __restrict__ means2d, float tile_size, int tile_w, int tile_h,
+                   uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                   unsigned long long* __restrict__ box_by_row) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-    keys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
-    vals[i] = i;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-isect2_count_kernel(int V, const int32_t* __restrict__ order, const float* __restrict__ means2d,
-                    const int32_t* __restrict__ radii, float tile_size, int tile_w, int tile_h,
-                    int64_t* __restrict__ cum) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
-    const int i = order[j];
-    int cnt = 0;
     const int r = radii[i];
+    keys[i] = r > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+    vals[i] = i;
+    unsigned long long b = 0ull;
     if (r > 0) {
       const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
-      const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
-      cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
+      b = pack_box(tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h));
     }
-    cum[j] = cnt;
+    box_by_row[i] = b;
   }
 }
 
-// vals2 != NULL ("slot mode"): the sort payload is the pair (row id, EMIT index p);
-// row_start/row_cnt give every row its contiguous emit range.  The backward tile
-// kernel then stores its per-(row, tile) partial gradients at p with plain stores and a per-row
-// pass sums the contiguous range: no float atomics, deterministic.
 __global__ void __launch_bounds__(256)
-isect2_emit_kernel(int V, const int32_t* __restrict__ order, const float* __restrict__ means2d,
-                   const int32_t* __restrict__ radii, const int64_t* __restrict__ cum,
-                   float tile_size, int tile_w, int tile_h, uint32_t* __restrict__ tkeys,
-                   int32_t* __restrict__ vals, int2* __restrict__ vals2,
-                   int32_t* __restrict__ row_start, int32_t* __restrict__ row_cnt) {
+isect2_count_kernel(int V, const int32_t* __restrict__ order,
+                    const unsigned long long* __restrict__ box_by_row,
+                    unsigned long long* __restrict__ box_by_rank, int64_t* __restrict__ cum) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
+    const unsigned long long b = box_by_row[order[j]];
+    const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
+    const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
+    box_by_rank[j] = b;
+    cum[j] = (int64_t)(x1 - x0) * (y1 - y0);
+  }
+}
+
+// vals2 != NULL ("slot mode"): the sort payload is the pair (row id, EMIT index p).  A row's
+// intersections are emitted contiguously (emit range of rank j = [cum[j-1], cum[j])): the backward
+// tile kernel stores its per-(row, tile) partial gradients at p with plain stores and a pass in
+// rank order sums each contiguous range: no float atomics, deterministic.
+__global__ void __launch_bounds__(256)
+isect2_emit_kernel(int V, const int32_t* __restrict__ order,
+                   const unsigned long long* __restrict__ box_by_rank,
+                   const int64_t* __restrict__ cum, int tile_w, uint32_t* __restrict__ tkeys,
+                   int32_t* __restrict__ vals, int2* __restrict__ vals2) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
+    const unsigned long long b = box_by_rank[j];
+    if (b == 0ull) continue;
+    const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
+    const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
     const int i = order[j];
-    const int r = radii[i];
     int64_t cur = (j == 0) ? 0 : cum[j - 1];
-    if (row_start) { row_start[i] = (int32_t)cur; row_cnt[i] = (int32_t)(cum[j] - cur); }
-    if (r <= 0) continue;
-    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
-    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
-    for (int ty = b.y0; ty < b.y1; ++ty)
-      for (int tx = b.x0; tx < b.x1; ++tx) {
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx) {
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
         if (vals2) vals2[cur] = make_int2(i, (int)cur);
         else vals[cur] = i;
@@ -268,17 +280,21 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
 
 extern "C" size_t clmgs_isect2_order_temp_bytes(int V) {
   if (V <= 0) return 256;
-  return 4 * align_up((size_t)V * 4, 256) + radix_table_bytes(V) + scan_scratch_bytes(V) + 256;
+  return 4 * align_up((size_t)V * 4, 256) + align_up((size_t)V * 8, 256) + radix_table_bytes(V) +
+         scan_scratch_bytes(V) + 256;
 }
 
-// order[V] i32 (rows by depth, culled last), cum[V] i64 (inclusive tile counts in that order).
+// order[V] i32 (rows by depth, culled last), cum[V] i64 (inclusive tile counts in that order),
+// boxes[V] u64 (packed tile box of every rank, 0 = culled; input of clmgs_isect2_emit_sort).
 extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2d,
                                         const int32_t* radii, const float* depths, int tile_size,
                                         int tile_width, int tile_height, int32_t* order,
-                                        int64_t* cum, void* temp, size_t temp_bytes) {
+                                        int64_t* cum, uint64_t* boxes, void* temp,
+                                        size_t temp_bytes) {
   CLMGS_CHECK_ARG(V >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
+  CLMGS_CHECK_ARG(tile_width < 65536 && tile_height < 65536);
   if (V == 0) return 0;
-  CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && temp);
+  CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && boxes && temp);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_order_temp_bytes(V));
   hipStream_t s = (hipStream_t)stream;
   char* base = (char*)temp;
@@ -286,16 +302,18 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
   int32_t* v_a = (int32_t*)base; base += align_up((size_t)V * 4, 256);
   int32_t* v_b = (int32_t*)base; base += align_up((size_t)V * 4, 256);
+  unsigned long long* box_by_row = (unsigned long long*)base; base += align_up((size_t)V * 8, 256);
   uint32_t* table = (uint32_t*)base; base += radix_table_bytes(V);
   int64_t* scan_tmp = (int64_t*)base;
   const int grid = min(ceil_div(V, 256), 256 * 16);
-  hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, k_a, v_a);
+  hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, means2d,
+                     (float)tile_size, tile_width, tile_height, k_a, v_a, box_by_row);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
   if (rc) return rc;
-  hipLaunchKernelGGL(isect2_count_kernel, dim3(grid), dim3(256), 0, s, V, order, means2d, radii,
-                     (float)tile_size, tile_width, tile_height, cum);
+  hipLaunchKernelGGL(isect2_count_kernel, dim3(grid), dim3(256), 0, s, V, order, box_by_row,
+                     (unsigned long long*)boxes, cum);
   CLMGS_LAUNCH_CHECK();
   return inclusive_scan_i64(s, V, cum, scan_tmp);
 }
@@ -306,30 +324,22 @@ extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
 }
 
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
-// isect_ids[I] i64 optional (NULL to skip).  emit_slot[I] / row_start[V] / row_cnt[V] optional
-// (all or none): the emit index of every sorted intersection and each row's emit range, consumed
-// by clmgs_rasterize_bwd's atomic-free accumulation.
-extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* means2d,
-                                      const int32_t* radii, const float* depths,
-                                      const int32_t* order, const int64_t* cum, int tile_size,
-                                      int tile_width, int tile_height, int32_t* flatten_ids,
-                                      int32_t* offsets, int64_t* isect_ids, int32_t* emit_slot,
-                                      int32_t* row_start, int32_t* row_cnt, void* temp,
-                                      size_t temp_bytes) {
+// isect_ids[I] i64 optional (NULL to skip).  emit_slot[I] optional: the emit index of every sorted
+// intersection, consumed (with order / cum) by clmgs_rasterize_bwd's atomic-free accumulation.
+extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
+                                      const int32_t* order, const int64_t* cum,
+                                      const uint64_t* boxes, int tile_width, int tile_height,
+                                      int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
+                                      int32_t* emit_slot, void* temp, size_t temp_bytes) {
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
-  CLMGS_CHECK_ARG((emit_slot && row_start && row_cnt) || (!emit_slot && !row_start && !row_cnt));
   if (n_isects == 0) {
     CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
-    if (row_cnt && V > 0) {
-      CLMGS_HIP(hipMemsetAsync(row_cnt, 0, sizeof(int32_t) * (size_t)V, s));
-      CLMGS_HIP(hipMemsetAsync(row_start, 0, sizeof(int32_t) * (size_t)V, s));
-    }
     return 0;
   }
   CLMGS_CHECK_ARG(n_isects < ((int64_t)1 << 31));
-  CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && flatten_ids && temp);
+  CLMGS_CHECK_ARG(depths && order && cum && boxes && flatten_ids && temp);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_sort_temp_bytes(n_isects));
   char* base = (char*)temp;
   const size_t a4 = align_up((size_t)n_isects * 4, 256);
@@ -342,8 +352,8 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   const bool slots = emit_slot != nullptr;
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
-                     order, means2d, radii, cum, (float)tile_size, tile_width, tile_height, k_a,
-                     (int32_t*)v_a, slots ? (int2*)v_a : nullptr, row_start, row_cnt);
+                     order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
+                     slots ? (int2*)v_a : nullptr);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc;

@@ -480,34 +480,40 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   }
 }
 
-// Per-row sum of the tile partials (fixed order: ascending emit index) -> the row's gradient line.
+// Per-row sum of the tile partials, walked in RANK (depth) order: rank j owns the contiguous emit
+// range [cum[j-1], cum[j]), so consecutive threads stream consecutive ranges of the partials buffer;
+// fixed order (ascending emit index) -> the row's gradient line (one scattered 64 B store).
 // partials line: Sx Sy Sxx Sxy | Syy r g b | o - - - | -   (moments of v_sigma, see the tile kernel)
 __global__ void __launch_bounds__(256)
-raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ row_start,
-                           const int32_t* __restrict__ row_cnt,
-                           const float4* __restrict__ partials, const float4* __restrict__ packed,
-                           float4* __restrict__ packed_grad) {
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows;
-       r += (int64_t)gridDim.x * blockDim.x) {
-    const int cnt = row_cnt[r];
+raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ order,
+                           const int64_t* __restrict__ cum, const float4* __restrict__ partials,
+                           const float4* __restrict__ packed, float4* __restrict__ packed_grad) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n_rows;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = order[j];
+    const int64_t s0 = j ? cum[j - 1] : 0;
+    const int cnt = (int)(cum[j] - s0);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     float o = 0.f;
-    if (cnt > 0) {
-      const float4* src = partials + 4 * (size_t)row_start[r];
-      for (int j = 0; j < cnt; ++j) {
-        const float4 pa = src[4 * j], pb = src[4 * j + 1];
-        const float po = src[4 * j + 2].x;
-        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
-        o += po;
-      }
+    const float4* src = partials + 4 * (size_t)s0;
+    for (int t = 0; t < cnt; ++t) {
+      const float4 pa = src[4 * t], pb = src[4 * t + 1];
+      const float po = src[4 * t + 2].x;
+      a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+      b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+      o += po;
     }
-    const float4 ra = packed[REC_F4 * r], rb = packed[REC_F4 * r + 1];
-    const float ca = ra.w, cb = rb.x, cc = rb.y;
     float4* dst = packed_grad + REC_F4 * r;
-    dst[0] = make_float4(ca * a.x + cb * a.y, cb * a.x + cc * a.y, 0.5f * a.z, a.w);
-    dst[1] = make_float4(0.5f * b.x, b.y, b.z, b.w);
-    dst[2] = make_float4(o, 0.f, 0.f, 0.f);
+    if (cnt > 0) {
+      const float4 ra = packed[REC_F4 * r], rb = packed[REC_F4 * r + 1];
+      const float ca = ra.w, cb = rb.x, cc = rb.y;
+      dst[0] = make_float4(ca * a.x + cb * a.y, cb * a.x + cc * a.y, 0.5f * a.z, a.w);
+      dst[1] = make_float4(0.5f * b.x, b.y, b.z, b.w);
+      dst[2] = make_float4(o, 0.f, 0.f, 0.f);
+    } else {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[0] = z; dst[1] = z; dst[2] = z;
+    }
   }
 }
 
@@ -572,14 +578,13 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
                                    const float* v_render_alphas, void* packed_grad,
                                    float* v_means2d, float* v_conics, float* v_colors,
                                    float* v_opacities, const int32_t* emit_slot,
-                                   const int32_t* row_start, const int32_t* row_cnt,
-                                   void* partials) {
+                                   const int32_t* order, const int64_t* cum, void* partials) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
   CLMGS_CHECK_ARG(!v_means2d || (v_conics && v_colors && v_opacities));
   const bool part = emit_slot != nullptr;
-  CLMGS_CHECK_ARG(!part || (C == 1 && row_start && row_cnt && partials && (((uintptr_t)partials & 63) == 0)));
+  CLMGS_CHECK_ARG(!part || (C == 1 && order && cum && partials && (((uintptr_t)partials & 63) == 0)));
   hipStream_t s = (hipStream_t)stream;
   const int64_t CN = (int64_t)C * N;
   if (CN == 0) return 0;
@@ -607,7 +612,7 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
     CLMGS_LAUNCH_CHECK();
     if (part) {
       hipLaunchKernelGGL(raster_partials_sum_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256),
-                         0, s, CN, row_start, row_cnt, (const float4*)partials,
+                         0, s, CN, order, cum, (const float4*)partials,
                          (const float4*)packed, (float4*)packed_grad);
       CLMGS_LAUNCH_CHECK();
     }

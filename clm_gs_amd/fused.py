@@ -88,7 +88,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
         dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
-    fids, offsets, _, (emit_slot, row_start, row_cnt) = isect_tiles_two_level(
+    fids, offsets, _, (emit_slot, order, cum) = isect_tiles_two_level(
         means2d, radii, depths, TILE, tw, th, want_slots=True)
     out = torch.empty((H, W, 3), dtype=F32, device=dev)
     alphas = torch.empty((H, W), dtype=F32, device=dev)
@@ -128,7 +128,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     check(L.clmgs_rasterize_bwd(s_r, 1, V, n_isects, dptr(packed), dptr(bg, F32, True), W, H, TILE, tw,
                                 th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
                                 dptr(v_out), None, dptr(packed_grad), None, None, None, None,
-                                dptr(emit_slot), dptr(row_start), dptr(row_cnt), dptr(partials)))
+                                dptr(emit_slot), dptr(order), dptr(cum), dptr(partials)))
     if raster_stream is not None:
         cur.wait_stream(raster_stream)
     stats = update_stats and (not args.disable_auto_densification) and \
@@ -149,7 +149,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         *small_out, dptr(g_sh_rows, F32, allow_host=True),
         *stat_ptrs, None, int(bool(stats_only_visible))))
     if keep is not None:
-        keep += [packed, packed_grad, radii, filt, partials, emit_slot, row_start, row_cnt]
+        keep += [packed, packed_grad, radii, filt, partials, emit_slot, order, cum]
     if return_event:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

@@ -208,7 +208,8 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
     sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
     identical to isect_tiles + isect_offset_encode for C = 1.  want_slots: a 4th result
-    (emit_slot[I], row_start[V], row_cnt[V]) i32 for the atomic-free rasterize backward."""
+    (emit_slot[I] i32, order[V] i32, cum[V] i64) for the atomic-free rasterize backward: rank j
+    (row order[j]) owns the contiguous emit range [cum[j-1], cum[j])."""
     L = _lib.lib()
     V = radii.numel()
     dev = radii.device
@@ -218,14 +219,15 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
         offsets.zero_()
         e = torch.empty(0, dtype=I32, device=dev)
         res = (e, offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
-        return res + ((e, e.clone(), e.clone()),) if want_slots else res
+        return res + ((e, e.clone(), torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
     order = torch.empty((V,), dtype=I32, device=dev)
     cum = torch.empty((V,), dtype=I64, device=dev)
+    boxes = torch.empty((V,), dtype=I64, device=dev)
     tb = L.clmgs_isect2_order_temp_bytes(V)
     temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
     check(L.clmgs_isect2_order_count(stream(), V, dptr(means2d, F32), dptr(radii, I32), dptr(depths, F32),
                                      int(tile_size), int(tile_width), int(tile_height), dptr(order),
-                                     dptr(cum), dptr(temp), tb))
+                                     dptr(cum), dptr(boxes), dptr(temp), tb))
     n_isects = int(cum[-1].item())  # the one host sync of the front end
     _lib.STATS["n_isects"].append(n_isects)
     if len(_lib.STATS["n_isects"]) > 4096:
@@ -234,16 +236,11 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     ids = torch.empty((n_isects,), dtype=I64, device=dev) if want_isect_ids else None
     sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
     temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
-    slots = None
-    if want_slots:
-        slots = (torch.empty((n_isects,), dtype=I32, device=dev), torch.empty((V,), dtype=I32, device=dev),
-                 torch.empty((V,), dtype=I32, device=dev))
-    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(means2d), dptr(radii), dptr(depths),
-                                   dptr(order), dptr(cum), int(tile_size), int(tile_width),
-                                   int(tile_height), dptr(fids), dptr(offsets), dptr(ids, I64, True),
-                                   dptr(slots[0]) if slots else None, dptr(slots[1]) if slots else None,
-                                   dptr(slots[2]) if slots else None, dptr(temp2), sb))
-    return (fids, offsets, ids, slots) if want_slots else (fids, offsets, ids)
+    emit_slot = torch.empty((n_isects,), dtype=I32, device=dev) if want_slots else None
+    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(depths), dptr(order), dptr(cum), dptr(boxes),
+                                   int(tile_width), int(tile_height), dptr(fids), dptr(offsets),
+                                   dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb))
+    return (fids, offsets, ids, (emit_slot, order, cum)) if want_slots else (fids, offsets, ids)
 
 
 # ---------------------------------------------------------------------- rasterize

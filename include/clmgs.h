@@ -91,20 +91,19 @@ int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids
  * in that order (order[V] i32, cum[V] i64 inclusive; caller reads cum[V-1] = I);
  * B = emit in depth order + ONE stable sort on the tile-id bits -> flatten_ids[I] i32 (row ids),
  * offsets[tile_w*tile_h] i32, and isect_ids[I] i64 if non-NULL.
- * emit_slot[I] / row_start[V] / row_cnt[V] (all three or none, i32): the emit index of every
- * sorted intersection and each row's contiguous emit range -- hand them to clmgs_rasterize_bwd
+ * emit_slot[I] (i32, optional): the emit index of every sorted intersection; a rank's emit range
+ * is the contiguous [cum[j-1], cum[j]) -- hand emit_slot, order and cum to clmgs_rasterize_bwd
  * for the atomic-free (deterministic) gradient accumulation. */
 size_t clmgs_isect2_order_temp_bytes(int V);
 int clmgs_isect2_order_count(void* stream, int V, const float* means2d, const int32_t* radii,
                              const float* depths, int tile_size, int tile_width, int tile_height,
-                             int32_t* order, int64_t* cum, void* temp, size_t temp_bytes);
+                             int32_t* order, int64_t* cum, uint64_t* boxes, void* temp,
+                             size_t temp_bytes);
 size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects);
-int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* means2d,
-                           const int32_t* radii, const float* depths, const int32_t* order,
-                           const int64_t* cum, int tile_size, int tile_width, int tile_height,
-                           int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
-                           int32_t* emit_slot, int32_t* row_start, int32_t* row_cnt, void* temp,
-                           size_t temp_bytes);
+int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
+                           const int32_t* order, const int64_t* cum, const uint64_t* boxes,
+                           int tile_width, int tile_height, int32_t* flatten_ids, int32_t* offsets,
+                           int64_t* isect_ids, int32_t* emit_slot, void* temp, size_t temp_bytes);
 
 /* ---- gsplat.rasterize_to_pixels  (base_engine.py:192-203)
  * means2d[C*N,2] conics[C*N,3] colors[C*N,3] opacities[C*N], backgrounds[C,3] or NULL ->
@@ -123,9 +122,9 @@ int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects, const floa
  * gradient line per Gaussian (x y ca cb | cc r g b | o).  Two accumulation modes:
  *   - emit_slot == NULL: packed_grad is zeroed here and the per-(Gaussian,tile) sums are added
  *     with float atomics (any flatten_ids / offsets, C >= 1);
- *   - emit_slot / row_start / row_cnt from clmgs_isect2_emit_sort (C == 1) + `partials` scratch of
+ *   - emit_slot from clmgs_isect2_emit_sort, order / cum from clmgs_isect2_order_count (C == 1) + `partials` scratch of
  *     clmgs_rasterize_partials_bytes(n_isects) bytes (64 B aligned): every (Gaussian,tile) sum is
- *     STORED at its emit slot and a per-row pass adds each row's contiguous range in a fixed
+ *     STORED at its emit slot and a pass in rank order adds each row's contiguous range in a fixed
  *     order -- no atomics (they bound the kernel: 4.05 -> ~2 ms at 12 M intersections), bitwise
  *     reproducible gradients.
  * v_means2d[C*N,2] v_conics[C*N,3] v_colors[C*N,3] v_opacities[C*N] are OVERWRITTEN;
@@ -138,7 +137,7 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
                         const int32_t* last_ids, const float* v_render_colors,
                         const float* v_render_alphas, void* packed_grad, float* v_means2d,
                         float* v_conics, float* v_colors, float* v_opacities,
-                        const int32_t* emit_slot, const int32_t* row_start, const int32_t* row_cnt,
+                        const int32_t* emit_slot, const int32_t* order, const int64_t* cum,
                         void* partials);
 
 /* ---- fused per-camera front end (engine-internal fast path; same arithmetic as the op chain

@@ -466,18 +466,20 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
     colors = torch.rand(1, n, 3, generator=g)
     opac = s["opac"].reshape(1, -1)
     f0, o0, _ = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th)
-    fids, off, _, (slot, rstart, rcnt) = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th,
-                                                                 want_slots=True)
+    fids, off, _, (slot, order, cum) = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th,
+                                                               want_slots=True)
     assert torch.equal(fids, f0) and torch.equal(off, o0)
     I = fids.numel()
     assert torch.equal(torch.sort(slot.long()).values.cpu(), torch.arange(I))  # a permutation of the emit order
-    assert int(rcnt.sum()) == I
+    assert int(cum[-1]) == I and torch.equal(torch.sort(order.long()).values.cpu(), torch.arange(n))
     owner = torch.empty(I, dtype=torch.int64)
     owner[slot.long().cpu()] = fids.long().cpu()  # row id stored at each emit slot
-    rs, rc = rstart.long().cpu(), rcnt.long().cpu()
-    for r in torch.nonzero(rc).flatten()[:200].tolist():
-        assert bool((owner[rs[r]:rs[r] + rc[r]] == r).all())
-    assert bool((rc[radii[0] <= 0] == 0).all())
+    cu, od = cum.cpu(), order.long().cpu()
+    starts = torch.cat((torch.zeros(1, dtype=torch.int64), cu[:-1]))
+    cnt = cu - starts
+    for j in torch.nonzero(cnt).flatten()[:200].tolist():  # rank j owns a contiguous range of its row
+        assert bool((owner[starts[j]:cu[j]] == od[j]).all())
+    assert bool((cnt[radii[0][od] <= 0] == 0).all())
 
     t = [x.to(dev).contiguous() for x in (m2, cn, colors, opac)]
     out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
@@ -496,7 +498,7 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
         assert L.clmgs_rasterize_partials_bytes(I) == parts.numel() * 4
         check(L.clmgs_rasterize_bwd(stream(), 1, n, I, dptr(packed), None, w, h, 16, tw, th, dptr(off), dptr(fids),
                                     dptr(al), dptr(last), dptr(vi), dptr(va), dptr(pg), *[dptr(x) for x in outs],
-                                    *((dptr(slot), dptr(rstart), dptr(rcnt), dptr(parts)) if slots else (None,) * 4)))
+                                    *((dptr(slot), dptr(order), dptr(cum), dptr(parts)) if slots else (None,) * 4)))
         torch.cuda.synchronize()
         return [x.cpu() for x in outs]
 
