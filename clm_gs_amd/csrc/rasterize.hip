@@ -450,7 +450,13 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
         const float4* a = reinterpret_cast<const float4*>(sm.acc[lane]);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 r0 = z4, r1 = z4, r2 = z4;
-        if (hit) { r0 = a[0]; r1 = a[1]; r2 = a[2]; r2.y = r2.z = r2.w = 0.f; }
+        if (hit) {  // moments -> gradients here (the conic is at hand): x y ca cb | cc r g b | o
+          const float4 m0 = a[0], m1 = a[1];
+          const float ca = sm.a[lane].w, cb = sm.b[lane].x, cc = sm.b[lane].y;
+          r0 = make_float4(ca * m0.x + cb * m0.y, cb * m0.x + cc * m0.y, 0.5f * m0.z, m0.w);
+          r1 = make_float4(0.5f * m1.x, m1.y, m1.z, m1.w);
+          r2 = make_float4(a[2].x, 0.f, 0.f, 0.f);
+        }
         float4* dst = partials + 4 * (size_t)sm.id[lane];
         dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = z4;
       }
@@ -481,13 +487,13 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
 }
 
 // Per-row sum of the tile partials, walked in RANK (depth) order: rank j owns the contiguous emit
-// range [cum[j-1], cum[j]), so consecutive threads stream consecutive ranges of the partials buffer;
+// range [cum[j-1], cum[j]), so a wave streams one contiguous stretch of the partials buffer;
 // fixed order (ascending emit index) -> the row's gradient line (one scattered 64 B store).
-// partials line: Sx Sy Sxx Sxy | Syy r g b | o - - - | -   (moments of v_sigma, see the tile kernel)
+// partials line = gradient line: x y ca cb | cc r g b | o - - - | -
 __global__ void __launch_bounds__(256)
 raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ order,
                            const int64_t* __restrict__ cum, const float4* __restrict__ partials,
-                           const float4* __restrict__ packed, float4* __restrict__ packed_grad) {
+                           float4* __restrict__ packed_grad) {
   for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n_rows;
        j += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = order[j];
@@ -496,24 +502,25 @@ raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ order,
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     float o = 0.f;
     const float4* src = partials + 4 * (size_t)s0;
-    for (int t = 0; t < cnt; ++t) {
-      const float4 pa = src[4 * t], pb = src[4 * t + 1];
-      const float po = src[4 * t + 2].x;
-      a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-      b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
-      o += po;
+    for (int t = 0; t < cnt; t += 4) {  // four lines in flight per step (clamped; extra ones masked)
+      float4 pa[4], pb[4];
+      float po[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = min(t + u, cnt - 1);
+        pa[u] = src[4 * tt]; pb[u] = src[4 * tt + 1]; po[u] = src[4 * tt + 2].x;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t + u < cnt) {
+          a.x += pa[u].x; a.y += pa[u].y; a.z += pa[u].z; a.w += pa[u].w;
+          b.x += pb[u].x; b.y += pb[u].y; b.z += pb[u].z; b.w += pb[u].w;
+          o += po[u];
+        }
+      }
     }
     float4* dst = packed_grad + REC_F4 * r;
-    if (cnt > 0) {
-      const float4 ra = packed[REC_F4 * r], rb = packed[REC_F4 * r + 1];
-      const float ca = ra.w, cb = rb.x, cc = rb.y;
-      dst[0] = make_float4(ca * a.x + cb * a.y, cb * a.x + cc * a.y, 0.5f * a.z, a.w);
-      dst[1] = make_float4(0.5f * b.x, b.y, b.z, b.w);
-      dst[2] = make_float4(o, 0.f, 0.f, 0.f);
-    } else {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[0] = z; dst[1] = z; dst[2] = z;
-    }
+    dst[0] = a; dst[1] = b; dst[2] = make_float4(o, 0.f, 0.f, 0.f);
   }
 }
 
@@ -612,8 +619,7 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
     CLMGS_LAUNCH_CHECK();
     if (part) {
       hipLaunchKernelGGL(raster_partials_sum_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256),
-                         0, s, CN, order, cum, (const float4*)partials,
-                         (const float4*)packed, (float4*)packed_grad);
+                         0, s, CN, order, cum, (const float4*)partials, (float4*)packed_grad);
       CLMGS_LAUNCH_CHECK();
     }
   }
