@@ -137,6 +137,14 @@ __global__ void set_signal_kernel(int32_t* signal, int idx, int32_t value) {
 }
 
 // --------------------------------------------------------------------- Adam
+// update term  m / (sqrt(v) / sqrt(bc2) + eps)  with the hardware sqrt and reciprocal (1 ulp each):
+// the lazy replay is VALU-bound on the ~20-instruction IEEE sqrt + divide sequences (0.92 G VALU
+// instructions per launch), and a 2-ulp error of the update is far below one ulp of the parameter
+// it is subtracted from.  All three Adam kernels share it, so eager, lazy and packed agree.
+__device__ __forceinline__ float adam_ratio(float m, float v, float inv_sqrt_bc2, float eps) {
+  return m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+
 // VEC = 4 when cols % 4 == 0 (the [N,48] SH rows): one 16 B access per array per thread, the
 // per-step scalars are computed once per thread instead of once per element.
 template <int VEC> struct VecT;
@@ -175,8 +183,7 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
       const float gs = g ? gg[c] * grad_scale : 0.f;
       mm[c] = beta1 * mm[c] + ob1 * gs;
       vv[c] = beta2 * vv[c] + ob2 * gs * gs;
-      const float denom = sqrtf(vv[c]) * inv_sqrt_bc2 + eps;
-      pp[c] -= (lr[c] * inv_bc1) * (mm[c] / denom);
+      pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
       gg[c] = 0.f;
     }
     vstore<VEC>(m + o, mm); vstore<VEC>(v + o, vv); vstore<VEC>(p + o, pp);
@@ -230,7 +237,7 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
       for (int c = 0; c < VEC; ++c) {
         mm[c] *= beta1;
         vv[c] *= beta2;
-        pp[c] -= (lr[c] * inv_bc1) * (mm[c] / (sqrtf(vv[c]) * inv_sqrt_bc2 + eps));
+        pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
       }
       pw1 *= beta1; pw2 *= beta2;
     }
@@ -258,7 +265,7 @@ __device__ __forceinline__ float adam_elem(float& m, float& v, float p, float g,
                                            float inv_sqrt_bc2) {
   m = beta1 * m + ob1 * g;
   v = beta2 * v + ob2 * g * g;
-  return p - lr_bc * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+  return p - lr_bc * adam_ratio(m, v, inv_sqrt_bc2, eps);
 }
 
 __global__ void __launch_bounds__(SA_ROWS)
