@@ -20,6 +20,9 @@ SIGNATURES = {
     "clmgs_version": (_i, []),
     "clmgs_last_error": (ctypes.c_char_p, []),
     "clmgs_projection_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "clmgs_visibility_select_temp_bytes": (_sz, [_i, _i]),
+    "clmgs_visibility_select_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _sz, _vp]),
+    "clmgs_visibility_select_emit": (_i, [_vp, _i, _i, _vp, _vp]),
     "clmgs_visibility_raw": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "clmgs_projection_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_sh_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -100,7 +103,7 @@ class _Namespace:
 
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
-              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
+              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters"}
 
 

@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...);
 #define CLMGS_LAUNCH_CHECK() CLMGS_HIP(hipGetLastError())
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed,
 // speed only).  Remap so each XCD's L2 sees one contiguous range of work items.

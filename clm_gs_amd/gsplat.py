@@ -115,6 +115,33 @@ def visibility_radii(means, quats, scales, viewmats, Ks, width, height, eps2d=0.
     return radii
 
 
+def visibility_select(means, quats_raw, log_scales, viewmats, Ks, width, height, eps2d=0.3,
+                      near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+    """The batch's visibility filters selected on the GPU: same cull as visibility_radii(raw=True)
+    but without the radii[C,N] round trip and torch.nonzero -- one ballot word per (camera, 64
+    Gaussians), a scan, and an emit pass.  -> (filters: tuple of C int64 index tensors (ascending),
+    touched_rows: int64 indices of the union over the cameras).  One host read (the C+1 totals)."""
+    L = _lib.lib()
+    means, quats_raw, log_scales = means.contiguous(), quats_raw.contiguous(), log_scales.contiguous()
+    viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+    C, N = viewmats.shape[0], means.shape[0]
+    dev = means.device
+    tb = L.clmgs_visibility_select_temp_bytes(C, N)
+    temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    cum = torch.empty((C + 1,), dtype=I64, device=dev)
+    check(L.clmgs_visibility_select_count(
+        stream(), C, N, dptr(means, F32), dptr(quats_raw, F32), dptr(log_scales, F32), dptr(viewmats, F32),
+        dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+        float(radius_clip), dptr(temp), tb, dptr(cum)))
+    ends = cum.tolist()  # the one host sync of the filter stage
+    out = torch.empty((max(ends[-1], 1),), dtype=I64, device=dev)
+    if ends[-1] > 0:
+        check(L.clmgs_visibility_select_emit(stream(), C, N, dptr(temp), dptr(out)))
+    starts = [0] + ends[:-1]
+    pieces = tuple(out[a:b] for a, b in zip(starts, ends))
+    return pieces[:C], pieces[C]
+
+
 # ------------------------------------------------------------ spherical harmonics
 class _SphericalHarmonics(torch.autograd.Function):
     @staticmethod

@@ -13,6 +13,23 @@ LAMBDA_DSSIM = 0.2
 TILE_SIZE = 16
 
 
+def select_filters(batched_cameras, xyz_gpu, scaling_raw_gpu, rotation_raw_gpu):
+    """calculate_filters on the stored (raw) parameters, selected entirely on the GPU
+    (gsplat.visibility_select) -> (filters, touched_rows): the same index sets as calculate_filters
+    plus the union over the batch's cameras."""
+    from ..gsplat import visibility_select
+    args = utils.get_args()
+    with torch.no_grad():
+        Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in batched_cameras])
+        viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in batched_cameras])
+        filters, touched_rows = visibility_select(
+            xyz_gpu, rotation_raw_gpu, scaling_raw_gpu, viewmats, Ks, int(utils.get_img_width()),
+            int(utils.get_img_height()), radius_clip=args.radius_clip)
+    assert all(f.numel() > 0 for f in filters), (
+        "every camera must see at least one gaussian (base_engine.py:64-67)")
+    return filters, touched_rows
+
+
 def calculate_filters(batched_cameras, xyz_gpu, opacity_gpu, scaling_gpu, rotation_gpu,
                       return_ids=False, raw=False):
     """Per-camera visible index lists: ONE cull pass over (bsz cameras x N Gaussians).

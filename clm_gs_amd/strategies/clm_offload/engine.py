@@ -30,7 +30,7 @@ from ...densification import update_densification_stats_offload_accum_grads
 from ...gsplat import (fully_fused_projection, isect_offset_encode, isect_tiles,
                        rasterize_to_pixels, spherical_harmonics)
 from ...host import pinned_empty
-from ..base_engine import (TILE_SIZE, calculate_filters, pipeline_forward_one_step,
+from ..base_engine import (select_filters, TILE_SIZE, calculate_filters, pipeline_forward_one_step,
                            torch_compiled_loss)
 
 _BITMAP_DTYPE = {4: torch.int8, 8: torch.int8, 16: torch.int16, 32: torch.int32, 64: torch.int64}
@@ -233,23 +233,32 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                          pipe_args, comm_stream, args):
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
+    touched = touched_rows = None
     with torch.no_grad():
         if getattr(args, "fused_front_end", True):
-            # same fast exp as the fused front end -> filter and render agree on every cull
-            filters, _, _ = calculate_filters(batched_cameras, gaussians._xyz.detach(), None,
-                                              gaussians._scaling.detach(), gaussians._rotation.detach(),
-                                              raw=True)
+            # same fast exp as the fused front end -> filter and render agree on every cull;
+            # filters AND the union of touched rows are selected on the GPU in one pass
+            filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
+                                                   gaussians._scaling.detach(), gaussians._rotation.detach())
         else:
             filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
                                               gaussians.get_scaling, gaussians.get_rotation)
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
-    touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
-    for f in filters:
-        touched[f] = True
-    # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
-    # only globally untouched rows may take the early zero-gradient update
-    touched = dp.allreduce_touched(touched)
+    lazy_mode = gaussians.lazy_rows and not args.stop_update_param
+    need_mask = touched_rows is None or args.sparse_adam or dp.world_size() > 1 or not lazy_mode
+    if need_mask:
+        touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
+        if touched_rows is not None:
+            touched[touched_rows] = True
+        else:
+            for f in filters:
+                touched[f] = True
+        # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
+        # only globally untouched rows may take the early zero-gradient update
+        if dp.world_size() > 1:
+            touched = dp.allreduce_touched(touched)
+            touched_rows = None
     row_adam = gaussians.optimizer.cpu_adam
     params = gaussians._parameters
     grad_buf = parameters_grad_buffer[:N]
@@ -270,7 +279,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                               group["betas"][0], group["betas"][1], group["eps"], step,
                               group["bias_correction"], 1.0 / (bsz * dp.world_size()), True)
 
-    touched_rows = torch.nonzero(touched).flatten().to(torch.int32)
+    if touched_rows is None:
+        touched_rows = torch.nonzero(touched).flatten()
+    touched_rows = touched_rows.to(torch.int32)
     lazy = gaussians.lazy_rows and not args.stop_update_param
     if lazy:
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped

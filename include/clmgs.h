@@ -48,6 +48,20 @@ int clmgs_visibility_raw(void* stream, int C, int N, const float* means, const f
                          const float* log_scales, const float* viewmats, const float* Ks, int width,
                          int height, float eps2d, float near_plane, float far_plane,
                          float radius_clip, int32_t* radii);
+
+/* Visibility filters of a batch selected on the GPU (calculate_filters, base_engine.py:18-76, plus the
+ * union "rows the batch touches"), same cull as clmgs_visibility_raw but nothing of size C*N leaves
+ * the kernel: _count writes one ballot word + popcount per (camera, 64 Gaussians) into `temp`, scans
+ * them and leaves cum_totals[C+1] (device, i64: set bits of cameras 0..r; row C = union over the
+ * cameras); the caller reads cum_totals, allocates out[cum_totals[C]] i64 and calls _emit, which
+ * writes the ascending Gaussian indices of camera 0, camera 1, ..., then of the union. */
+size_t clmgs_visibility_select_temp_bytes(int C, int N);
+int clmgs_visibility_select_count(void* stream, int C, int N, const float* means,
+                                  const float* quats_raw, const float* log_scales,
+                                  const float* viewmats, const float* Ks, int width, int height,
+                                  float eps2d, float near_plane, float far_plane, float radius_clip,
+                                  void* temp, size_t temp_bytes, int64_t* cum_totals);
+int clmgs_visibility_select_emit(void* stream, int C, int N, const void* temp, int64_t* out);
 /* VJP of the above.  v_means[N,3], v_quats[N,4], v_scales[N,3] are overwritten
  * with the sum over the C cameras. */
 int clmgs_projection_bwd(void* stream, int C, int N, const float* means, const float* quats,

@@ -512,3 +512,20 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
         assert torch.isfinite(x).all(), name
         assert rel_l2(x, y) < 1e-5, name
         assert rel_l2(x.reshape(ref.grad.shape), ref.grad) < GRAD_TOL, name
+
+
+def test_visibility_select_equals_radii_nonzero(dev):
+    """GPU-side filter selection == nonzero(radii > 0) per camera, and its extra row == the union."""
+    from clm_gs_amd import gsplat as G
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    for n in (1, 63, 64, 65, 5000, 70001):
+        sc = synth_gaussians(n, seed=3, device="cuda")
+        cams = nadir_cameras(3, max(n, 2000), 160, 96, 0.4, seed=1, device="cuda")
+        Ks = torch.stack([c.K for c in cams])
+        vms = torch.stack([c.world_view_transform.t() for c in cams])
+        radii = G.visibility_radii(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, 160, 96, raw=True)
+        filters, union = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, 160, 96)
+        assert len(filters) == 3
+        for c in range(3):
+            assert torch.equal(filters[c], torch.nonzero(radii[c] > 0).flatten())
+        assert torch.equal(union, torch.nonzero((radii > 0).any(dim=0)).flatten())
