@@ -11,123 +11,173 @@
 
 namespace clmgs {
 
-// 32x32 output pixels per 256-thread block (halo overhead 1.7x instead of 2.6x for 16x16) and
-// 4-wide register blocking of both separable passes: a thread loads 14 taps once and produces 4
-// neighbouring outputs, ~3x fewer LDS reads than one output per thread -- these kernels are
-// LDS-issue bound, not HBM bound.
-constexpr int LT = 32, LR = 5, LH = LT + 2 * LR;  // tile, radius, halo edge (42)
+// Streaming separable 11-tap window, one WAVEFRONT per strip of 64 output columns x LS_ROWS output
+// rows (x one channel in the forward):
+//   * the wave walks down the strip in MACRO steps of 11 input rows.  The 11 x 74 input values of
+//     the NEXT macro step (with the +-5 column halo) are requested while the current 11 rows are
+//     processed (13 loads per lane and array stay in flight for ~11 row times: HBM latency is
+//     covered without relying on occupancy); at the macro boundary they are written to a 16-row LDS
+//     ring;
+//   * per row every lane reads its 11 taps from the ring and forms the HORIZONTAL sums;
+//   * the VERTICAL pass is a sliding window in registers: the last 11 rows of horizontal sums
+//     live in a statically indexed ring (the row loop is unrolled by 11), so a finished output row
+//     costs 11 FMAs per statistic and no LDS at all;
+//   * no workgroup barrier anywhere (wave-scope fences only), ~10 KB of LDS per wave.
+// The tiled version it replaces (32x32 tile, 42 KB of LDS per 256-thread block, five barriers per
+// channel) sat at ~55 % VALU utilisation with 3 waves/SIMD.
+constexpr int LR = 5;                             // window radius
+constexpr int LM = 2 * LR + 1;                    // rows per macro step = window length (11)
+constexpr int LS_W = 64, LS_ROWS = 66;            // strip: output columns (= lanes), output rows (6 macros)
+constexpr int LS_IN = LS_W + 2 * LR;              // input columns per row (74)
+constexpr int LS_PITCH = LS_IN + 2;               // LDS row pitch (floats)
+constexpr int LS_RING = 16;                       // LDS ring rows: 11 of the macro + 5 older (L1 centre)
 constexpr int LOSS_SLOTS = 1024;                  // partial-sum slots (spreads the atomics)
 constexpr float L_C1 = 0.01f * 0.01f, L_C2 = 0.03f * 0.03f;
 
-__constant__ float l_win[11] = {
+// compile-time weights: they become instruction literals, not 11 live VGPRs
+constexpr float l_win[11] = {
     0.0010283801f, 0.0075987582f, 0.0360007721f, 0.1093606895f, 0.2130055377f, 0.2660117249f,
     0.2130055377f, 0.1093606895f, 0.0360007721f, 0.0075987582f, 0.0010283801f};
 
 struct ImgView { const float* p; int64_t sc, sy, sx; };
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(256)
+// clamp(u8 / 255, 0, 1) (base_engine.py:79-103), correctly rounded like the IEEE division for all 256
+// inputs (checked exhaustively) in 3 VALU instead of the ~10 of v_div_scale/fmas/fixup:
+// q = v * (1/255); q += fma(-q, 255, v) * (1/255).  The clamp is a no-op on [0, 1].
+__device__ __forceinline__ float gt_val(const uint8_t* __restrict__ gt, size_t o) {
+  const float v = (float)gt[o];
+  const float r = 1.0f / 255.0f;
+  const float q = v * r;
+  return fmaf(fmaf(-q, 255.0f, v), r, q);
+}
+
+__global__ void __launch_bounds__(64)
 loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float* __restrict__ partials,
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
-  __shared__ float sx[LH][LH + 1];
-  __shared__ float sy[LH][LH + 1];
-  __shared__ float hz[5][LH][LT + 1];
-  __shared__ float red[4];
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-  const int tid = threadIdx.x;
+  __shared__ float la[LS_RING][LS_PITCH], lb[LS_RING][LS_PITCH];
+  const int lane = threadIdx.x;
+  const int x0 = blockIdx.x * LS_W, y0 = blockIdx.y * LS_ROWS, c = blockIdx.z;
   const size_t plane = (size_t)H * W;
-  float w[11];
+  const int xo = x0 + lane;                              // output column
+  const int n_rows = min(LS_ROWS, H - y0) + 2 * LR;      // input rows to walk
+  // Staging map: per macro step a lane requests its OWN column of the 11 rows (row pointer = scalar
+  // base + lane: two VALU per load, a wave-uniform branch for rows outside the image) plus two of
+  // the 110 halo values (columns 64..73 of the 11 rows).
+  const int xs = x0 - LR + lane;                         // this lane's input column
+  const bool xs_ok = xs >= 0 && xs < W;
+  int hrow[2], hcol[2];
+  bool h_ok[2];
 #pragma unroll
-  for (int k = 0; k < 11; ++k) w[k] = l_win[k];
-  float l1 = 0.f, ss = 0.f;
-  for (int c = 0; c < 3; ++c) {
-    __syncthreads();
-    for (int i = tid; i < LH * LH; i += 256) {
-      const int r = i / LH, cx = i - r * LH;
-      const int y = y0 + r - LR, x = x0 + cx - LR;
-      float a = 0.f, b = 0.f;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        a = img.p[c * img.sc + y * img.sy + x * img.sx];
-        b = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
+  for (int u = 0; u < 2; ++u) {
+    const int h = lane + 64 * u;
+    hrow[u] = h / (2 * LR); hcol[u] = LS_W + h - hrow[u] * (2 * LR);
+    const int xh = x0 - LR + hcol[u];
+    h_ok[u] = h < LM * 2 * LR && xh < W;
+  }
+  float pa[LM], pb[LM], ha[2], hb[2];                    // the macro step in flight
+  auto fetch = [&](int r0) {  // request input rows r0 .. r0+10 (zero outside the image)
+#pragma unroll
+    for (int k = 0; k < LM; ++k) {
+      const int y = y0 - LR + r0 + k;                    // wave-uniform
+      pa[k] = 0.f; pb[k] = 0.f;
+      if (y >= 0 && y < H && xs_ok) {
+        pa[k] = img.p[c * img.sc + y * img.sy + xs * img.sx];
+        pb[k] = gt_val(gt, c * plane + (size_t)y * W + xs);
       }
-      sx[r][cx] = a; sy[r][cx] = b;
     }
-    __syncthreads();
-    // horizontal pass: task = (row, 4 consecutive output columns)
-    for (int t = tid; t < LH * (LT / 4); t += 256) {
-      const int r = t / (LT / 4), c4 = (t - r * (LT / 4)) * 4;
-      float a[14], b[14];
 #pragma unroll
-      for (int k = 0; k < 14; ++k) { a[k] = sx[r][c4 + k]; b[k] = sy[r][c4 + k]; }
+    for (int u = 0; u < 2; ++u) {
+      const int y = y0 - LR + r0 + hrow[u], x = x0 - LR + hcol[u];
+      ha[u] = 0.f; hb[u] = 0.f;
+      if (h_ok[u] && y >= 0 && y < H) {
+        ha[u] = img.p[c * img.sc + y * img.sy + x * img.sx];
+        hb[u] = gt_val(gt, c * plane + (size_t)y * W + x);
+      }
+    }
+  };
+  fetch(0);
+  float win[LM][5];   // ring of horizontal sums: mu1 mu2 E[aa] E[bb] E[ab]
+  float l1 = 0.f, ss = 0.f;
+  for (int r0 = 0; r0 < n_rows; r0 += LM) {
+    // macro boundary: rows r0 .. r0+10 -> LDS ring, then the next macro step takes off
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
+    for (int k = 0; k < LM; ++k) {
+      const int slot = (r0 + k) & (LS_RING - 1);
+      la[slot][lane] = pa[k]; lb[slot][lane] = pb[k];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (lane + 64 * u < LM * 2 * LR) {
+        const int slot = (r0 + hrow[u]) & (LS_RING - 1);
+        la[slot][hcol[u]] = ha[u]; lb[slot][hcol[u]] = hb[u];
+      }
+    }
+    fetch(r0 + LM);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < LM; ++k) {
+      const int r = r0 + k;
+      if (r < n_rows) {  // wave-uniform
+        const int buf = r & (LS_RING - 1);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-          const float av = a[o + k], bv = b[o + k], wk = w[k];
-          s0 += wk * av; s1 += wk * bv; s2 += wk * av * av; s3 += wk * bv * bv; s4 += wk * av * bv;
+        for (int j = 0; j < LM; ++j) {
+          const float av = la[buf][lane + j], bv = lb[buf][lane + j];
+          const float wa_ = l_win[j] * av, wb_ = l_win[j] * bv;
+          s0 += wa_; s1 += wb_; s2 += wa_ * av; s3 += wb_ * bv; s4 += wa_ * bv;
         }
-        hz[0][r][c4 + o] = s0; hz[1][r][c4 + o] = s1; hz[2][r][c4 + o] = s2;
-        hz[3][r][c4 + o] = s3; hz[4][r][c4 + o] = s4;
-      }
-    }
-    __syncthreads();
-    // vertical pass: task = (column, 4 consecutive output rows); 256 tasks = one per thread
-    {
-      const int col = tid & 31, r4 = (tid >> 5) * 4;
-      float acc[5][4];
+        win[k][0] = s0; win[k][1] = s1; win[k][2] = s2; win[k][3] = s3; win[k][4] = s4;
+        if (r >= 2 * LR) {  // rows r-10 .. r are in the ring: output row y0 + r - 10
+          float acc[5];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        float v[14];
+          for (int q = 0; q < 5; ++q) {
+            float sacc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = hz[q][r4 + k][col];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          float sacc = 0.f;
-#pragma unroll
-          for (int k = 0; k < 11; ++k) sacc += w[k] * v[o + k];
-          acc[q][o] = sacc;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int y = y0 + r4 + o, x = x0 + col;
-        if (y < H && x < W) {
-          const float mu1 = acc[0][o], mu2 = acc[1][o];
-          const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-          const float s1 = acc[2][o] - mu1sq, s2 = acc[3][o] - mu2sq, s12 = acc[4][o] - mu12;
-          const float A = 2.f * mu12 + L_C1, B = 2.f * s12 + L_C2;
-          const float D = mu1sq + mu2sq + L_C1, E = s1 + s2 + L_C2;
-          const float iDE = 1.f / (D * E);
-          const float val = A * B * iDE;
-          ss += val;
-          l1 += fabsf(sx[r4 + o + LR][col + LR] - sy[r4 + o + LR][col + LR]);
-          if (m1) {
-            const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 / D;
-            const float d_s1 = -val / E, d_s12 = 2.f * A * iDE;
-            const size_t oidx = c * plane + (size_t)y * W + x;
-            m1[oidx] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12; m2[oidx] = d_s1; m3[oidx] = d_s12;
+            for (int j = 0; j < LM; ++j) sacc += l_win[j] * win[(k + 1 + j) % LM][q];
+            acc[q] = sacc;
+          }
+          const int y = y0 + r - 2 * LR;
+          if (xo < W && y < H) {
+            const float mu1 = acc[0], mu2 = acc[1];
+            const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sg1 = acc[2] - mu1sq, sg2 = acc[3] - mu2sq, sg12 = acc[4] - mu12;
+            const float A = 2.f * mu12 + L_C1, B = 2.f * sg12 + L_C2;
+            const float D = mu1sq + mu2sq + L_C1, E = sg1 + sg2 + L_C2;
+            const float iDE = __builtin_amdgcn_rcpf(D * E);  // 1-ulp reciprocals: three IEEE divides
+            const float val = A * B * iDE;                   // per pixel were a tenth of the kernel
+            ss += val;
+            const int cbuf = (r - LR) & (LS_RING - 1);  // centre: input row r - 5, still in the ring
+            l1 += fabsf(la[cbuf][lane + LR] - lb[cbuf][lane + LR]);
+            if (m1) {
+              const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 * __builtin_amdgcn_rcpf(D);
+              const float d_s1 = -val * __builtin_amdgcn_rcpf(E), d_s12 = 2.f * A * iDE;
+              const size_t oidx = c * plane + (size_t)y * W + xo;
+              m1[oidx] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12; m2[oidx] = d_s1; m3[oidx] = d_s12;
+            }
           }
         }
       }
     }
+    wave_sync();  // the ring rows of this macro step are consumed before the next one lands
   }
-  const float tl1 = block_sum(l1, red);
-  const float tss = block_sum(ss, red);
-  if (tid == 0) {
-    const int slot = (blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_SLOTS - 1);
+  const float tl1 = wave_sum(l1), tss = wave_sum(ss);
+  if (lane == 0) {
+    const int slot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (LOSS_SLOTS - 1);
     atomicAdd(partials + 2 * slot, tl1);
     atomicAdd(partials + 2 * slot + 1, tss);
   }
 }
 
+// Backward: the tiled form (32x32 output pixels per 256-thread block, separable passes through LDS
+// with 4-wide register blocking).  A streaming version like the forward was measured equal or
+// slower (0.52-0.62 vs 0.49 ms): its output-pixel loads sit behind the prefetch in vmcnt order.
+constexpr int LT = 32, LH = LT + 2 * LR;  // tile, halo edge (42)
 // v_img (same strides as img) = v * ( w_l1 * sign(x - y) - w_ssim * dSSIMsum/dx ) / numel
 __global__ void __launch_bounds__(256)
 loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const float* __restrict__ v,
@@ -139,9 +189,6 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
   const float vv = v[0];
-  float w[11];
-#pragma unroll
-  for (int k = 0; k < 11; ++k) w[k] = l_win[k];
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
     for (int i = tid; i < LH * LH; i += 256) {
@@ -165,7 +212,7 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
       for (int o = 0; o < 4; ++o) {
         float sacc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) sacc += w[k] * a[o + k];
+        for (int k = 0; k < 11; ++k) sacc += l_win[k] * a[o + k];
         hz[q][r][c4 + o] = sacc;
       }
     }
@@ -182,7 +229,7 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
         for (int o = 0; o < 4; ++o) {
           float sacc = 0.f;
 #pragma unroll
-          for (int k = 0; k < 11; ++k) sacc += w[k] * vcol[o + k];
+          for (int k = 0; k < 11; ++k) sacc += l_win[k] * vcol[o + k];
           g[q][o] = sacc;
         }
       }
@@ -192,7 +239,7 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
         if (y < H && x < W) {
           const int64_t oi = c * img.sc + y * img.sy + x * img.sx;
           const float xv = img.p[oi];
-          const float yv = fminf(fmaxf((float)gt[c * plane + (size_t)y * W + x] / 255.0f, 0.f), 1.f);
+          const float yv = gt_val(gt, c * plane + (size_t)y * W + x);
           const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
           const float dss = g[0][o] + 2.f * xv * g[1][o] + yv * g[2][o];
           v_img[oi] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
@@ -214,8 +261,8 @@ extern "C" int clmgs_l1_ssim_loss_fwd(void* stream, int H, int W, const float* i
   CLMGS_CHECK_ARG(H >= 1 && W >= 1 && img && gt_u8 && partials);
   CLMGS_CHECK_ARG((m1 && m2 && m3) || (!m1 && !m2 && !m3));
   ImgView v{img, stride_c, stride_y, stride_x};
-  dim3 grid(ceil_div(W, LT), ceil_div(H, LT));
-  hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, v, gt_u8,
+  dim3 grid(ceil_div(W, LS_W), ceil_div(H, LS_ROWS), 3);
+  hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, H, W, v, gt_u8,
                      partials, m1, m2, m3);
   CLMGS_LAUNCH_CHECK();
   return 0;
