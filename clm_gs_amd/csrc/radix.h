@@ -18,13 +18,18 @@
 namespace clmgs {
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;   // 2048 keys per block: 32 KB of LDS, ~70 VGPRs -> 5 blocks per CU
-constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // keys per block
+// Keys per thread.  8 (2048 keys per block, 32 KB of LDS with 4 B payloads) is the fastest solo;
+// 8 B payloads use 4 (1024 keys, 20 KB of LDS instead of 42 KB): the tile sort runs concurrently
+// with the alpha-blend kernels, whose small blocks keep ~120 KB of each CU's LDS occupied, and a
+// 42 KB block was starved for minutes of kernel time (1.03 ms per pass instead of 0.12 ms solo).
+template <typename ValT> struct RsItems { static constexpr int value = sizeof(ValT) > 4 ? 4 : 8; };
+constexpr int RS_MIN_CHUNK = RS_THREADS * 4;
 
-template <typename KeyT>
+template <typename KeyT, int RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int n_blocks,
                   uint32_t* __restrict__ table /*[256][n_blocks]*/) {
+  constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -88,12 +93,13 @@ radix_scan_digits_kernel(uint32_t* __restrict__ row_tot) {
   row_tot[threadIdx.x] = woff + x - v;
 }
 
-template <typename KeyT, typename ValT>
+template <typename KeyT, typename ValT, int RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, int shift,
                      int n_blocks, const uint32_t* __restrict__ table,
                      const uint32_t* __restrict__ digit_base) {
+  constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
   // cnt[round][wave][digit]: first the number of keys of that digit in that (round, wave), then
   // (after the per-digit prefix) the offset of that group inside the block's digit bucket.
   __shared__ uint16_t cnt[RS_ITEMS][4][256];
@@ -185,7 +191,7 @@ radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __
 }
 
 static inline size_t radix_table_bytes(int64_t n) {
-  const int64_t nb = (n + RS_CHUNK - 1) / RS_CHUNK;
+  const int64_t nb = (n + RS_MIN_CHUNK - 1) / RS_MIN_CHUNK;  // upper bound over both block sizes
   return ((size_t)(nb + 1) * 256 * sizeof(uint32_t) + 255) / 256 * 256;  // table + 256 digit bases
 }
 
@@ -197,6 +203,8 @@ template <typename KeyT, typename ValT = int32_t>
 static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                             ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
                             uint32_t* table, KeyT** keys_sorted) {
+  constexpr int ITEMS = RsItems<ValT>::value;
+  constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
   uint32_t* digit_base = table + (size_t)n_blocks * 256;
@@ -211,11 +219,11 @@ static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, 
     const int shift = begin_bit + 8 * p;
     KeyT* kdst = (ksrc == keysA) ? keysB : keysA;
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
-    hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
+    hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
                        n_blocks, table);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, s, n_blocks, table, digit_base);
     hipLaunchKernelGGL(radix_scan_digits_kernel, dim3(1), dim3(256), 0, s, digit_base);
-    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
+    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
                        kdst, vdst, shift, n_blocks, table, digit_base);
     CLMGS_LAUNCH_CHECK();
     ksrc = kdst;
