@@ -317,6 +317,35 @@ class BaseGaussianModel(ABC):
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         save_ply(path, self._xyz, self._shs48_rows(None), self._opacity, self._scaling, self._rotation)
 
+    def save_sub_plys(self, path, n_split, split_size):
+        """Split PLY output for models that do not fit host RAM in one piece
+        (clm_offload/gaussian_model.py:292-360; scene/__init__.py:262-277): files
+        <stem>_rk{i}_ws{n_split}.ply holding rows [i*split_size, (i+1)*split_size)."""
+        import os
+        from ..io_ply import save_ply
+        assert path.endswith(".ply")
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        n = self._xyz.shape[0]
+        shs = self._shs48_rows(None)
+        written = []
+        for i in range(n_split):
+            a, b = i * split_size, min((i + 1) * split_size, n)
+            this_path = path[:-4] + "_rk" + str(i) + "_ws" + str(n_split) + ".ply"
+            save_ply(this_path, self._xyz[a:b], shs[a:b], self._opacity[a:b], self._scaling[a:b],
+                     self._rotation[a:b])
+            written.append(this_path)
+        return written
+
+    def load_sub_plys(self, path, n_split, spatial_lr_scale=1.0):
+        """Inverse of save_sub_plys: reassemble <stem>_rk{i}_ws{n_split}.ply in rank order."""
+        import torch as _t
+        from ..io_ply import load_ply
+        parts = [load_ply(path[:-4] + "_rk" + str(i) + "_ws" + str(n_split) + ".ply") for i in range(n_split)]
+        cat = {k: _t.cat([p[k] for p in parts], dim=0) for k in ("xyz", "shs48", "scaling", "rotation", "opacity")}
+        self.create_from_tensors(cat["xyz"], cat["shs48"], cat["scaling"], cat["rotation"], cat["opacity"],
+                                 spatial_lr_scale)
+        self.active_sh_degree = self.max_sh_degree
+
     def load_ply(self, path, spatial_lr_scale=1.0):
         from ..io_ply import load_ply
         d = load_ply(path)

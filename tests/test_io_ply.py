@@ -35,3 +35,37 @@ def test_ply_layout_and_roundtrip(tmp_path):
     d = io_ply.load_ply(str(p))
     for k, t in (("xyz", xyz), ("shs48", shs), ("opacity", op), ("scaling", sc), ("rotation", rot)):
         assert torch.equal(d[k], t), k
+
+
+def test_split_ply_naming_and_reassembly(tmp_path):
+    """save_sub_plys writes <stem>_rk{i}_ws{n}.ply slices (scene/__init__.py:262-277 naming) whose
+    concatenation is the single-file model."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.base_gaussian_model import BaseGaussianModel
+
+    utils.set_args(utils.default_args(bsz=4))
+    g = torch.Generator().manual_seed(1)
+    n = 23
+
+    class _M(BaseGaussianModel):  # storage-only model on the host: enough for the file formats
+        get_features = property(lambda self: self._shs.reshape(-1, 16, 3))
+
+        def create_from_tensors(self, xyz, shs48, scaling, rotation, opacity, spatial_lr_scale=1.0):
+            self._xyz, self._shs, self._scaling, self._rotation, self._opacity = xyz, shs48, scaling, rotation, opacity
+
+        def _shs48_rows(self, mask):
+            return self._shs
+
+        all_parameters = training_setup = _append_rows = prune_points = reset_opacity = lambda self, *a: None
+
+    m = _M(3)
+    m.create_from_tensors(torch.randn(n, 3, generator=g), torch.randn(n, 48, generator=g),
+                          torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g), torch.randn(n, 1, generator=g))
+    files = m.save_sub_plys(str(tmp_path / "point_cloud.ply"), 3, 8)
+    assert [f.rsplit("/", 1)[1] for f in files] == [f"point_cloud_rk{i}_ws3.ply" for i in range(3)]
+    assert [io_ply.load_ply(f)["xyz"].shape[0] for f in files] == [8, 8, 7]
+    m2 = _M(3)
+    m2.load_sub_plys(str(tmp_path / "point_cloud.ply"), 3)
+    for a, b in ((m._xyz, m2._xyz), (m._shs, m2._shs), (m._opacity, m2._opacity), (m._scaling, m2._scaling),
+                 (m._rotation, m2._rotation)):
+        assert torch.equal(a, b)
