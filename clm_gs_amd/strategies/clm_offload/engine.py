@@ -375,11 +375,12 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     if dp.world_size() > 1:  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
         if use_packed:
-            dp.allreduce_small_grads([small_gk], average=False)  # one 48 B/Gaussian collective
+            # one collective: packed small gradients + SH gradient rows of the globally touched set
+            dp.allreduce_tables_rows([small_gk, grad_buf], touched_rows, N, average=False)
         else:
             dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
                                       gaussians._scaling.grad, gaussians._rotation.grad], average=False)
-        dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
+            dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
     if use_packed:
         gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()))
     else:

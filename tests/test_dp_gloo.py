@@ -41,8 +41,19 @@ def _worker(rank, world, port, out):
     m.denom = torch.full((N, 1), 1.0)
     m.max_radii2D = torch.full((N,), float(rank * 5))
     dp.allreduce_densify_stats(m)
+    # packed one-collective exchange of several row tables over the global touched set
+    t_small = torch.zeros(N, 12); t_rows = torch.zeros(N, 48)
+    t_small[touched] = torch.randn(int(touched.sum()), 12, generator=g)
+    t_rows[touched] = torch.randn(int(touched.sum()), 48, generator=g)
+    ts_ref, tr_ref = t_small.clone(), t_rows.clone()
+    rows_g = torch.nonzero(tg).flatten()
+    a_small, a_rows = t_small.clone(), t_rows.clone()
+    dp.allreduce_tables_rows([a_small, a_rows], rows_g, N)                    # packed branch
+    b_small, b_rows = t_small.clone(), t_rows.clone()
+    dp.allreduce_tables_rows([b_small, b_rows], rows_g, N, dense_above=0.0)   # in-place branch
     gathered = [None] * world
-    dist.all_gather_object(gathered, dict(ref=ref, rows_ref=rows_ref, touched_ref=touched_ref))
+    dist.all_gather_object(gathered, dict(ref=ref, rows_ref=rows_ref, touched_ref=touched_ref,
+                                          ts_ref=ts_ref, tr_ref=tr_ref))
     if rank == 0:
         want_small = [sum(gd["ref"][i] for gd in gathered) / world for i in range(4)]
         want_t = gathered[0]["touched_ref"] | gathered[1]["touched_ref"]
@@ -50,6 +61,10 @@ def _worker(rank, world, port, out):
         ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(grads, want_small))
         ok &= torch.equal(tg, want_t)
         ok &= torch.allclose(rows, want_rows, atol=1e-6)
+        want_ts = sum(gd["ts_ref"] for gd in gathered)
+        want_tr = sum(gd["tr_ref"] for gd in gathered)
+        for got_s, got_r in ((a_small, a_rows), (b_small, b_rows)):
+            ok &= torch.allclose(got_s, want_ts, atol=1e-6) and torch.allclose(got_r, want_tr, atol=1e-6)
         ok &= bool((m.xyz_gradient_accum == 3.0).all() and (m.denom == 2.0).all() and (m.max_radii2D == 5.0).all())
         out.put(ok)
     dist.barrier()
