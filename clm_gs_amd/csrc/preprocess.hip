@@ -17,12 +17,9 @@
 
 namespace clmgs {
 
-#ifndef CLMGS_PRE_PREFETCH_GSH
-#define CLMGS_PRE_PREFETCH_GSH 0  // 1: prefetch the SH gradient rows across the SH VJP (+48 VGPRs; measured slower)
-#endif
-#ifndef CLMGS_PRE_SCHED_BARRIER
-#define CLMGS_PRE_SCHED_BARRIER 0
-#endif
+// Measured and rejected for the backward (kept out of the code): requesting the SH rows before the
+// projection VJP (256 VGPRs), prefetching the SH gradient rows across the SH VJP (+48 VGPRs, 0.99 vs
+// 0.90 ms), 3 waves/SIMD via launch bounds (spills, 1.02 ms).
 constexpr int PP_ROWS = 64;   // one wavefront owns a chunk of 64 rows; no workgroup barriers
 constexpr int PP_PITCH = 52;  // floats per LDS row (see sh.hip)
 
@@ -238,8 +235,8 @@ struct PreGrads {
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
 };
 
-template <int DEG, bool EARLY, int WAVES, bool PK>
-__global__ void __launch_bounds__(PP_ROWS, WAVES)
+template <int DEG, bool PK>
+__global__ void __launch_bounds__(PP_ROWS, 2)
 preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
                       const float4* __restrict__ packed_grad, PreGrads o) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -307,7 +304,6 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);        \
     st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
   }
-    if (EARLY) { CLMGS_LAUNDER_LANE CLMGS_FOR12(CLMGS_LOAD_SH) }
     {
       const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
       my_row = -1; my_radius = 0;
@@ -350,24 +346,19 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     }
     if (!live) continue;  // wave-uniform: nothing of this chunk reached the screen
     // ---- SH rows -> LDS; their registers then prefetch the gradient rows to accumulate into
-    if (!EARLY) { CLMGS_LAUNDER_LANE CLMGS_FOR12(CLMGS_LOAD_SH) }  // register-lean variant: SH rows requested only now
+    { CLMGS_LAUNDER_LANE CLMGS_FOR12(CLMGS_LOAD_SH) }  // SH rows are requested only now (register-lean)
 #undef CLMGS_LOAD_SH
     wave_lds_sync();  // the previous chunk's LDS rows are consumed
 #define CLMGS_X(j)                                                                                  \
   if constexpr (j < NF4) {                                                                          \
     CLMGS_ELEM(j)                                                                                   \
     *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) = st##j;                                 \
-    const int rr = ((live >> r) & 1ull) ? r : first;                                                \
-    const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);    \
-    if (CLMGS_PRE_PREFETCH_GSH)                                                                     \
-      st##j = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);                 \
   }
     { CLMGS_LAUNDER_LANE
     CLMGS_FOR12(CLMGS_X)
     }
 #undef CLMGS_X
     wave_lds_sync();
-    if (CLMGS_PRE_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
     if (vis) {
       float* row = lds + t * PP_PITCH;
       // recompute the pre-clamp colour for the clamp mask, then the VJP
@@ -433,9 +424,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl(g_l, r) : (int64_t)(base + r);         \
     if ((live >> r) & 1ull) {                                                                       \
       const float4 v = *reinterpret_cast<const float4*>(lds + r * PP_PITCH + 4 * k);                \
-      float4 c = CLMGS_PRE_PREFETCH_GSH                                                             \
-                     ? st##j                                                                        \
-                     : *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);        \
+      float4 c = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);            \
       c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;                                               \
       *reinterpret_cast<float4*>(o.g_sh_rows + dst_row * 48 + 4 * k) = c;                           \
     }                                                                                               \
@@ -541,25 +530,20 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
              pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible};
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
-#define CLMGS_PRE_BWD(D, E, W)                                                                    \
+#define CLMGS_PRE_BWD(D)                                                                          \
   do {                                                                                             \
     if (pg)                                                                                        \
-      hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W, true>), dim3(grid), dim3(PP_ROWS), lds,   \
+      hipLaunchKernelGGL((preprocess_bwd_kernel<D, true>), dim3(grid), dim3(PP_ROWS), lds,         \
                          (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o);         \
     else                                                                                           \
-      hipLaunchKernelGGL((preprocess_bwd_kernel<D, E, W, false>), dim3(grid), dim3(PP_ROWS), lds,  \
+      hipLaunchKernelGGL((preprocess_bwd_kernel<D, false>), dim3(grid), dim3(PP_ROWS), lds,        \
                          (hipStream_t)stream, V, a, radii, (const float4*)packed_grad, o);         \
   } while (0)
-  static const int variant = getenv("CLMGS_PRE_VARIANT") ? atoi(getenv("CLMGS_PRE_VARIANT")) : 0;
   switch (degree) {
-    case 0: CLMGS_PRE_BWD(0, false, 3); break;
-    case 1: CLMGS_PRE_BWD(1, false, 3); break;
-    case 2: CLMGS_PRE_BWD(2, false, 2); break;
-    default:
-      if (variant == 1) CLMGS_PRE_BWD(3, true, 2);
-      else if (variant == 2) CLMGS_PRE_BWD(3, false, 3);
-      else CLMGS_PRE_BWD(3, false, 2);
-      break;
+    case 0: CLMGS_PRE_BWD(0); break;
+    case 1: CLMGS_PRE_BWD(1); break;
+    case 2: CLMGS_PRE_BWD(2); break;
+    default: CLMGS_PRE_BWD(3); break;
   }
 #undef CLMGS_PRE_BWD
   CLMGS_LAUNCH_CHECK();
