@@ -9,6 +9,11 @@ A "step" is one pass of the hot path over one batch of `bsz` cameras
 + sort / rasterize / loss / backward -> Adam).  N > 1: one process per GPU (launched by
 torch.distributed.run), camera data parallel, weak scaling (every rank renders its own bsz
 cameras; one gradient exchange per batch over RCCL).  Rank 0 prints ONE JSON line.
+
+`vs_baseline` = value / the reference's own published figure for the same configuration and
+strategy (derived there from published training time / iterations, measured
+on the reference's testbed, 1x RTX 4090 -- different hardware, stated in `baseline.source`); null
+for multi-GPU runs and for configurations the reference publishes nothing for.
 """
 import argparse
 import json
@@ -300,12 +305,19 @@ def main():
     A_img = 228 * n_rows + 636 * V_avg + (220 * V_avg if a.strategy == "clm_offload" else 0) + \
         (144 + 24 * p_pass) * I_avg + 143 * P + 4 * T
     adam_img = 1652.0 * N / bsz
+    # published numbers of BASELINE.md section 1 for exactly this (config, strategy), single GPU
+    published = {("rubble28m", "clm_offload"): 4.04, ("rubble28m", "naive_offload"): 2.45,
+                 ("rubble10m", "clm_offload"): 8.08, ("rubble10m", "no_offload"): 8.55,
+                 ("rubble10m", "naive_offload"): 4.49, ("bicycle6m", "no_offload"): 40.9,
+                 ("bicycle6m", "clm_offload"): 22.3, ("bicycle6m", "naive_offload"): 12.1}
+    ref_img_s = published.get((a.config, a.strategy)) if (world == 1 and a.residency == "hbm") else None
+    vs_baseline = round(value / ref_img_s, 3) if ref_img_s else None
     out = {
         "metric": "training images/s (Rubble-4K 28M Gaussians clm_offload)" if a.config == "rubble28m"
         else f"training images/s ({a.config} {a.strategy})",
         "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
@@ -316,7 +328,9 @@ def main():
         "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1),
                            "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),
                            "frac_of_8TBps": round((A_img + adam_img) * value / world / 8e12, 5)},
-        "reference_rtx4090_img_s": 4.04 if a.config == "rubble28m" else None,
+        "baseline": {"img_s": ref_img_s, "source": "BASELINE.md section 1 (reference's own testbed: 1x RTX 4090 + "
+                     "16-core host; img/s derived there from published training time / iterations)"}
+        if ref_img_s else None,
         "roofline": roofline, "kernels": kernels,
     }
     if not a.no_cpu_baseline and world == 1:
