@@ -529,3 +529,37 @@ def test_visibility_select_equals_radii_nonzero(dev):
         for c in range(3):
             assert torch.equal(filters[c], torch.nonzero(radii[c] > 0).flatten())
         assert torch.equal(union, torch.nonzero((radii > 0).any(dim=0)).flatten())
+
+
+def test_rasterize_with_no_intersections(dev):
+    """Edge case: nothing lands on the image.  Forward = background / alpha 0, backward = exact zeros,
+    through both accumulation modes of the C ABI."""
+    from clm_gs_amd import _lib, gsplat as G
+    from clm_gs_amd._lib import check, dptr, stream
+    L = _lib.lib()
+    w, h, n = 40, 23, 50
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    m2 = torch.full((1, n, 2), -500.0, device=dev)           # far off screen
+    radii = torch.zeros((1, n), dtype=torch.int32, device=dev)  # culled
+    depths = torch.ones((1, n), device=dev)
+    fids, off, _, (slot, order, cum) = G.isect_tiles_two_level(m2, radii, depths, 16, tw, th, want_slots=True)
+    assert fids.numel() == 0 and int(off.abs().sum()) == 0 and int(cum[-1]) == 0
+    packed = torch.zeros(n, 16, device=dev)
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device=dev)
+    out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
+    last = torch.empty(1, h, w, dtype=torch.int32, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, n, 0, None, None, None, None, dptr(bg), w, h, 16, tw, th, dptr(off),
+                                None, dptr(packed), dptr(out), dptr(al), dptr(last)))
+    assert torch.equal(out[0], bg.expand(h, w, 3)) and float(al.abs().max()) == 0.0
+    vi = torch.randn(1, h, w, 3, device=dev)
+    for slots in (False, True):
+        pg = torch.full((n, 16), float("nan"), device=dev)
+        parts = torch.empty((1, 16), device=dev)
+        outs = [torch.full((n, 2), 7.0, device=dev), torch.full((n, 3), 7.0, device=dev),
+                torch.full((n, 3), 7.0, device=dev), torch.full((n,), 7.0, device=dev)]
+        check(L.clmgs_rasterize_bwd(stream(), 1, n, 0, dptr(packed), dptr(bg), w, h, 16, tw, th, dptr(off), None,
+                                    dptr(al), dptr(last), dptr(vi), None, dptr(pg), *[dptr(x) for x in outs],
+                                    *((dptr(slot, torch.int32, True), dptr(order), dptr(cum), dptr(parts)) if slots
+                                      else (None,) * 4)))
+        for x in outs:
+            assert float(x.abs().max()) == 0.0
