@@ -40,6 +40,9 @@ CONFIGS = {
 
 # algorithmic bytes per launch of each kernel: n rows in, V visible, I
 # intersections, P pixels, T tiles.  Used for roofline.achieved = bytes / measured duration.
+# I is the REFERENCE's intersection count (gsplat.isect_tiles: 3-sigma tile boxes) -- the work the
+# algorithm defines; the list this build actually sorts and blends after exact per-tile culling
+# is reported beside it as I_emitted_avg.
 ALGO_BYTES = {
     "clmgs_projection_fwd": lambda n, V, I, P, T: 68 * n,
     "clmgs_projection_bwd": lambda n, V, I, P, T: 132 * n,
@@ -243,6 +246,7 @@ def main():
     if not a.no_kernel_timing:
         _lib.TIMING = {}
     _lib.STATS["n_isects"].clear()
+    _lib.STATS["n_emitted"].clear()
     sparsities = []
     t0 = time.perf_counter()
     for b in range(a.warmup, a.warmup + a.steps):
@@ -261,6 +265,8 @@ def main():
     n_images = a.steps * bsz
     isects = _lib.STATS["n_isects"][-n_images:] if a.strategy == "clm_offload" else _lib.STATS["n_isects"]
     I_avg = sum(isects) / max(1, len(isects))
+    emitted = _lib.STATS["n_emitted"][-n_images:] if a.strategy == "clm_offload" else _lib.STATS["n_emitted"]
+    I_emitted = sum(emitted) / max(1, len(emitted))
     V_avg = (sum(sparsities) / max(1, len(sparsities))) * N if sparsities else float(N)
     n_rows = V_avg if a.strategy == "clm_offload" else float(N)
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
@@ -324,6 +330,7 @@ def main():
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac},
         "peak_gpu_bytes": int(peak),
         "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
+                     "I_emitted_avg": round(I_emitted, 1),
                      "pixels": P, "tiles": T, "loss_last": float(losses[-1])},
         "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1),
                            "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),

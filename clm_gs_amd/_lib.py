@@ -33,7 +33,7 @@ SIGNATURES = {
     "clmgs_isect_emit_sort": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "clmgs_isect_offsets": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
     "clmgs_isect2_order_temp_bytes": (_sz, [_i]),
-    "clmgs_isect2_order_count": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz]),
+    "clmgs_isect2_order_count": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_isect2_sort_temp_bytes": (_sz, [_i64]),
     "clmgs_isect2_emit_sort": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_rasterize_pack_bytes": (_sz, [_i, _i]),
@@ -72,7 +72,7 @@ _lib = None
 # stream-taking call is bracketed by two events recorded on the stream it is launched on.
 TIMING = None
 # Data-dependent sizes seen by the front end (intersections per image), for the same purpose.
-STATS = {"n_isects": []}
+STATS = {"n_isects": [], "n_emitted": []}
 
 
 class ClmgsError(RuntimeError):

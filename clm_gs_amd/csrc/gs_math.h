@@ -305,6 +305,27 @@ CLMGS_HD void sh_basis_grad(int deg, float x, float y, float z, float Bx[16], fl
   Bx[15] = c30 * (3.f * xx - 3.f * yy); By[15] = c30 * (-6.f * xy);        Bz[15] = 0.f;
 }
 
+// ------------------------------------------------ exact footprint tests (culling)
+// min over t in [lo, hi] of  q = 0.5 * (Af * f^2 + 2 * B * f * t + Ct * t^2)   (f fixed, Ct > 0)
+CLMGS_HD float edge_min_sigma(float Af, float B, float Ct, float rcpCt, float f,
+                                                float lo, float hi) {
+  const float t = fminf(fmaxf(-B * f * rcpCt, lo), hi);
+  return 0.5f * (Af * f * f + (2.f * B * f + Ct * t) * t);
+}
+
+// Exact minimum of sigma(d) = 0.5 (a dx^2 + 2 b dx dy + c dy^2) over the rectangle
+// [ux0, ux1] x [vy0, vy1] of offsets from the Gaussian centre (convex: 0 if the centre is inside,
+// otherwise attained on one of the four edges).
+CLMGS_HD float rect_min_sigma(float ca, float cb, float cc, float rca, float rcc,
+                                                float ux0, float ux1, float vy0, float vy1) {
+  if (ux0 <= 0.f && ux1 >= 0.f && vy0 <= 0.f && vy1 >= 0.f) return 0.f;
+  const float e0 = edge_min_sigma(ca, cb, cc, rcc, ux0, vy0, vy1);
+  const float e1 = edge_min_sigma(ca, cb, cc, rcc, ux1, vy0, vy1);
+  const float e2 = edge_min_sigma(cc, cb, ca, rca, vy0, ux0, ux1);
+  const float e3 = edge_min_sigma(cc, cb, ca, rca, vy1, ux0, ux1);
+  return fminf(fminf(e0, e1), fminf(e2, e3));
+}
+
 // ------------------------------------------------------------- alpha blend
 // One (pixel, Gaussian) evaluation.  Returns false when the pair is skipped
 // (sigma < 0 or alpha < 1/255).  dx,dy = mean - pixel centre.

@@ -191,37 +191,87 @@ __device__ __forceinline__ unsigned long long pack_box(const TileBox& b) {
          ((unsigned long long)b.x1 << 32) | ((unsigned long long)b.y1 << 48);
 }
 
-// Row order (coalesced): depth key, identity payload and the row's tile box -- the only place the
-// means / radii are read; count and emit then work from 8 B boxes (one gather in depth order,
-// afterwards sequential) instead of re-gathering two arrays each.
+// Tile mask of a row: bit t of the (row-major) tiles of its box is set when alpha >= 1/255 is
+// reachable somewhere on the tile -- the exact minimum of sigma over the tile's rectangle of pixel
+// centres against ln(255 o), the same test (and margin) the tile kernels apply per 8x8 quadrant.
+// Boxes of more than 64 tiles and degenerate conics are not culled (mask = all ones).
+__device__ __forceinline__ unsigned long long exact_tile_mask(const float4* __restrict__ rec, int x0,
+                                                              int y0, int x1, int y1) {
+  const int bw = x1 - x0, nt = bw * (y1 - y0);
+  if (nt > 64) return ~0ull;
+  const float4 A = rec[0], B = rec[1];  // x y opacity ca | cb cc . .
+  const float mx = A.x, my = A.y, opac = A.z, ca = A.w, cb = B.x, cc = B.y;
+  if (!(opac >= 1.f / 255.f)) return 0ull;
+  const float det = ca * cc - cb * cb;
+  const float Lm = __logf(255.f * opac) * 1.0001f + 1e-4f;
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f) || !(Lm == Lm)) return ~0ull;
+  const float rca = __builtin_amdgcn_rcpf(ca), rcc = __builtin_amdgcn_rcpf(cc);
+  unsigned long long m = 0ull;
+  int t = 0;
+  for (int ty = y0; ty < y1; ++ty) {
+    const float v0 = (float)(ty * 16) + 0.5f - my, v1 = v0 + 15.f;
+    for (int tx = x0; tx < x1; ++tx, ++t) {
+      const float u0 = (float)(tx * 16) + 0.5f - mx, u1 = u0 + 15.f;
+      if (rect_min_sigma(ca, cb, cc, rca, rcc, u0, u1, v0, v1) <= Lm) m |= 1ull << t;
+    }
+  }
+  return m;
+}
+
+// Row order (coalesced): depth key, identity payload, the row's tile box and tile mask -- the only
+// place the means / radii / raster records are read; count and emit then work from 16 B per row
+// (one gather in depth order, afterwards sequential) instead of re-gathering the arrays.
+// packed == NULL: no exact culling (mask all ones, the gsplat.isect_tiles list).
 __global__ void __launch_bounds__(256)
 isect2_keys_kernel(int V, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-                   const float* __restrict__ means2d, float tile_size, int tile_w, int tile_h,
-                   uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                   unsigned long long* __restrict__ box_by_row) {
+                   const float* __restrict__ means2d, const float4* __restrict__ packed,
+                   float tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys,
+                   int32_t* __restrict__ vals, unsigned long long* __restrict__ box_by_row) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     const int r = radii[i];
     keys[i] = r > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
     vals[i] = i;
-    unsigned long long b = 0ull;
+    unsigned long long b = 0ull, m = ~0ull;
     if (r > 0) {
-      const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
-      b = pack_box(tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h));
+      const float2 mm = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
+      const TileBox tb = tile_box(mm.x, mm.y, (float)r, tile_size, tile_w, tile_h);
+      b = pack_box(tb);
+      if (packed) m = exact_tile_mask(packed + 4 * (size_t)i, tb.x0, tb.y0, tb.x1, tb.y1);
     }
-    box_by_row[i] = b;
+    box_by_row[2 * (size_t)i] = b;
+    box_by_row[2 * (size_t)i + 1] = m;
   }
 }
 
+// boxes[2*j] = packed box of rank j (0 = nothing to emit), boxes[2*j+1] = its tile mask;
+// ref_total accumulates the UN-culled intersection count.
 __global__ void __launch_bounds__(256)
 isect2_count_kernel(int V, const int32_t* __restrict__ order,
                     const unsigned long long* __restrict__ box_by_row,
-                    unsigned long long* __restrict__ box_by_rank, int64_t* __restrict__ cum) {
+                    unsigned long long* __restrict__ boxes, int64_t* __restrict__ cum,
+                    unsigned long long* __restrict__ ref_total) {
+  unsigned long long ref = 0ull;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
-    const unsigned long long b = box_by_row[order[j]];
+    const int i = order[j];
+    const unsigned long long b = box_by_row[2 * (size_t)i], m = box_by_row[2 * (size_t)i + 1];
     const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
     const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
-    box_by_rank[j] = b;
-    cum[j] = (int64_t)(x1 - x0) * (y1 - y0);
+    const int nt = (x1 - x0) * (y1 - y0);
+    const int cnt = nt <= 64 ? __popcll(m & (nt == 64 ? ~0ull : ((1ull << nt) - 1ull))) : nt;
+    boxes[2 * (size_t)j] = cnt > 0 ? b : 0ull;
+    boxes[2 * (size_t)j + 1] = m;
+    cum[j] = cnt;
+    ref += (unsigned long long)nt;
+  }
+  if (ref_total) {  // one atomic per BLOCK: same-address atomics serialise at the memory side
+    __shared__ unsigned long long wsum[4];
+    ref = (unsigned long long)wave_sum_i64((long long)ref);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ref;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (tot) atomicAdd(ref_total, tot);
+    }
   }
 }
 
@@ -231,18 +281,22 @@ isect2_count_kernel(int V, const int32_t* __restrict__ order,
 // rank order sums each contiguous range: no float atomics, deterministic.
 __global__ void __launch_bounds__(256)
 isect2_emit_kernel(int V, const int32_t* __restrict__ order,
-                   const unsigned long long* __restrict__ box_by_rank,
+                   const unsigned long long* __restrict__ boxes,
                    const int64_t* __restrict__ cum, int tile_w, uint32_t* __restrict__ tkeys,
                    int32_t* __restrict__ vals, int2* __restrict__ vals2) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
-    const unsigned long long b = box_by_rank[j];
+    const unsigned long long b = boxes[2 * (size_t)j];
     if (b == 0ull) continue;
+    const unsigned long long m = boxes[2 * (size_t)j + 1];
     const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
     const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
+    const bool masked = (x1 - x0) * (y1 - y0) <= 64;
     const int i = order[j];
     int64_t cur = (j == 0) ? 0 : cum[j - 1];
+    int t = 0;
     for (int ty = y0; ty < y1; ++ty)
-      for (int tx = x0; tx < x1; ++tx) {
+      for (int tx = x0; tx < x1; ++tx, ++t) {
+        if (masked && !((m >> t) & 1ull)) continue;
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
         if (vals2) vals2[cur] = make_int2(i, (int)cur);
         else vals[cur] = i;
@@ -280,21 +334,24 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
 
 extern "C" size_t clmgs_isect2_order_temp_bytes(int V) {
   if (V <= 0) return 256;
-  return 4 * align_up((size_t)V * 4, 256) + align_up((size_t)V * 8, 256) + radix_table_bytes(V) +
+  return 4 * align_up((size_t)V * 4, 256) + align_up((size_t)V * 16, 256) + radix_table_bytes(V) +
          scan_scratch_bytes(V) + 256;
 }
 
 // order[V] i32 (rows by depth, culled last), cum[V] i64 (inclusive tile counts in that order),
-// boxes[V] u64 (packed tile box of every rank, 0 = culled; input of clmgs_isect2_emit_sort).
+// boxes[2V] u64 (packed tile box + tile mask of every rank, box 0 = nothing to emit; input of
+// clmgs_isect2_emit_sort), totals[2] i64 device = {intersections to emit, un-culled count}.
+// packed != NULL (the [V,16] raster records): exact per-tile culling.
 extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2d,
                                         const int32_t* radii, const float* depths, int tile_size,
-                                        int tile_width, int tile_height, int32_t* order,
-                                        int64_t* cum, uint64_t* boxes, void* temp,
-                                        size_t temp_bytes) {
+                                        int tile_width, int tile_height, const void* packed,
+                                        int32_t* order, int64_t* cum, uint64_t* boxes,
+                                        int64_t* totals, void* temp, size_t temp_bytes) {
   CLMGS_CHECK_ARG(V >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
   CLMGS_CHECK_ARG(tile_width < 65536 && tile_height < 65536);
   if (V == 0) return 0;
-  CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && boxes && temp);
+  CLMGS_CHECK_ARG(means2d && radii && depths && order && cum && boxes && totals && temp);
+  CLMGS_CHECK_ARG(!packed || tile_size == 16);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_isect2_order_temp_bytes(V));
   hipStream_t s = (hipStream_t)stream;
   char* base = (char*)temp;
@@ -302,20 +359,25 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   uint32_t* k_b = (uint32_t*)base; base += align_up((size_t)V * 4, 256);
   int32_t* v_a = (int32_t*)base; base += align_up((size_t)V * 4, 256);
   int32_t* v_b = (int32_t*)base; base += align_up((size_t)V * 4, 256);
-  unsigned long long* box_by_row = (unsigned long long*)base; base += align_up((size_t)V * 8, 256);
+  unsigned long long* box_by_row = (unsigned long long*)base; base += align_up((size_t)V * 16, 256);
   uint32_t* table = (uint32_t*)base; base += radix_table_bytes(V);
   int64_t* scan_tmp = (int64_t*)base;
   const int grid = min(ceil_div(V, 256), 256 * 16);
   hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, means2d,
-                     (float)tile_size, tile_width, tile_height, k_a, v_a, box_by_row);
+                     (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a,
+                     box_by_row);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
   if (rc) return rc;
-  hipLaunchKernelGGL(isect2_count_kernel, dim3(grid), dim3(256), 0, s, V, order, box_by_row,
-                     (unsigned long long*)boxes, cum);
+  CLMGS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), s));
+  hipLaunchKernelGGL(isect2_count_kernel, dim3(min(grid, 1024)), dim3(256), 0, s, V, order, box_by_row,
+                     (unsigned long long*)boxes, cum, (unsigned long long*)(totals + 1));
   CLMGS_LAUNCH_CHECK();
-  return inclusive_scan_i64(s, V, cum, scan_tmp);
+  rc = inclusive_scan_i64(s, V, cum, scan_tmp);
+  if (rc) return rc;
+  CLMGS_HIP(hipMemcpyAsync(totals, cum + (V - 1), sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  return 0;
 }
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {

@@ -89,7 +89,8 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
         dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
     fids, offsets, _, (emit_slot, order, cum) = isect_tiles_two_level(
-        means2d, radii, depths, TILE, tw, th, want_slots=True)
+        means2d, radii, depths, TILE, tw, th, want_slots=True,
+        packed=packed if getattr(args, "exact_tile_cull", True) else None)
     out = torch.empty((H, W, 3), dtype=F32, device=dev)
     alphas = torch.empty((H, W), dtype=F32, device=dev)
     last_ids = torch.empty((H, W), dtype=I32, device=dev)

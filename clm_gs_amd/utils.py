@@ -46,7 +46,7 @@ def default_args(**over):
         # this build: fused front-end kernels + no autograd tape inside the engines (fused.py);
         # False = the op-by-op gsplat/clm_kernels chain the reference engines spell out
         fused_front_end=True,
-        overlap_cameras=True, overlap_lanes=2, packed_small=True, packed_stats=True,
+        overlap_cameras=True, overlap_lanes=2, packed_small=True, packed_stats=True, exact_tile_cull=True,
         lazy_dense_adam=True,   # HBM rows: replay zero-gradient Adam steps on demand (exact)   # two cameras of a batch in flight on two HIP streams
     )
     for k, v in over.items():

@@ -111,8 +111,8 @@ int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids
 size_t clmgs_isect2_order_temp_bytes(int V);
 int clmgs_isect2_order_count(void* stream, int V, const float* means2d, const int32_t* radii,
                              const float* depths, int tile_size, int tile_width, int tile_height,
-                             int32_t* order, int64_t* cum, uint64_t* boxes, void* temp,
-                             size_t temp_bytes);
+                             const void* packed, int32_t* order, int64_t* cum, uint64_t* boxes,
+                             int64_t* totals, void* temp, size_t temp_bytes);
 size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects);
 int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
                            const int32_t* order, const int64_t* cum, const uint64_t* boxes,
