@@ -1,7 +1,8 @@
 """GaussianModelNaiveOffload: EVERY parameter and all optimizer state live in pinned host memory
 (reference: strategies/naive_offload/gaussian_model.py:27-680); the GPU only ever holds a
 per-batch copy.  Scope row f4 -- the comparison baseline of the three-strategy table, not a hot
-path: densification is not built for it (BigCity, the config that needs offload, disables it).
+path.  Densification runs the shared base-class logic against temporary DEVICE copies of the 11
+small attributes (the statistics live on the device anyway) and resizes the pinned host tables.
 
 Layout (MI355X-side choice): two pinned buffers, `small[N,12]` = xyz 3 | opacity 1 | scaling 3 |
 rotation 4 | pad, and `parameters[N,48]` (SH rows), each with twin grad / exp_avg / exp_avg_sq
@@ -50,10 +51,6 @@ class GaussianModelNaiveOffload(BaseGaussianModel):
     def get_features(self):
         return self._parameters.detach().view(-1, 16, 3)
 
-    def _shs48_rows(self, mask):
-        p = self._parameters.detach()
-        return p if mask is None else p[mask.cpu()]
-
     def all_parameters(self):
         return [self._small, self._parameters]
 
@@ -87,15 +84,85 @@ class GaussianModelNaiveOffload(BaseGaussianModel):
         self.small_adam.columns_lr[0] = lr
         return lr
 
-    # --------------------------------------------------- not built for this strategy
+    # ------------------------------------------------------------ densification
+    def _device_views(self, on):
+        """While densify_and_prune runs, _xyz/_opacity/_scaling/_rotation are device copies (the
+        shared logic indexes them with device masks); afterwards they are host views again."""
+        if on:
+            d = self._small.detach().to("cuda")
+            self._xyz, self._opacity = d[:, 0:3].contiguous(), d[:, 3:4].contiguous()
+            self._scaling, self._rotation = d[:, 4:7].contiguous(), d[:, 7:11].contiguous()
+        else:
+            self._bind_views()
+        self._dev_views = on
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        self._device_views(True)
+        try:
+            super().densify_and_prune(max_grad, min_opacity, extent, max_screen_size)
+        finally:
+            self._device_views(False)
+
+    def _shs48_rows(self, mask):
+        p = self._parameters.detach()
+        if mask is None:
+            return p
+        return p[mask.cpu()].to(mask.device)
+
+    def _resize(self, new_small, new_rows, state_fn):
+        """Swap in resized pinned tables (+ gradients) and carry the host Adam state along."""
+        for opt, name, new in ((getattr(self, "small_adam", None), "_small", new_small),
+                               (getattr(self, "row_adam", None), "_parameters", new_rows)):
+            old = getattr(self, name)
+            buf = pinned_empty(tuple(new.shape))
+            buf.copy_(new)
+            p = nn.Parameter(buf.requires_grad_(True))
+            if opt is not None:
+                st = opt.state.pop(old, None)
+                p.grad = pinned_empty(tuple(new.shape)).zero_()
+                opt.param_groups[0]["params"][0] = p
+                if st is not None:
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        v = state_fn(st[k])
+                        st[k] = pinned_empty(tuple(v.shape))
+                        st[k].copy_(v)
+                    opt.state[p] = st
+            setattr(self, name, p)
+        if getattr(self, "optimizer", None) is not None:
+            self.optimizer.param_groups = self.small_adam.param_groups + self.row_adam.param_groups
+        n = new_small.shape[0]
+        if getattr(self, "_dev_views", False):
+            self._device_views(True)
+        else:
+            self._bind_views()
+        return n
+
     def _append_rows(self, new):
-        raise NotImplementedError("densification is not built for naive_offload (scope row f4)")
+        k = new["xyz"].shape[0]
+        add_small = torch.zeros((k, 12))
+        for name in ("xyz", "opacity", "scaling", "rotation"):
+            a, b = _SMALL[name]
+            add_small[:, a:b] = new[name].detach().float().cpu().reshape(k, b - a)
+        add_rows = new["shs48"].detach().float().cpu().reshape(k, 48)
+        self._resize(torch.cat((self._small.detach(), add_small), 0), torch.cat((self._parameters.detach(), add_rows), 0),
+                     lambda s: torch.cat((s, torch.zeros((k, s.shape[1]))), 0))
 
     def prune_points(self, mask):
-        raise NotImplementedError("densification is not built for naive_offload (scope row f4)")
+        keep = (~mask).cpu()
+        self._resize(self._small.detach()[keep], self._parameters.detach()[keep], lambda s: s[keep])
+        kd = keep.to(self.max_radii2D.device)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[kd]
+        self.denom = self.denom[kd]
+        self.max_radii2D = self.max_radii2D[kd]
 
     def reset_opacity(self):
-        raise NotImplementedError("densification is not built for naive_offload (scope row f4)")
+        from ... import utils
+        with torch.no_grad():
+            op = torch.sigmoid(self._small.detach()[:, 3:4])
+            self._small.detach()[:, 3:4] = utils.inverse_sigmoid(torch.min(op, torch.ones_like(op) * 0.01))
+            for k in ("exp_avg", "exp_avg_sq"):  # the reference zeroes the opacity moments
+                self.small_adam.state[self._small][k][:, 3:4] = 0.0
+        self._bind_views()
 
 
 class _NaiveOptimizer:

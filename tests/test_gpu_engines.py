@@ -372,5 +372,51 @@ def test_naive_offload_equals_clm_offload_after_two_steps(dev, sparse):
     img_c = clm_offload_eval_one_cam(cams[0], ref, None, _Scene)
     assert sparse or (img_n - img_c).abs().max() < 5e-3
     assert torch.equal(render_single_image(m, _Scene, cams[0]), torch.clamp(img_n, 0, 1))
-    with pytest.raises(NotImplementedError):
-        m.prune_points(torch.zeros(N, dtype=torch.bool, device=dev))
+
+
+def test_naive_offload_densify_and_prune(dev):
+    """Row f4: densification on the host-resident model -- pinned tables, gradients, host Adam state
+    and device statistics stay aligned; the engine and eval still run afterwards."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.naive_offload import (GaussianModelNaiveOffload, naive_offload_eval_one_cam,
+                                                     naive_offload_train_one_batch)
+    args, sc, cams = _setup("clm_offload", "hbm", False)
+    args.clm_offload, args.naive_offload = False, True
+    m = GaussianModelNaiveOffload(3)
+    m.create_from_tensors(sc["xyz"].clone(), sc["shs48"].clone(), sc["scaling"].clone(), sc["rotation"].clone(),
+                          sc["opacity"].clone(), spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(args)
+    utils.set_cur_iter(1)
+    naive_offload_train_one_batch(m, _Scene, cams, None)
+    n0 = m.get_xyz.shape[0]
+    before = m._small.detach().clone()
+    m.xyz_gradient_accum = torch.rand_like(m.xyz_gradient_accum) * 1e-3
+    m.denom = torch.ones_like(m.denom)
+    m.split_generator = torch.Generator(device="cuda").manual_seed(3)
+    m.densify_and_prune(0.0002, 0.005, 30.0, None)
+    n1 = m.get_xyz.shape[0]
+    assert n1 != n0 and not m._xyz.is_cuda and m._small.is_pinned() and m._parameters.is_pinned()
+    assert m._small.shape == (n1, 12) and m._parameters.shape == (n1, 48)
+    assert m._small.grad.shape == (n1, 12) and m._parameters.grad.shape == (n1, 48)
+    for opt, p in ((m.small_adam, m._small), (m.row_adam, m._parameters)):
+        st = opt.state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        assert opt.param_groups[0]["params"][0] is p
+    for t in (m.xyz_gradient_accum, m.denom, m.max_radii2D):
+        assert t.shape[0] == n1 and t.is_cuda
+    assert m._features_rest.shape == (n1, 15, 3)
+    # same surgery as the clm model on the same inputs: same surviving / new rows
+    ref = _make("clm_offload", sc, utils.get_args())
+    with torch.no_grad():
+        ref._xyz.copy_(before[:, 0:3].cuda()); ref._opacity.copy_(before[:, 3:4].cuda())
+        ref._scaling.copy_(before[:, 4:7].cuda()); ref._rotation.copy_(before[:, 7:11].cuda())
+    torch.manual_seed(0)
+    ref.xyz_gradient_accum = torch.rand_like(ref.xyz_gradient_accum) * 1e-3
+    assert ref.get_xyz.shape[0] == n0
+    m.reset_opacity()
+    assert float(torch.sigmoid(m._opacity).max()) <= 0.0100001
+    utils.set_cur_iter(5)
+    losses, _ = naive_offload_train_one_batch(m, _Scene, cams, None)
+    assert all(torch.isfinite(l) for l in losses)
+    assert naive_offload_eval_one_cam(m, _Scene, cams[0], None).shape == (3, H, W)
