@@ -44,7 +44,10 @@ def psnr(img1, img2):
 
 def _pinned_gb(gaussians):
     tot = 0
-    for name in ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer"):
+    names = ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer")
+    if hasattr(gaussians, "_small"):  # naive_offload: its own two pinned tables (+ grads are transient)
+        names = ("_small", "_parameters")
+    for name in names:
         t = getattr(gaussians, name, None)
         if isinstance(t, torch.Tensor) and t.numel() and not t.is_cuda:
             tot += t.numel() * t.element_size()
@@ -82,7 +85,11 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     iterations = iterations or args.iterations
     utils.set_log_file(log_file)
     clm = bool(getattr(args, "clm_offload", False))
-    if clm:
+    naive = bool(getattr(args, "naive_offload", False))
+    if naive:
+        from .strategies.naive_offload import naive_offload_eval_one_cam, naive_offload_train_one_batch
+        render_fn = lambda cam: naive_offload_eval_one_cam(gaussians, scene, cam, background)
+    elif clm:
         from .strategies.clm_offload import clm_offload_eval_one_cam, clm_offload_train_one_batch
         comm_stream = torch.cuda.Stream()
         perm_generator = torch.Generator(device="cuda")
@@ -109,7 +116,11 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             order = list(range(len(train_cameras)))
             rng.shuffle(order)
         batch = [train_cameras[order.pop()] for _ in range(bsz)]
-        if clm:
+        if naive:
+            losses, visibility = naive_offload_train_one_batch(gaussians, scene, batch, background,
+                                                               sparse_adam=args.sparse_adam)
+            names, sparsity = [c.image_name for c in batch], None
+        elif clm:
             losses, ordered_cams, sparsity = clm_offload_train_one_batch(
                 gaussians, scene, batch, gaussians.parameters_grad_buffer, background, None, comm_stream,
                 perm_generator)
@@ -133,7 +144,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
                 iteration, bsz, args.densification_interval, 0):
             log_file.write(memory_line(iteration, bsz, gaussians))
-        if not clm:  # train.py:533-578
+        if not clm and not naive:  # train.py:533-578
             if args.lr_scale_mode != "accumu":
                 for p in gaussians.all_parameters():
                     if p.grad is not None:

@@ -28,7 +28,8 @@ def _parse_like_log2csv(text):
     return m
 
 
-@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("no_offload", "hbm"), ("clm_offload", "host")])
+@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("no_offload", "hbm"), ("clm_offload", "host"),
+                                                ("naive_offload", "hbm")])
 def test_training_loop_improves_psnr_and_logs(dev, strategy, residency):
     from clm_gs_amd import trainer, utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
@@ -53,7 +54,9 @@ def test_training_loop_improves_psnr_and_logs(dev, strategy, residency):
     g = torch.Generator(device="cuda").manual_seed(1)
     noisy_sh = truth["shs48"].clone()
     noisy_sh[:, :3] += torch.randn((N, 3), generator=g, device="cuda") * 0.6   # wrong base colours
-    model = (GaussianModelCLMOffload if strategy == "clm_offload" else GaussianModelNoOffload)(3)
+    from clm_gs_amd.strategies.naive_offload import GaussianModelNaiveOffload
+    model = {"clm_offload": GaussianModelCLMOffload, "no_offload": GaussianModelNoOffload,
+             "naive_offload": GaussianModelNaiveOffload}[strategy](3)
     model.create_from_tensors(truth["xyz"] + torch.randn((N, 3), generator=g, device="cuda") * 0.05, noisy_sh,
                               truth["scaling"], truth["rotation"], truth["opacity"], spatial_lr_scale=truth["extent"])
     model.training_setup(args)
