@@ -4,6 +4,7 @@ i.e. the TRANSPOSE of the 4x4 world->camera matrix), K, camtoworlds,
 original_image (uint8 [3,H,W] on the GPU), image_name, create_k_on_gpu()."""
 import math
 
+import numpy as np
 import torch
 
 
@@ -18,7 +19,14 @@ class Camera:
         self.world_view_transform = w2c.t().contiguous().to(device)
         self.original_image = image_u8.to(device) if image_u8 is not None else None
         self.K = self.create_k_on_gpu(device)
-        self.camtoworlds = torch.inverse(w2c)[None].to(device)  # [1,4,4] as train.py:293-301
+        c2w = torch.inverse(w2c)
+        self.camtoworlds = c2w[None].to(device)  # [1,4,4] as train.py:293-301
+        # host copies of the per-camera constants the kernels take by value (fused._cam_host would
+        # otherwise read them back from the device: three blocking copies per new camera)
+        k_host = self.create_k_on_gpu("cpu")
+        self._clmgs_host = (np.ascontiguousarray(w2c.numpy().astype(np.float32).reshape(16)),
+                            np.ascontiguousarray(k_host.numpy().astype(np.float32).reshape(9)),
+                            np.ascontiguousarray(c2w[:3, 3].numpy().astype(np.float32).reshape(3)))
 
     def create_k_on_gpu(self, device="cuda"):
         fx = self.image_width / (2 * math.tan(self.FoVx * 0.5))

@@ -374,10 +374,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   hipLaunchKernelGGL(isect2_count_kernel, dim3(min(grid, 1024)), dim3(256), 0, s, V, order, box_by_row,
                      (unsigned long long*)boxes, cum, (unsigned long long*)(totals + 1));
   CLMGS_LAUNCH_CHECK();
-  rc = inclusive_scan_i64(s, V, cum, scan_tmp);
-  if (rc) return rc;
-  CLMGS_HIP(hipMemcpyAsync(totals, cum + (V - 1), sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-  return 0;
+  return inclusive_scan_i64(s, V, cum, scan_tmp, totals);  // totals[0] = cum[V-1], no extra copy
 }
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {

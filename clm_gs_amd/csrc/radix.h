@@ -18,12 +18,11 @@
 namespace clmgs {
 
 constexpr int RS_THREADS = 256;
-// Keys per thread.  8 (2048 keys per block, 32 KB of LDS with 4 B payloads) is the fastest solo;
-// 8 B payloads use 4 (1024 keys, 20 KB of LDS instead of 42 KB): the tile sort runs concurrently
-// with the alpha-blend kernels, whose small blocks keep ~120 KB of each CU's LDS occupied, and a
-// 42 KB block was starved for minutes of kernel time (1.03 ms per pass instead of 0.12 ms solo).
-template <typename ValT> struct RsItems { static constexpr int value = sizeof(ValT) > 4 ? 4 : 8; };
-constexpr int RS_MIN_CHUNK = RS_THREADS * 4;
+// Keys per thread: 4 (1024 keys per block, 12-20 KB of LDS).  8 is ~10 % faster solo, but the
+// sorts run concurrently with the alpha-blend kernels, whose small blocks keep most of each CU's
+// LDS and registers occupied: 35-42 KB blocks were starved (1-2 ms per pass instead of 0.03-0.12).
+constexpr int RS_DEFAULT_ITEMS = 4;
+constexpr int RS_MIN_CHUNK = RS_THREADS * RS_DEFAULT_ITEMS;
 
 template <typename KeyT, int RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
@@ -43,16 +42,20 @@ radix_hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int n_blo
   table[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of every digit's row of the [256][n_blocks] table (block d = digit d) + row totals
-__global__ void __launch_bounds__(1024)
+// exclusive scan of every digit's row of the [256][n_blocks] table (block d = digit d) + row totals.
+// 256-thread blocks on purpose (like every kernel of the binning chain): next to the alpha-blend
+// kernels, whose one-wave blocks refill every freed wave slot, a 1024-thread block (16 slots on ONE
+// CU at once) was not dispatched until the tile kernel had drained -- 1.5 ms instead of 5 us.
+constexpr int RS_SCAN_THREADS = 256;
+__global__ void __launch_bounds__(RS_SCAN_THREADS)
 radix_scan_rows_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __restrict__ row_tot) {
-  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t wsum[RS_SCAN_THREADS / 64];
   __shared__ uint32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * n_blocks;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int base = 0; base < n_blocks; base += 1024) {
+  for (int base = 0; base < n_blocks; base += RS_SCAN_THREADS) {
     const int i = base + threadIdx.x;
     const uint32_t v = i < n_blocks ? row[i] : 0u;
     uint32_t x = v;  // inclusive scan inside the wave
@@ -68,7 +71,7 @@ radix_scan_rows_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __r
     const uint32_t carry = carry_s;
     if (i < n_blocks) row[i] = carry + woff + x - v;
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    if (threadIdx.x == RS_SCAN_THREADS - 1) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (threadIdx.x == 0) row_tot[blockIdx.x] = carry_s;
@@ -199,11 +202,10 @@ static inline size_t radix_table_bytes(int64_t n) {
 // scratch of the same size; `table` is radix_table_bytes(n) of scratch.  The sorted VALUES are
 // written to vals_final (distinct from valsA / valsB); *keys_sorted tells which key buffer holds
 // the sorted keys.
-template <typename KeyT, typename ValT = int32_t>
-static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
-                            ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
-                            uint32_t* table, KeyT** keys_sorted) {
-  constexpr int ITEMS = RsItems<ValT>::value;
+template <typename KeyT, typename ValT, int ITEMS>
+static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
+                                 ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
+                                 uint32_t* table, KeyT** keys_sorted) {
   constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -221,7 +223,7 @@ static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, 
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
     hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
                        n_blocks, table);
-    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(1024), 0, s, n_blocks, table, digit_base);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, digit_base);
     hipLaunchKernelGGL(radix_scan_digits_kernel, dim3(1), dim3(256), 0, s, digit_base);
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
                        kdst, vdst, shift, n_blocks, table, digit_base);
@@ -231,6 +233,14 @@ static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, 
   }
   *keys_sorted = ksrc;
   return 0;
+}
+
+template <typename KeyT, typename ValT = int32_t>
+static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
+                            ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
+                            uint32_t* table, KeyT** keys_sorted) {
+  return radix_sort_pairs_impl<KeyT, ValT, RS_DEFAULT_ITEMS>(s, n, keysA, keysB, valsA, valsB, vals_final,
+                                                      begin_bit, end_bit, table, keys_sorted);
 }
 
 // ------------------------------------------------------------- inclusive scan of int64
@@ -272,15 +282,15 @@ scan_i64_blocks_kernel(int64_t n, int64_t* __restrict__ data, int64_t* __restric
   if (threadIdx.x == SC_THREADS - 1) block_tot[blockIdx.x] = off + run;
 }
 
-// pass 2: exclusive scan of the block totals, one block
-__global__ void __launch_bounds__(1024)
+// pass 2: exclusive scan of the block totals, one block (256 threads, see radix_scan_rows_kernel)
+__global__ void __launch_bounds__(SC_THREADS)
 scan_i64_totals_kernel(int nb, int64_t* __restrict__ tot) {
-  __shared__ int64_t wsum[16];
+  __shared__ int64_t wsum[SC_THREADS / 64];
   __shared__ int64_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int base = 0; base < nb; base += 1024) {
+  for (int base = 0; base < nb; base += SC_THREADS) {
     const int i = base + threadIdx.x;
     const int64_t v = i < nb ? tot[i] : 0;
     const int64_t x = wave_incl_scan_i64(v, lane);
@@ -291,30 +301,36 @@ scan_i64_totals_kernel(int nb, int64_t* __restrict__ tot) {
     const int64_t carry = carry_s;
     if (i < nb) tot[i] = carry + woff + x - v;
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    if (threadIdx.x == SC_THREADS - 1) carry_s = carry + woff + x;
     __syncthreads();
   }
 }
 
-// pass 3: add the block offsets
+// pass 3: add the block offsets; last_out (optional) receives the grand total data[n-1]
 __global__ void __launch_bounds__(SC_THREADS)
-scan_i64_add_kernel(int64_t n, int64_t* __restrict__ data, const int64_t* __restrict__ tot) {
+scan_i64_add_kernel(int64_t n, int64_t* __restrict__ data, const int64_t* __restrict__ tot,
+                    int64_t* __restrict__ last_out) {
   const int64_t off = tot[blockIdx.x];
   const int64_t base = (int64_t)blockIdx.x * SC_CHUNK;
   for (int k = threadIdx.x; k < SC_CHUNK; k += SC_THREADS)
-    if (base + k < n) data[base + k] += off;
+    if (base + k < n) {
+      const int64_t v = data[base + k] + off;
+      data[base + k] = v;
+      if (last_out && base + k == n - 1) *last_out = v;
+    }
 }
 
 static inline size_t scan_scratch_bytes(int64_t n) {
   return (((n + SC_CHUNK - 1) / SC_CHUNK) * sizeof(int64_t) + 255) / 256 * 256 + 256;
 }
 
-static int inclusive_scan_i64(hipStream_t s, int64_t n, int64_t* data, int64_t* scratch) {
+static int inclusive_scan_i64(hipStream_t s, int64_t n, int64_t* data, int64_t* scratch,
+                              int64_t* last_out = nullptr) {
   if (n <= 0) return 0;
   const int nb = (int)((n + SC_CHUNK - 1) / SC_CHUNK);
   hipLaunchKernelGGL(scan_i64_blocks_kernel, dim3(nb), dim3(SC_THREADS), 0, s, n, data, scratch);
-  hipLaunchKernelGGL(scan_i64_totals_kernel, dim3(1), dim3(1024), 0, s, nb, scratch);
-  hipLaunchKernelGGL(scan_i64_add_kernel, dim3(nb), dim3(SC_THREADS), 0, s, n, data, scratch);
+  hipLaunchKernelGGL(scan_i64_totals_kernel, dim3(1), dim3(SC_THREADS), 0, s, nb, scratch);
+  hipLaunchKernelGGL(scan_i64_add_kernel, dim3(nb), dim3(SC_THREADS), 0, s, n, data, scratch, last_out);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

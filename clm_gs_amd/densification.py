@@ -12,14 +12,16 @@ def _in_window(args, iteration):
 def gsplat_densification(iteration, scene, gaussians, batched_screenspace_pkg=None):
     """Every densification_interval images inside (densify_from_iter, densify_until_iter]:
     densify_and_prune; every opacity_reset_interval images: reset_opacity (densification.py:5-56).
-    Triggers use the bsz-stride test so no image index is skipped."""
+    Triggers use the bsz-stride test so no image index is skipped (camera-DP: the image counter
+    strides by the GLOBAL batch, bsz x ranks)."""
     args = utils.get_args()
+    gbsz = args.bsz * dp.world_size()
     timers = utils.get_timers()
     if not _in_window(args, iteration):
         return
     timers.start("densification")
     if iteration > args.densify_from_iter and utils.check_update_at_this_iter(
-            iteration, args.bsz, args.densification_interval, 0):
+            iteration, gbsz, args.densification_interval, 0):
         assert not args.stop_update_param
         gaussians.optimizer.zero_grad(set_to_none=True)
         dp.allreduce_densify_stats(gaussians)  # camera-DP: sum / sum / max over ranks
@@ -29,7 +31,7 @@ def gsplat_densification(iteration, scene, gaussians, batched_screenspace_pkg=No
                                     scene.cameras_extent, size_threshold)
         timers.stop("densify_and_prune")
         utils.inc_densify_iter()
-    if utils.check_update_at_this_iter(iteration, args.bsz, args.opacity_reset_interval, 0):
+    if utils.check_update_at_this_iter(iteration, gbsz, args.opacity_reset_interval, 0):
         timers.start("reset_opacity")
         gaussians.reset_opacity()
         timers.stop("reset_opacity")

@@ -41,6 +41,158 @@ def _np(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _CameraPass:
+    """Everything one camera's forward leaves behind for its backward (kept alive by the caller
+    until the streams involved have consumed it)."""
+    __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
+                 "packed", "fids", "offsets", "emit_slot", "order", "cum", "out", "alphas", "last_ids",
+                 "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux")
+
+
+def _sptr(torch_stream):
+    return ctypes.c_void_p(torch_stream.cuda_stream)
+
+
+def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
+                   lambda_dssim=0.2, small_packed=None, streams=None):
+    """Projection + binning (stream `front`), alpha-blend forward (stream `raster`), loss forward +
+    backward (stream `mem`) of one camera; returns the _CameraPass for camera_backward.  The three
+    streams may be one and the same; distinct streams are chained by events, so the caller can put
+    all cameras' tile kernels on one low-priority stream and order them RF0 RF1 RB0 RF2 RB1 ...
+    (software pipelining over the cameras of a batch: the tile stream never waits for a loss)."""
+    L = _lib.lib()
+    args = utils.get_args()
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    dev = gaussians._xyz.device
+    cur = torch.cuda.current_stream()
+    s_front, s_mem, s_raster = streams if streams is not None else (cur, cur, cur)
+    p = _CameraPass()
+    p.streams = (s_front, s_mem, s_raster)
+    V = p.V = int(this_filter.shape[0]) if this_filter is not None else int(gaussians._xyz.shape[0])
+    p.cam = _cam_host(camera)
+    vm, K, campos = p.cam
+    deg = p.deg = int(gaussians.active_sh_degree)
+    p.sh_rows, p.sh_by_filter, p.small_packed = sh_rows, sh_by_filter, small_packed
+    filt = p.filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
+    if small_packed is not None:
+        small_in = (dptr(small_packed, F32), None, None, None)
+        p.aux = (small_packed,)
+    else:
+        xyz, opa = gaussians._xyz.detach(), gaussians._opacity.detach()
+        sca, rot = gaussians._scaling.detach(), gaussians._rotation.detach()
+        small_in = (dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32))
+        p.aux = (xyz, opa, sca, rot)
+    p.small_in = small_in
+    tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
+    with torch.cuda.stream(s_front):
+        radii = p.radii = torch.empty((1, V), dtype=I32, device=dev)
+        means2d = torch.empty((1, V, 2), dtype=F32, device=dev)
+        depths = torch.empty((1, V), dtype=F32, device=dev)
+        packed = p.packed = torch.empty((V, 16), dtype=F32, device=dev)
+        check(L.clmgs_preprocess_fwd(
+            _sptr(s_front), V, dptr(filt, torch.int64, True), *small_in,
+            dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
+            0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
+            dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
+        p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect_tiles_two_level(
+            means2d, radii, depths, TILE, tw, th, want_slots=True,
+            packed=packed if getattr(args, "exact_tile_cull", True) else None)
+        p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
+        p.alphas = torch.empty((H, W), dtype=F32, device=dev)
+        p.last_ids = torch.empty((H, W), dtype=I32, device=dev)
+        p.bg = background.reshape(1, 3).to(F32).contiguous() if background is not None else None
+        p.aux = p.aux + (means2d, depths)
+    if s_raster is not s_front:
+        s_raster.wait_stream(s_front)
+    n_isects = p.fids.numel()
+    check(L.clmgs_rasterize_fwd(_sptr(s_raster), 1, V, n_isects, None, None, None, None, dptr(p.bg, F32, True),
+                                W, H, TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(packed), dptr(p.out),
+                                dptr(p.alphas), dptr(p.last_ids)))
+    if s_mem is not s_raster:
+        ev = torch.cuda.Event()
+        ev.record(s_raster)
+        s_mem.wait_event(ev)
+    with torch.cuda.stream(s_mem):
+        # loss forward + backward straight on the [H,W,3] buffer viewed as [3,H,W]
+        slots = L.clmgs_loss_slots()
+        partials = torch.zeros((slots, 2), dtype=F32, device=dev)
+        maps = p.maps = torch.empty((3, 3, H, W), dtype=F32, device=dev)
+        sc, sy, sx = 1, 3 * W, 3
+        gt = gt_u8.contiguous()
+        sm = _sptr(s_mem)
+        check(L.clmgs_l1_ssim_loss_fwd(sm, H, W, dptr(p.out), sc, sy, sx, dptr(gt, U8), dptr(partials),
+                                       dptr(maps[0]), dptr(maps[1]), dptr(maps[2])))
+        tot = partials.sum(dim=0) / float(3 * H * W)
+        loss = (1.0 - lambda_dssim) * tot[0] + lambda_dssim * (1.0 - tot[1])
+        one = torch.ones((1,), dtype=F32, device=dev)
+        p.v_out = torch.empty_like(p.out)
+        check(L.clmgs_l1_ssim_loss_bwd(sm, H, W, dptr(p.out), sc, sy, sx, dptr(gt, U8), dptr(one),
+                                       float(lambda_dssim), dptr(maps[0]), dptr(maps[1]), dptr(maps[2]),
+                                       dptr(p.v_out)))
+        p.loss = loss.detach()
+        p.ev_loss = None
+        if s_raster is not s_mem:
+            p.ev_loss = torch.cuda.Event()
+            p.ev_loss.record(s_mem)
+        p.aux = p.aux + (gt, one, partials)
+    return p
+
+
+def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True, stats_delta=None,
+                    stats_only_visible=False, visibility_out=None, accumulate_after=None):
+    """Alpha-blend backward (stream `raster`) + projection / SH backward (stream `mem`) of the
+    camera whose forward left `p`.  Gradients are ACCUMULATED (see train_one_camera)."""
+    L = _lib.lib()
+    args = utils.get_args()
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    dev = gaussians._xyz.device
+    s_front, s_mem, s_raster = p.streams
+    V = p.V
+    vm, K, campos = p.cam
+    tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
+    n_isects = p.fids.numel()
+    if p.small_packed is not None:
+        assert small_grad is not None
+        small_out = (dptr(small_grad, F32), None, None, None)
+    else:
+        small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
+                     dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
+    with torch.cuda.stream(s_mem):
+        packed_grad = torch.empty_like(p.packed)
+        # atomic-free accumulation: one 64 B line per intersection, summed per row afterwards
+        partials = torch.empty((max(n_isects, 1), 16), dtype=F32, device=dev)
+    if p.ev_loss is not None:
+        s_raster.wait_event(p.ev_loss)
+    check(L.clmgs_rasterize_bwd(_sptr(s_raster), 1, V, n_isects, dptr(p.packed), dptr(p.bg, F32, True), W, H,
+                                TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(p.alphas), dptr(p.last_ids),
+                                dptr(p.v_out), None, dptr(packed_grad), None, None, None, None,
+                                dptr(p.emit_slot), dptr(p.order), dptr(p.cum), dptr(partials)))
+    if s_mem is not s_raster:
+        ev = torch.cuda.Event()
+        ev.record(s_raster)
+        s_mem.wait_event(ev)
+    stats = update_stats and (not args.disable_auto_densification) and \
+        utils.get_cur_iter() <= args.densify_until_iter
+    if stats and stats_delta is not None:  # [N,4] delta table (see GaussianModelCLMOffload.stats_delta)
+        stat_ptrs = (dptr(stats_delta, F32), None, None)
+    else:
+        stat_ptrs = (dptr(gaussians.max_radii2D if stats else None, F32, True),
+                     dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
+                     dptr(gaussians.denom if stats else None, F32, True))
+    with torch.cuda.stream(s_mem):
+        if accumulate_after is not None:
+            s_mem.wait_event(accumulate_after)
+        if visibility_out is not None:
+            visibility_out |= (p.radii.reshape(-1) > 0)
+        check(L.clmgs_preprocess_bwd(
+            _sptr(s_mem), V, dptr(p.filt, torch.int64, True), *p.small_in, dptr(p.sh_rows, F32, allow_host=True),
+            int(p.sh_by_filter), _np(vm), _np(K), _np(campos), W, H, p.deg, 0.3, dptr(p.radii),
+            dptr(packed_grad), *small_out, dptr(g_sh_rows, F32, allow_host=True),
+            *stat_ptrs, None, int(bool(stats_only_visible))))
+    p.aux = p.aux + (packed_grad, partials)
+    return p.loss
+
+
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
                      return_event=False, stats_only_visible=False, visibility_out=None,
@@ -59,100 +211,15 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     `small_packed` / `small_grad`: the [N,12] mirror of the four small parameter tensors and the
     packed [N,12] gradient table (GaussianModelCLMOffload.small_packed / small_grad); the kernels
     then gather one 48 B row per Gaussian and accumulate into one, instead of four pieces each."""
-    L = _lib.lib()
-    args = utils.get_args()
-    W, H = int(utils.get_img_width()), int(utils.get_img_height())
-    dev = gaussians._xyz.device
-    V = int(this_filter.shape[0]) if this_filter is not None else int(gaussians._xyz.shape[0])
-    vm, K, campos = _cam_host(camera)
-    deg = int(gaussians.active_sh_degree)
-    xyz, opa = gaussians._xyz.detach(), gaussians._opacity.detach()
-    sca, rot = gaussians._scaling.detach(), gaussians._rotation.detach()
-    radii = torch.empty((1, V), dtype=I32, device=dev)
-    means2d = torch.empty((1, V, 2), dtype=F32, device=dev)
-    depths = torch.empty((1, V), dtype=F32, device=dev)
-    packed = torch.empty((V, 16), dtype=F32, device=dev)
-    filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
-    s = stream()
-    if small_packed is not None:
-        assert small_grad is not None
-        small_in = (dptr(small_packed, F32), None, None, None)
-        small_out = (dptr(small_grad, F32), None, None, None)
-    else:
-        small_in = (dptr(xyz, F32), dptr(opa, F32), dptr(sca, F32), dptr(rot, F32))
-        small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
-                     dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
-    check(L.clmgs_preprocess_fwd(
-        s, V, dptr(filt, torch.int64, True), *small_in,
-        dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
-        0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
-        dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
-    tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
-    fids, offsets, _, (emit_slot, order, cum) = isect_tiles_two_level(
-        means2d, radii, depths, TILE, tw, th, want_slots=True,
-        packed=packed if getattr(args, "exact_tile_cull", True) else None)
-    out = torch.empty((H, W, 3), dtype=F32, device=dev)
-    alphas = torch.empty((H, W), dtype=F32, device=dev)
-    last_ids = torch.empty((H, W), dtype=I32, device=dev)
-    bg = background.reshape(1, 3).to(F32).contiguous() if background is not None else None
-    n_isects = fids.numel()
     cur = torch.cuda.current_stream()
-    s_r = s
-    if raster_stream is not None:
-        raster_stream.wait_stream(cur)
-        s_r = ctypes.c_void_p(raster_stream.cuda_stream)
-    check(L.clmgs_rasterize_fwd(s_r, 1, V, n_isects, None, None, None, None, dptr(bg, F32, True), W, H,
-                                TILE, tw, th, dptr(offsets), dptr(fids), dptr(packed), dptr(out),
-                                dptr(alphas), dptr(last_ids)))
-    if raster_stream is not None:
-        cur.wait_stream(raster_stream)
-    # loss forward + backward straight on the [H,W,3] buffer viewed as [3,H,W]
-    slots = L.clmgs_loss_slots()
-    partials = torch.zeros((slots, 2), dtype=F32, device=dev)
-    maps = torch.empty((3, 3, H, W), dtype=F32, device=dev)
-    sc, sy, sx = 1, 3 * W, 3
-    gt = gt_u8.contiguous()
-    check(L.clmgs_l1_ssim_loss_fwd(s, H, W, dptr(out), sc, sy, sx, dptr(gt, U8), dptr(partials),
-                                   dptr(maps[0]), dptr(maps[1]), dptr(maps[2])))
-    tot = partials.sum(dim=0) / float(3 * H * W)
-    loss = (1.0 - lambda_dssim) * tot[0] + lambda_dssim * (1.0 - tot[1])
-    one = torch.ones((1,), dtype=F32, device=dev)
-    v_out = torch.empty_like(out)
-    check(L.clmgs_l1_ssim_loss_bwd(s, H, W, dptr(out), sc, sy, sx, dptr(gt, U8), dptr(one),
-                                   float(lambda_dssim), dptr(maps[0]), dptr(maps[1]), dptr(maps[2]),
-                                   dptr(v_out)))
-    packed_grad = torch.empty_like(packed)
-    # atomic-free accumulation: one 64 B line per intersection, summed per row afterwards
-    partials = torch.empty((max(n_isects, 1), 16), dtype=F32, device=dev)
-    if raster_stream is not None:
-        raster_stream.wait_stream(cur)
-    check(L.clmgs_rasterize_bwd(s_r, 1, V, n_isects, dptr(packed), dptr(bg, F32, True), W, H, TILE, tw,
-                                th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
-                                dptr(v_out), None, dptr(packed_grad), None, None, None, None,
-                                dptr(emit_slot), dptr(order), dptr(cum), dptr(partials)))
-    if raster_stream is not None:
-        cur.wait_stream(raster_stream)
-    stats = update_stats and (not args.disable_auto_densification) and \
-        utils.get_cur_iter() <= args.densify_until_iter
-    if stats and stats_delta is not None:  # [N,4] delta table (see GaussianModelCLMOffload.stats_delta)
-        stat_ptrs = (dptr(stats_delta, F32), None, None)
-    else:
-        stat_ptrs = (dptr(gaussians.max_radii2D if stats else None, F32, True),
-                     dptr(gaussians.xyz_gradient_accum if stats else None, F32, True),
-                     dptr(gaussians.denom if stats else None, F32, True))
-    if accumulate_after is not None:
-        torch.cuda.current_stream().wait_event(accumulate_after)
-    if visibility_out is not None:
-        visibility_out |= (radii.reshape(-1) > 0)
-    check(L.clmgs_preprocess_bwd(
-        s, V, dptr(filt, torch.int64, True), *small_in, dptr(sh_rows, F32, allow_host=True),
-        int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg, 0.3, dptr(radii), dptr(packed_grad),
-        *small_out, dptr(g_sh_rows, F32, allow_host=True),
-        *stat_ptrs, None, int(bool(stats_only_visible))))
+    p = camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
+                       lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur))
+    loss = camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
+                           stats_only_visible, visibility_out, accumulate_after)
     if keep is not None:
-        keep += [packed, packed_grad, radii, filt, partials, emit_slot, order, cum]
+        keep.append(p)
     if return_event:
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        return loss.detach(), ev
-    return loss.detach()
+        ev.record(cur)
+        return loss, ev
+    return loss

@@ -22,7 +22,7 @@ import threading
 
 import torch
 
-from ... import clm_kernels, dp, fast_tsp, utils
+from ... import _lib, clm_kernels, dp, fast_tsp, utils
 from ...clm_kernels import (send_shs2cpu_grad_buffer_stream,
                             send_shs2cpu_grad_buffer_stream_retention, send_shs2gpu_stream,
                             send_shs2gpu_stream_retention, spherical_harmonics_bwd_inplace)
@@ -315,51 +315,78 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # Two cameras in flight on two streams: the ALU-bound tile kernels of one overlap with the
         # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
         # events so the read-modify-write gradient sums stay ordered.
-        from ...fused import train_one_camera
+        from ...fused import camera_backward, camera_forward, train_one_camera
         mode = getattr(args, "overlap_cameras", True)
-        mode = {True: "typed", False: "off"}.get(mode, mode)
+        mode = {True: "pipeline", False: "off"}.get(mode, mode)
         n_lanes = max(1, int(getattr(args, "overlap_lanes", 2)))
         sts = getattr(gaussians, "_clmgs_streams", None)
-        if sts is None or len(sts["mem"]) < n_lanes:
+        if sts is None or len(sts["mem"]) < max(2, n_lanes):
             try:
                 lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
             except AttributeError:
                 lo, hi = 0, -1
             sts = gaussians._clmgs_streams = {
                 "aux": torch.cuda.Stream(),
-                "mem": [torch.cuda.Stream(priority=hi) for _ in range(n_lanes)],
-                "raster": [torch.cuda.Stream(priority=lo) for _ in range(n_lanes)]}
-        rasters = None
-        if mode == "typed":
-            # streams by kernel TYPE: the ALU-bound tile kernels run on low-priority streams, the
-            # latency-bound rest of the cameras in flight on high-priority streams and is dispatched
-            # first whenever it has work -- it fills the memory system while the tile kernels fill
-            # the VALUs.  Large images: ONE tile stream (a 4K image has 62 k tiles, tile kernels gain
-            # nothing from overlapping each other); small images (a 1080p image has 8 k one-wave
-            # tiles for 1024 SIMDs x 5 waves): one tile stream per camera in flight.
-            lanes = sts["mem"][:n_lanes]
-            n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
-            rasters = sts["raster"][:n_lanes] if n_tiles < 20000 else [sts["raster"][0]] * n_lanes
-        elif mode == "camera":
-            lanes = [default_stream, sts["aux"]]
+                "mem": [torch.cuda.Stream(priority=hi) for _ in range(max(2, n_lanes))],
+                "raster": [torch.cuda.Stream(priority=lo) for _ in range(max(2, n_lanes))]}
+            reserve = int(getattr(args, "raster_reserve_cus", 0))
+            if reserve > 0:
+                sts["raster"][0] = _lib.cu_masked_stream(reserve)
+        n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
+        if mode == "pipeline":
+            # Software pipeline over the cameras of the batch, streams by kernel TYPE:
+            #   front  (high priority): projection + binning of camera k, one camera ahead
+            #   mem    (high priority): loss of camera k, projection/SH backward of camera k-1
+            #   raster (low priority) : the ALU-bound tile kernels, enqueued RF0 RF1 RB0 RF2 RB1 ...
+            # so the tile stream always has the next forward to run while a loss is being computed,
+            # and the latency-bound kernels fill the memory system underneath it.  The per-camera
+            # tensors stay alive until the end-of-batch synchronisation (several streams read them).
+            s_front, s_mem, s_raster = sts["mem"][0], sts["mem"][1], sts["raster"][0]
+            for st_ in (s_front, s_mem, s_raster):
+                st_.wait_stream(default_stream)
+            # the previous batch's per-camera tensors: every stream that read them has been joined
+            # into the default stream, which the three streams now wait for -> safe to recycle
+            gaussians._clmgs_passes = None
+            passes = []
+            for micro_idx in range(bsz):
+                passes.append(camera_forward(
+                    gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, background,
+                    batched_cameras[micro_idx].original_image, small_packed=small_pk,
+                    streams=(s_front, s_mem, s_raster)))
+                if micro_idx >= 1:
+                    losses.append(camera_backward(gaussians, passes[micro_idx - 1], grad_buf, small_gk,
+                                                  stats_delta=stats_d))
+            losses.append(camera_backward(gaussians, passes[-1], grad_buf, small_gk, stats_delta=stats_d))
+            for st_ in (s_front, s_mem, s_raster):
+                default_stream.wait_stream(st_)
+            gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)
         else:
-            lanes = [default_stream]
-        for ln in lanes:
-            if ln is not default_stream:
-                ln.wait_stream(default_stream)
-        prev = None
-        for micro_idx in range(bsz):
-            with torch.cuda.stream(lanes[micro_idx % len(lanes)]):
-                loss, prev = train_one_camera(
-                    gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
-                    background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
-                    return_event=True,
-                    raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
-                    small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d)
-            losses.append(loss)
-        for ln in lanes:
-            if ln is not default_stream:
-                default_stream.wait_stream(ln)
+            rasters = None
+            if mode == "typed":
+                # one camera per memory lane, tile kernels on low-priority streams (one shared tile
+                # stream for large images, one per lane for small ones)
+                lanes = sts["mem"][:n_lanes]
+                rasters = sts["raster"][:n_lanes] if n_tiles < 20000 else [sts["raster"][0]] * n_lanes
+            elif mode == "camera":
+                lanes = [default_stream, sts["aux"]]
+            else:
+                lanes = [default_stream]
+            for ln in lanes:
+                if ln is not default_stream:
+                    ln.wait_stream(default_stream)
+            prev = None
+            for micro_idx in range(bsz):
+                with torch.cuda.stream(lanes[micro_idx % len(lanes)]):
+                    loss, prev = train_one_camera(
+                        gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
+                        background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
+                        return_event=True,
+                        raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
+                        small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d)
+                losses.append(loss)
+            for ln in lanes:
+                if ln is not default_stream:
+                    default_stream.wait_stream(ln)
     for micro_idx in range(0 if fused else bsz):  # op-by-op path (fused_front_end=False)
         this_filter = filters[micro_idx]
         with torch.no_grad():
@@ -394,7 +421,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     st["step"] = step
     if side_event is not None:
         default_stream.wait_event(side_event)
-    torch.cuda.synchronize()
+    # No device synchronisation here: everything above is ordered on the default stream, so the
+    # host can already prepare the next batch (its first host wait is the filter sizes) while the
+    # optimizer kernels run; callers that read the losses synchronise by doing so.
+    if getattr(args, "sync_each_batch", False):
+        torch.cuda.synchronize()
     return losses, ordered_cams, sparsity
 
 

@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import utils
+from . import dp, utils
 from .densification import gsplat_densification
 
 
@@ -35,6 +35,10 @@ class End2endTimer:
     def print_time(self, log_file, n_iterations):
         log_file.write("end2end total_time: {:.3f} s, iterations: {}, throughput {:.2f} it/s\n".format(
             self.total_time, n_iterations, n_iterations / max(self.total_time, 1e-9)))
+
+
+def clm_hbm_only(args):
+    return bool(getattr(args, "clm_offload", False)) and getattr(args, "sh_residency", "hbm") == "hbm"
 
 
 def psnr(img1, img2):
@@ -79,9 +83,20 @@ def evaluate(name, iteration, cameras, render_fn, log_file, max_images=10 ** 9):
 
 def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations=None,
              test_iterations=(), background=None, shuffle_seed=0):
-    """Runs `iterations` images of training; returns the End2endTimer."""
+    """Runs `iterations` images of training; returns the End2endTimer.
+
+    Camera-DP: when a process group is up every rank runs this same loop over the
+    same shuffled order, takes cameras rank::ranks of each GLOBAL batch (bsz x ranks images), and
+    the image counter strides by the global batch; the engine does the one exchange per batch,
+    densification reduces its statistics (densification.py) and draws identical split samples."""
     args = utils.get_args()
     bsz = args.bsz
+    ws, rk = dp.world_size(), dp.rank()
+    gbsz = bsz * ws
+    if ws > 1:
+        assert clm_hbm_only(args), "camera-DP trains clm_offload with sh_residency='hbm'"
+        if getattr(gaussians, "split_generator", None) is None:
+            dp.seed_split_generator(gaussians)
     iterations = iterations or args.iterations
     utils.set_log_file(log_file)
     clm = bool(getattr(args, "clm_offload", False))
@@ -107,15 +122,15 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     order = []
     timer = End2endTimer()
     timer.start()
-    for iteration in range(1, iterations + 1, bsz):
+    for iteration in range(1, iterations + 1, gbsz):
         utils.set_cur_iter(iteration)
         gaussians.update_learning_rate(iteration)
-        if utils.check_update_at_this_iter(iteration, bsz, 1000, 0):
+        if utils.check_update_at_this_iter(iteration, gbsz, 1000, 0):
             gaussians.oneupSHdegree()
-        if len(order) < bsz:  # new epoch: shuffle, drop_last (train.py:156-167)
+        if len(order) < gbsz:  # new epoch: shuffle, drop_last (train.py:156-167)
             order = list(range(len(train_cameras)))
             rng.shuffle(order)
-        batch = [train_cameras[order.pop()] for _ in range(bsz)]
+        batch = [train_cameras[order.pop()] for _ in range(gbsz)][rk::ws]
         if naive:
             losses, visibility = naive_offload_train_one_batch(gaussians, scene, batch, background,
                                                                sparse_adam=args.sparse_adam)
@@ -131,9 +146,9 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             names, sparsity = [c.image_name for c in batch], None
         batched_loss = torch.stack(losses).cpu().tolist()
         log_file.write("iteration[{},{}) loss: {} image: {}".format(
-            iteration, iteration + bsz, " ".join("%.6f" % l for l in batched_loss), names))
+            iteration, iteration + gbsz, " ".join("%.6f" % l for l in batched_loss), names))
         log_file.write((" sparsity: " + " ".join("%.4f" % s for s in sparsity) + "\n") if sparsity else "\n")
-        if any(iteration <= t < iteration + bsz for t in test_iterations):
+        if any(iteration <= t < iteration + gbsz for t in test_iterations):
             timer.stop()  # evaluation is excluded from the throughput figure
             evaluate("train", iteration, train_cameras, render_fn, log_file, max_images=5)
             if test_cameras:
@@ -142,8 +157,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         n_before = gaussians.get_xyz.shape[0]
         gsplat_densification(iteration, scene, gaussians, None)
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
-                iteration, bsz, args.densification_interval, 0):
-            log_file.write(memory_line(iteration, bsz, gaussians))
+                iteration, gbsz, args.densification_interval, 0):
+            log_file.write(memory_line(iteration, gbsz, gaussians))
         if not clm and not naive:  # train.py:533-578
             if args.lr_scale_mode != "accumu":
                 for p in gaussians.all_parameters():
@@ -156,8 +171,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             gaussians.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
     timer.stop()
-    n_done = ((iterations - 1) // bsz + 1) * bsz + 1
+    n_done = ((iterations - 1) // gbsz + 1) * gbsz + 1
     timer.print_time(log_file, n_done)
-    log_file.write(memory_line(iteration, bsz, gaussians, what="final"))
+    log_file.write(memory_line(iteration, gbsz, gaussians, what="final"))
     log_file.write("Max Memory usage: {} GB.\n".format(torch.cuda.max_memory_allocated() / 2 ** 30))
     return timer

@@ -49,10 +49,53 @@ def _train(m, batches, args, world=1):
             m._rotation.detach().clone(), m._parameters.detach().clone()]
 
 
+def trainer_mode(rank, world):
+    """Both ranks run trainer.training (engine exchange + reduced densification statistics + the
+    shared split generator); after clone / split / prune the replicas must still be identical."""
+    import io
+    from clm_gs_amd import trainer, utils
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    n0, w, h = 6000, 128, 96
+    args = utils.default_args(bsz=4, sh_residency="hbm", densify_from_iter=16, densification_interval=16,
+                              densify_until_iter=48, densify_grad_threshold=0.00002)
+    args.clm_offload = True
+    utils.set_args(args)
+    utils.set_img_size(h, w)
+    sc = synth_gaussians(n0, seed=3, device="cuda")
+    cams = nadir_cameras(16, n0, w, h, 0.35, seed=3, device="cuda")
+    g = torch.Generator().manual_seed(9)
+    for c in cams:
+        c.original_image = (torch.rand(3, h, w, generator=g) * 255).to(torch.uint8).cuda()
+    m = _model(sc, args)
+    log = io.StringIO()
+    trainer.training(m, _Scene, cams, [], log, iterations=64)
+    n = torch.tensor([m.get_xyz.shape[0]], device="cuda")
+    n0t = n.clone()
+    dist.broadcast(n0t, src=0)
+    same = bool(n0t.item() == n.item())
+    if same:
+        for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters):
+            other = t.detach().clone()
+            dist.broadcast(other, src=0)
+            same &= bool(torch.equal(other, t.detach()))
+    flags = [None] * world
+    dist.all_gather_object(flags, same)
+    dist.barrier()
+    if rank == 0:
+        text = log.getvalue()
+        print("DPRESULT " + json.dumps({
+            "replicas_equal": all(flags), "n_before": n0, "n_after": int(n.item()),
+            "global_stride": "iteration[1,9)" in text and "iteration[9,17)" in text,
+            "split": "Number of split gaussians" in text}))
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        return trainer_mode(rank, world)
     from clm_gs_amd import dp, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 

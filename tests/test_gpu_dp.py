@@ -41,6 +41,19 @@ def test_two_ranks_equal_one_rank_with_double_batch(dev):
     assert max(res["rel_l2_vs_single"]) < 2e-4, res
 
 
+def test_trainer_two_ranks_densify_keeps_replicas_identical(dev):
+    """trainer.training under camera-DP: global-batch image stride, reduced densification
+    statistics, shared split samples -> bit-identical replicas after clone / split / prune."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "trainer"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert res["n_after"] != res["n_before"] and res["split"], res
+    assert res["global_stride"], res
+
+
 def test_bench_two_ranks_one_gpu(dev):
     """bench.py's N>1 branch (barrier, max over ranks, rank-0 JSON) with 2 ranks on one device."""
     env = dict(os.environ, CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1")
