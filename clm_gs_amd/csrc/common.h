@@ -30,6 +30,18 @@ void set_error(const char* fmt, ...);
 
 #define CLMGS_LAUNCH_CHECK() CLMGS_HIP(hipGetLastError())
 
+// Workgroup barrier that orders LDS only: unlike __syncthreads() (whose workgroup fence also
+// drains vmcnt) it lets global loads issued before it stay in flight, so a prefetch of the next
+// block of input survives the barriers of the current one.  Use only where every cross-thread
+// hand-over between the barriers goes through LDS.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

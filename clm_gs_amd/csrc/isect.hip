@@ -435,35 +435,169 @@ namespace clmgs {
 // ---- selection on the GPU: the batch's visibility filters without materialising radii[C,N]
 // A: one ballot word per (camera, 64 Gaussians) + its popcount; row C = union over the cameras
 //    (the rows the batch touches).  14 MB of bit words at 28 M x 4 cameras instead of 448 MB of radii.
+//
+// Two phases per block of 256 rows and group of 4 cameras.  Phase 1: every (row, camera) pair is
+// classified from its camera-space mean and an upper bound of the 3-sigma radius taken from the
+// largest scale (~45 instructions instead of the ~200 of the exact projection): certainly culled,
+// certainly visible, or undecided (means near the image border, huge splats, depths at the planes:
+// 1-2 % of the pairs), and the undecided ones are compacted into a list.  Phase 2: the EXACT
+// project_fwd runs over the list with all lanes busy.  The result is the exact test's, bit for
+// bit: both shortcuts are conservative (see vis_classify).
+constexpr int VB_CH = 4;        // cameras per group
+constexpr int VB_CAM_F = 20;    // floats per camera in LDS: R[9] t[3] fx fy cx cy Kc (+pad)
+constexpr int VB_MAX_CAMS = 64;
+
+// Kc = 0.5 (fx^2 (1 + limx^2) + fy^2 (1 + limy^2)) * 1.01: bound of 0.5 |J|_F^2 z^2
+__device__ __forceinline__ float vis_cam_kc(const Cam& c, float W, float H) {
+  const float tan_fovx = 0.5f * W / c.fx, tan_fovy = 0.5f * H / c.fy;
+  const float limx = fmaxf(fabsf((W - c.cx) / c.fx), fabsf(c.cx / c.fx)) + 0.3f * tan_fovx;
+  const float limy = fmaxf(fabsf((H - c.cy) / c.fy), fabsf(c.cy / c.fy)) + 0.3f * tan_fovy;
+  return 0.505f * (c.fx * c.fx * (1.f + limx * limx) + c.fy * c.fy * (1.f + limy * limy));
+}
+
+__device__ __forceinline__ Cam lds_cam(const float* f) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.R[i] = f[i];
+  c.t[0] = f[9]; c.t[1] = f[10]; c.t[2] = f[11];
+  c.fx = f[12]; c.fy = f[13]; c.cx = f[14]; c.cy = f[15];
+  return c;
+}
+
+// false only if project_fwd is certain to return radius 0.  With Sc's eigenvalues <= smax^2 and
+// |tx / z| <= lim:  b = (c00 + c11) / 2 <= smax^2 Kc / z^2 + eps2d =: B;  det > 0 => b^2 - det < b^2,
+// so v1 = b + sqrt(max(0.01, b^2 - det)) <= 2 B + 0.1 and radius = ceil(3 sqrt(v1)) <= 3 sqrt(2B + 0.1) + 1.
+// Margins (1 % on the radius, 2 px, 1e-5 on the depth planes) cover the fp32 rounding differences
+// between this short evaluation and the exact one; NaNs fall through to the exact test.
+// 0 = certainly culled, 1 = certainly visible, 2 = run the exact projection.
+// "Certainly visible": depth strictly inside the planes, mean inside the image by a pixel (the
+// radius is >= ceil(3 sqrt(eps2d)) = 2, so none of the four off-screen tests can fire), and
+// B < 400, which keeps the rounding error of det = c00 c11 - c01^2 (<= 2^-23 * 2 (2B)^2 ~ 0.08) below
+// its analytic floor 0.3 (c00' + c11') + 0.09, so the exact path's det > 0 test cannot fail.
+__device__ __forceinline__ int vis_classify(const Cam& c, float kc, const float m[3], float smax2,
+                                            float W, float H, float eps2d, float near_m, float far_m,
+                                            float near_p, float far_p, bool accept_ok) {
+  const float x = c.R[0] * m[0] + c.R[1] * m[1] + c.R[2] * m[2] + c.t[0];
+  const float y = c.R[3] * m[0] + c.R[4] * m[1] + c.R[5] * m[2] + c.t[1];
+  const float z = c.R[6] * m[0] + c.R[7] * m[1] + c.R[8] * m[2] + c.t[2];
+  if (z < near_m || z > far_m) return 0;
+  const float rz = __builtin_amdgcn_rcpf(z);
+  const float mx = c.fx * x * rz + c.cx, my = c.fy * y * rz + c.cy;
+  const float B = smax2 * rz * rz * kc + eps2d;
+  if (accept_ok && z > near_p && z < far_p && B < 400.f && mx >= 1.f && mx <= W - 1.f && my >= 1.f &&
+      my <= H - 1.f)
+    return 1;
+  const float Rb = 3.03f * __builtin_amdgcn_sqrtf(2.f * B + 0.1f) + 2.f;
+  return (mx + Rb <= 0.f || mx - Rb >= W || my + Rb <= 0.f || my - Rb >= H) ? 0 : 2;
+}
+
 __global__ void __launch_bounds__(256)
 visibility_bits_kernel(int C, int N, int W64, const float* __restrict__ means,
                        const float* __restrict__ quats_raw, const float* __restrict__ log_scales,
                        const float* __restrict__ viewmats, const float* __restrict__ Ks, float W, float H,
                        float eps2d, float near_plane, float far_plane, float radius_clip,
                        unsigned long long* __restrict__ bits, int64_t* __restrict__ counts) {
-  const int n_pad = W64 * 64;
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_pad; n += gridDim.x * blockDim.x) {
-    const int w = n >> 6;
+  __shared__ float cam_s[VB_MAX_CAMS][VB_CAM_F];
+  __shared__ float row_s[256][10];  // mean, raw quaternion, scales of the block's rows
+  __shared__ unsigned short cand[256 * VB_CH];  // row | camera-in-group << 8
+  __shared__ int n_cand;
+  __shared__ unsigned long long wb[VB_CH][4];
+  __shared__ unsigned long long anyw[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const float near_m = near_plane - (fabsf(near_plane) * 1e-5f + 1e-6f);
+  const float far_m = far_plane + fabsf(far_plane) * 1e-5f;
+  const float near_p = near_plane + (fabsf(near_plane) * 1e-5f + 1e-6f);
+  const float far_p = far_plane - fabsf(far_plane) * 1e-5f;
+  const bool accept_ok = radius_clip < 1.5f && eps2d >= 0.3f;  // radius >= 2 and the det floor above
+  const int wid = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    const Cam cam = load_cam(viewmats + 16 * c, Ks + 9 * c);
+    float* f = cam_s[c];
+    for (int i = 0; i < 9; ++i) f[i] = cam.R[i];
+    f[9] = cam.t[0]; f[10] = cam.t[1]; f[11] = cam.t[2];
+    f[12] = cam.fx; f[13] = cam.fy; f[14] = cam.cx; f[15] = cam.cy;
+    f[16] = vis_cam_kc(cam, W, H);
+  }
+  const int n_rb = (W64 + 3) / 4;
+  // the next block of rows is fetched while the current one is classified (the kernel is a chain of
+  // load -> classify -> barrier per block; without the prefetch its time was memory + compute)
+  float nm0 = 0.f, nm1 = 0.f, nm2 = 0.f, nl0 = 0.f, nl1 = 0.f, nl2 = 0.f;
+  float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int rbn) {
+    const int n = rbn * 256 + tid;
+    const int nn = (rbn < n_rb && n < N) ? n : 0;
+    nm0 = means[3 * nn]; nm1 = means[3 * nn + 1]; nm2 = means[3 * nn + 2];
+    nq = *reinterpret_cast<const float4*>(quats_raw + 4 * nn);
+    nl0 = log_scales[3 * nn]; nl1 = log_scales[3 * nn + 1]; nl2 = log_scales[3 * nn + 2];
+  };
+  fetch(blockIdx.x);
+  for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
+    const int n = rb * 256 + tid;
     const bool in = n < N;
-    const int nn = in ? n : 0;
-    const float m[3] = {means[3 * nn], means[3 * nn + 1], means[3 * nn + 2]};
-    const float4 q4 = *reinterpret_cast<const float4*>(quats_raw + 4 * nn);
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float s[3] = {__expf(log_scales[3 * nn]), __expf(log_scales[3 * nn + 1]), __expf(log_scales[3 * nn + 2])};
-    unsigned long long any = 0ull;
-    for (int c = 0; c < C; ++c) {
-      const Cam cam = load_cam(viewmats + 16 * c, Ks + 9 * c);
-      const Proj p = project_fwd(cam, m, q, s, W, H, eps2d, near_plane, far_plane, radius_clip);
-      const unsigned long long b = __ballot(in && p.radius > 0);
-      any |= b;
-      if ((threadIdx.x & 63) == 0) {
-        bits[(size_t)c * W64 + w] = b;
-        counts[(size_t)c * W64 + w] = __popcll(b);
+    const float m[3] = {nm0, nm1, nm2};
+    const float4 q4 = nq;
+    const float s0 = __expf(nl0), s1 = __expf(nl1), s2 = __expf(nl2);
+    fetch(rb + gridDim.x);
+    const float smax = fmaxf(s0, fmaxf(s1, s2));
+    const float smax2 = smax * smax;
+    // degenerate rows (zero / non-finite quaternion, NaN scale) make the exact projection return
+    // NaNs -> "culled"; they are never fast-accepted, the exact path decides
+    const float qn2 = q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w;
+    const bool row_ok = accept_ok && qn2 >= 1e-20f && qn2 <= 1e20f && (s0 + s1 + s2) < 1e30f;
+    lds_barrier();  // cam_s ready / the previous block of rows is done with the shared arrays
+    {
+      float* r = row_s[tid];
+      r[0] = m[0]; r[1] = m[1]; r[2] = m[2]; r[3] = q4.x; r[4] = q4.y; r[5] = q4.z; r[6] = q4.w;
+      r[7] = s0; r[8] = s1; r[9] = s2;
+    }
+    if (tid < 4) anyw[tid] = 0ull;
+    for (int c0 = 0; c0 < C; c0 += VB_CH) {
+      const int cn = min(VB_CH, C - c0);
+      if (tid < VB_CH * 4) wb[tid >> 2][tid & 3] = 0ull;
+      if (tid == 0) n_cand = 0;
+      lds_barrier();
+      for (int cc = 0; cc < cn; ++cc) {  // phase 1: conservative test, compaction
+        // wave-uniform camera: its constants arrive by scalar loads (SGPR operands, no VALU / LDS)
+        const Cam cam = load_cam(viewmats + 16 * (c0 + cc), Ks + 9 * (c0 + cc));
+        const int cls = in ? vis_classify(cam, cam_s[c0 + cc][16], m, smax2, W, H, eps2d, near_m, far_m,
+                                          near_p, far_p, row_ok) : 0;
+        const unsigned long long acc = __ballot(cls == 1);
+        if (lane == 0 && acc) atomicOr(&wb[cc][wid], acc);
+        const bool pass = cls == 2;
+        const unsigned long long b = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(&n_cand, __popcll(b));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pass) cand[base + __popcll(b & lt)] = (unsigned short)(tid | (cc << 8));
+      }
+      lds_barrier();
+      const int nc = n_cand;
+      for (int k = tid; k < nc; k += 256) {  // phase 2: exact projection of the survivors
+        const int e = cand[k], r = e & 255, cc = e >> 8;
+        const Cam cam = lds_cam(cam_s[c0 + cc]);
+        const float* rr = row_s[r];
+        const float mm[3] = {rr[0], rr[1], rr[2]};
+        const float qq[4] = {rr[3], rr[4], rr[5], rr[6]};
+        const float ss[3] = {rr[7], rr[8], rr[9]};
+        const Proj p = project_fwd(cam, mm, qq, ss, W, H, eps2d, near_plane, far_plane, radius_clip);
+        if (p.radius > 0) atomicOr(&wb[cc][r >> 6], 1ull << (r & 63));
+      }
+      lds_barrier();
+      if (tid < cn * 4) {
+        const int cc = tid >> 2, j = tid & 3, w = rb * 4 + j;
+        if (w < W64) {
+          const unsigned long long b = wb[cc][j];
+          bits[(size_t)(c0 + cc) * W64 + w] = b;
+          counts[(size_t)(c0 + cc) * W64 + w] = __popcll(b);
+          if (b) atomicOr(&anyw[j], b);
+        }
       }
     }
-    if ((threadIdx.x & 63) == 0) {
-      bits[(size_t)C * W64 + w] = any;
-      counts[(size_t)C * W64 + w] = __popcll(any);
+    lds_barrier();
+    if (tid < 4 && rb * 4 + tid < W64) {
+      bits[(size_t)C * W64 + rb * 4 + tid] = anyw[tid];
+      counts[(size_t)C * W64 + rb * 4 + tid] = __popcll(anyw[tid]);
     }
   }
 }
@@ -500,7 +634,7 @@ extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const f
                                              int height, float eps2d, float near_plane,
                                              float far_plane, float radius_clip, void* temp,
                                              size_t temp_bytes, int64_t* cum_totals) {
-  CLMGS_CHECK_ARG(C >= 1 && N >= 1 && width > 0 && height > 0);
+  CLMGS_CHECK_ARG(C >= 1 && C <= 64 && N >= 1 && width > 0 && height > 0);  // bsz <= 64 (engine.py)
   CLMGS_CHECK_ARG(means && quats_raw && log_scales && viewmats && Ks && temp && cum_totals);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_visibility_select_temp_bytes(C, N));
   hipStream_t s = (hipStream_t)stream;
@@ -510,7 +644,7 @@ extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const f
   unsigned long long* bits = (unsigned long long*)base; base += align_up(words * 8, 256);
   int64_t* counts = (int64_t*)base; base += align_up(words * 8, 256);
   int64_t* scratch = (int64_t*)base;
-  hipLaunchKernelGGL(visibility_bits_kernel, dim3(min(ceil_div((int64_t)W64 * 64, 256), 256 * 16)),
+  hipLaunchKernelGGL(visibility_bits_kernel, dim3(min(ceil_div((int64_t)W64 * 64, 256), 256 * 8)),
                      dim3(256), 0, s, C, N, W64, means, quats_raw, log_scales, viewmats, Ks,
                      (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, bits, counts);
   CLMGS_LAUNCH_CHECK();

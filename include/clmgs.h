@@ -54,7 +54,9 @@ int clmgs_visibility_raw(void* stream, int C, int N, const float* means, const f
  * the kernel: _count writes one ballot word + popcount per (camera, 64 Gaussians) into `temp`, scans
  * them and leaves cum_totals[C+1] (device, i64: set bits of cameras 0..r; row C = union over the
  * cameras); the caller reads cum_totals, allocates out[cum_totals[C]] i64 and calls _emit, which
- * writes the ascending Gaussian indices of camera 0, camera 1, ..., then of the union. */
+ * writes the ascending Gaussian indices of camera 0, camera 1, ..., then of the union.  1 <= C <= 64
+ * (the engines' largest batch); every pair first takes a conservative screen test, only the
+ * survivors the exact projection -- the selected sets are the exact test's. */
 size_t clmgs_visibility_select_temp_bytes(int C, int N);
 int clmgs_visibility_select_count(void* stream, int C, int N, const float* means,
                                   const float* quats_raw, const float* log_scales,

@@ -531,6 +531,48 @@ def test_visibility_select_equals_radii_nonzero(dev):
         assert torch.equal(union, torch.nonzero((radii > 0).any(dim=0)).flatten())
 
 
+def test_visibility_select_conservative_bound_stress(dev):
+    """The two-phase selection (cheap conservative screen test, then the exact projection of the
+    survivors) must equal the exact test everywhere: tilted / off-centre cameras, heavy-tailed
+    scales (huge splats whose 3-sigma box reaches the image from far outside), rows behind the
+    camera and near the clipping plane, and more cameras than one group of four."""
+    from clm_gs_amd import gsplat as G
+    from clm_gs_amd.cameras import Camera
+    g = torch.Generator().manual_seed(11)
+    n, w, h = 40000, 200, 120
+    xyz = (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([40.0, 40.0, 40.0])
+    rot = torch.randn(n, 4, generator=g)
+    log_s = torch.randn(n, 3, generator=g) * 1.5 - 2.0      # exp: 0.003 .. 10+
+    log_s[::97] += 4.0                                       # a few enormous ones
+    rot[5::1013] = 0.0                                       # degenerate quaternions (exact path: NaN -> culled)
+    log_s[7::1511, 1] = float("nan")
+    log_s[11::1999, 2] = float("inf")
+    xyz[13::2003, 0] = float("nan")
+    cams = []
+    for i in range(7):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        w2c = torch.eye(4)
+        w2c[:3, :3] = q
+        w2c[:3, 3] = torch.randn(3, generator=g) * 8.0
+        cams.append(Camera(i, w2c, 0.9 + 0.1 * i, 0.6 + 0.05 * i, w, h, device="cuda"))
+    Ks = torch.stack([c.K for c in cams])
+    Ks[1, 0, 2] += 37.0   # off-centre principal points
+    Ks[2, 1, 2] -= 21.0
+    vms = torch.stack([c.world_view_transform.t() for c in cams])
+    xyz, rot, log_s = xyz.cuda(), rot.cuda(), log_s.cuda()
+    radii = G.visibility_radii(xyz, rot, log_s, vms, Ks, w, h, raw=True)
+    filters, union = G.visibility_select(xyz, rot, log_s, vms, Ks, w, h)
+    assert len(filters) == 7
+    fracs = []
+    for c in range(7):
+        assert torch.equal(filters[c], torch.nonzero(radii[c] > 0).flatten())
+        fracs.append(filters[c].numel() / n)
+    assert torch.equal(union, torch.nonzero((radii > 0).any(dim=0)).flatten())
+    assert 0.01 < min(fracs) and max(fracs) < 0.9, fracs   # the test exercises both outcomes
+
+
 def test_rasterize_with_no_intersections(dev):
     """Edge case: nothing lands on the image.  Forward = background / alpha 0, backward = exact zeros,
     through both accumulation modes of the C ABI."""
