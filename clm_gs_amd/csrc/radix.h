@@ -4,8 +4,9 @@
 // One pass per 8-bit digit, three kernels per pass:
 //   histogram : every block counts the digits of its 4096-key chunk (LDS atomics) and writes a
 //               digit-major [256][n_blocks] table;
-//   scan      : exclusive scan of every digit's row (one block per digit) + of the 256 row
-//               totals -> the global base of every (digit, block) bucket;
+//   scan      : exclusive scan of every digit's row (one block per digit) + the 256 row totals
+//               (their exclusive scan, the global base of every digit, is redone by every
+//               scatter block: cheaper than a fourth dependent launch per pass);
 //   scatter   : every block re-reads its chunk (16 keys per thread kept in registers); the stable
 //               rank of a key inside its wave comes from 8 ballots (lanes with the same digit) +
 //               a popcount of the lanes below; the (round, wave) groups are ordered by ONE
@@ -77,43 +78,38 @@ radix_scan_rows_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __r
   if (threadIdx.x == 0) row_tot[blockIdx.x] = carry_s;
 }
 
-// exclusive scan of the 256 row totals -> global base of every digit
-__global__ void __launch_bounds__(256)
-radix_scan_digits_kernel(uint32_t* __restrict__ row_tot) {
-  __shared__ uint32_t wsum[4];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const uint32_t v = row_tot[threadIdx.x];
-  uint32_t x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
-  if (lane == 63) wsum[wid] = x;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wid; ++w) woff += wsum[w];
-  row_tot[threadIdx.x] = woff + x - v;
-}
-
 template <typename KeyT, typename ValT, int RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, int shift,
                      int n_blocks, const uint32_t* __restrict__ table,
-                     const uint32_t* __restrict__ digit_base) {
+                     const uint32_t* __restrict__ row_tot /*[256] keys per digit*/) {
   constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
   // cnt[round][wave][digit]: first the number of keys of that digit in that (round, wave), then
   // (after the per-digit prefix) the offset of that group inside the block's digit bucket.
   __shared__ uint16_t cnt[RS_ITEMS][4][256];
   __shared__ uint32_t cursor[256];
-  cursor[threadIdx.x] = table[(size_t)threadIdx.x * n_blocks + blockIdx.x] + digit_base[threadIdx.x];
+  __shared__ uint32_t wtot[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   {
+    // global base of digit d = exclusive scan of the 256 row totals, redone by every block (a
+    // wave scan + 3 adds) instead of a separate one-block launch between the scan and this kernel
+    const uint32_t tot = row_tot[threadIdx.x];
+    uint32_t x = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wtot[wid] = x;
     uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
     for (int i = threadIdx.x; i < RS_ITEMS * 4 * 256 / 2; i += RS_THREADS) z[i] = 0u;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wtot[w];
+    cursor[threadIdx.x] = table[(size_t)threadIdx.x * n_blocks + blockIdx.x] + woff + x - tot;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
   KeyT key[RS_ITEMS];
@@ -138,7 +134,6 @@ radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __
   }
   __syncthreads();
   __shared__ uint32_t dstart[256];  // first local (block-sorted) index of every digit
-  __shared__ uint32_t wtot[4];
   {  // thread d owns digit d: exclusive prefix over the 64 (round, wave) groups, in input order
     unsigned running = 0;
 #pragma unroll
@@ -209,7 +204,7 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
   constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
-  uint32_t* digit_base = table + (size_t)n_blocks * 256;
+  uint32_t* row_tot = table + (size_t)n_blocks * 256;  // keys per digit
   KeyT* ksrc = keysA;
   ValT* vsrc = valsA;
   if (passes == 0) {
@@ -223,10 +218,9 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
     hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
                        n_blocks, table);
-    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, digit_base);
-    hipLaunchKernelGGL(radix_scan_digits_kernel, dim3(1), dim3(256), 0, s, digit_base);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
-                       kdst, vdst, shift, n_blocks, table, digit_base);
+                       kdst, vdst, shift, n_blocks, table, row_tot);
     CLMGS_LAUNCH_CHECK();
     ksrc = kdst;
     vsrc = vdst;

@@ -329,9 +329,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 "aux": torch.cuda.Stream(),
                 "mem": [torch.cuda.Stream(priority=hi) for _ in range(max(2, n_lanes))],
                 "raster": [torch.cuda.Stream(priority=lo) for _ in range(max(2, n_lanes))]}
-            reserve = int(getattr(args, "raster_reserve_cus", 0))
-            if reserve > 0:
-                sts["raster"][0] = _lib.cu_masked_stream(reserve)
+            sts["raster_masked"] = {}
         n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
         if mode == "pipeline":
             # Software pipeline over the cameras of the batch, streams by kernel TYPE:
@@ -342,21 +340,37 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # and the latency-bound kernels fill the memory system underneath it.  The per-camera
             # tensors stay alive until the end-of-batch synchronisation (several streams read them).
             s_front, s_mem, s_raster = sts["mem"][0], sts["mem"][1], sts["raster"][0]
+            # The tile kernels' one-wave workgroups refill every freed wave slot of the chip, so the
+            # multi-wave workgroups of the front end wait for them.  When the front end is the long
+            # pole (many visible rows per tile: 53 at 28 M / 4K, +2 %) some CUs are kept out of the
+            # tile stream's CU mask; with light front ends (19 rows per tile at 10 M: -2.5 %) the
+            # tile kernels keep the whole chip.  raster_reserve_cus: -1 = this rule, >= 0 = fixed.
+            reserve = int(getattr(args, "raster_reserve_cus", -1))
+            if reserve < 0:
+                rows_per_tile = sum(int(f.shape[0]) for f in filters) / float(max(1, bsz) * max(1, n_tiles))
+                reserve = 32 if rows_per_tile >= 32.0 else 0
+            if reserve > 0:
+                if reserve not in sts["raster_masked"]:
+                    sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
+                s_raster = sts["raster_masked"][reserve]
             for st_ in (s_front, s_mem, s_raster):
                 st_.wait_stream(default_stream)
             # the previous batch's per-camera tensors: every stream that read them has been joined
             # into the default stream, which the three streams now wait for -> safe to recycle
             gaussians._clmgs_passes = None
             passes = []
+            # forwards run `depth` cameras ahead of the backwards: RF0 .. RF(depth) RB0 RF(depth+1) RB1 ...
+            depth = max(1, int(getattr(args, "pipeline_depth", 1)))
             for micro_idx in range(bsz):
                 passes.append(camera_forward(
                     gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, background,
                     batched_cameras[micro_idx].original_image, small_packed=small_pk,
                     streams=(s_front, s_mem, s_raster)))
-                if micro_idx >= 1:
-                    losses.append(camera_backward(gaussians, passes[micro_idx - 1], grad_buf, small_gk,
+                if micro_idx >= depth:
+                    losses.append(camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
                                                   stats_delta=stats_d))
-            losses.append(camera_backward(gaussians, passes[-1], grad_buf, small_gk, stats_delta=stats_d))
+            for k in range(max(0, bsz - depth), bsz):
+                losses.append(camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d))
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
             gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)

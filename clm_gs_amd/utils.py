@@ -47,8 +47,9 @@ def default_args(**over):
         # False = the op-by-op gsplat/clm_kernels chain the reference engines spell out
         fused_front_end=True,
         overlap_cameras=True, overlap_lanes=2, packed_small=True, packed_stats=True, exact_tile_cull=True,
+        pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
-        raster_reserve_cus=32,  # CUs the alpha-blend stream may not use (left to the concurrent streams)
+        raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         lazy_dense_adam=True,   # HBM rows: replay zero-gradient Adam steps on demand (exact)   # two cameras of a batch in flight on two HIP streams
     )
     for k, v in over.items():

@@ -3,6 +3,7 @@
 #   r01_bench_28m_latest.log   default `python bench.py` (JSON line incl. roofline + cpu_baseline)
 #   r01_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command, timed region only
 #   r01_timeline_step.txt      busy fraction / per-kernel totals / idle gaps of one step
+#   r01_timeline_streams.txt   the same step per HSA queue (front / memory / tile streams)
 #   r01_pmc_*                  separate --pmc passes (FETCH_SIZE, WRITE_SIZE), --kernel-trace only
 #   r01_bench_28m_no_overlap.log   solo kernel times (single stream)
 set -x
@@ -15,6 +16,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --no
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py "$DB" 160 > $R/gpurun_out/kernel_stats.csv
 python $R/profiles/timeline.py $DB 30 > $R/gpurun_out/timeline_default.txt 2>&1
+python $R/profiles/timeline_streams.py $DB 30 > $R/gpurun_out/timeline_streams.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmcF.log 2>&1
 python $R/profiles/pmc_summary.py $(find /tmp/pmcF -name "*counter_collection.csv" | head -1) > $R/gpurun_out/pmc_fetch.txt 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmcW.log 2>&1
