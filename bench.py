@@ -248,13 +248,19 @@ def main():
     _lib.STATS["n_isects"].clear()
     _lib.STATS["n_emitted"].clear()
     sparsities = []
+    _lib.STATS["host_wait_s"] = 0.0
+    if os.environ.get("CLMGS_HOST_REGIONS") == "1":
+        _lib.HOST_REGIONS = {}
     t0 = time.perf_counter()
     for b in range(a.warmup, a.warmup + a.steps):
         losses, sp = step(b)
         if sp:
             sparsities += sp
+    t_enq = time.perf_counter() - t0  # host: enqueue work + size readbacks, before the final fence
     fence()
     dt = time.perf_counter() - t0
+    host_wait = _lib.STATS["host_wait_s"]
+    host_regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -344,6 +350,10 @@ def main():
         else f"training images/s ({a.config} {a.strategy})",
         "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "host_ms_per_step": {"enqueue": round((t_enq - host_wait) / a.steps * 1e3, 3),
+                             "blocked_in_size_readbacks": round(host_wait / a.steps * 1e3, 3),
+                             **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
+                                if host_regions else {})},
         "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,

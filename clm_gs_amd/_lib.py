@@ -6,6 +6,7 @@ there is deliberately no eager/PyTorch fallback path.
 """
 import ctypes
 import os
+import time
 
 import torch
 
@@ -72,7 +73,7 @@ _lib = None
 # stream-taking call is bracketed by two events recorded on the stream it is launched on.
 TIMING = None
 # Data-dependent sizes seen by the front end (intersections per image), for the same purpose.
-STATS = {"n_isects": [], "n_emitted": []}
+STATS = {"n_isects": [], "n_emitted": [], "host_wait_s": 0.0}  # host_wait_s: time blocked in size readbacks
 
 
 class ClmgsError(RuntimeError):
@@ -139,6 +140,26 @@ def check(rc):
     if rc != 0:
         msg = lib().clmgs_last_error()
         raise ClmgsError(f"libclmgs_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+HOST_REGIONS = None  # set to {} to accumulate host wall time per engine region (diagnostics)
+
+
+class host_region:
+    """with host_region("name"): ...   -- adds the block's host wall time to HOST_REGIONS[name]."""
+    __slots__ = ("name", "t0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if HOST_REGIONS is not None:
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if HOST_REGIONS is not None:
+            HOST_REGIONS[self.name] = HOST_REGIONS.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
 
 
 _HIP = None

@@ -54,8 +54,18 @@ class FusedCPUAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = pinned_empty(tuple(p.shape)).zero_()
 
     def _col_lr(self, device):
-        v = torch.cat([torch.full((n,), float(l)) for n, l in zip(self.columns_sizes, self.columns_lr.tolist())])
-        return v.to(device) if device.type == "cuda" else v
+        """Per-column learning rates as a tensor on `device`.  The device copy is cached per value
+        set: a host->device copy from pageable memory blocks the host until the stream has
+        drained, i.e. it would be a hidden end-of-batch synchronisation."""
+        lrs = tuple(float(l) for l in self.columns_lr.tolist())
+        key = (str(device), lrs)
+        cache = self.__dict__.setdefault("_col_lr_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            v = torch.cat([torch.full((n,), l) for n, l in zip(self.columns_sizes, lrs)])
+            cache[key] = v.to(device) if device.type == "cuda" else v
+        return cache[key]
 
     def _update(self, rows, signal, grad_scale, zero_grad, step):
         g = self.param_groups[0]

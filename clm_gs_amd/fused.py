@@ -94,9 +94,10 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
             dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
             0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
             dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
-        p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect_tiles_two_level(
-            means2d, radii, depths, TILE, tw, th, want_slots=True,
-            packed=packed if getattr(args, "exact_tile_cull", True) else None)
+        with _lib.host_region("fwd_isect"):
+            p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect_tiles_two_level(
+                means2d, radii, depths, TILE, tw, th, want_slots=True,
+                packed=packed if getattr(args, "exact_tile_cull", True) else None)
         p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
         p.alphas = torch.empty((H, W), dtype=F32, device=dev)
         p.last_ids = torch.empty((H, W), dtype=I32, device=dev)

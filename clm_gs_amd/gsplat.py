@@ -8,6 +8,8 @@ backward call the C ABI; there is no eager fallback.
 """
 import math
 
+import time
+
 import torch
 
 from . import _lib
@@ -133,7 +135,9 @@ def visibility_select(means, quats_raw, log_scales, viewmats, Ks, width, height,
         stream(), C, N, dptr(means, F32), dptr(quats_raw, F32), dptr(log_scales, F32), dptr(viewmats, F32),
         dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
         float(radius_clip), dptr(temp), tb, dptr(cum)))
+    _t0 = time.perf_counter()
     ends = cum.tolist()  # the one host sync of the filter stage
+    _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
     out = torch.empty((max(ends[-1], 1),), dtype=I64, device=dev)
     if ends[-1] > 0:
         check(L.clmgs_visibility_select_emit(stream(), C, N, dptr(temp), dptr(out)))
@@ -260,7 +264,9 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
                                      int(tile_size), int(tile_width), int(tile_height),
                                      dptr(packed, F32, True), dptr(order), dptr(cum), dptr(boxes),
                                      dptr(totals), dptr(temp), tb))
+    _t0 = time.perf_counter()
     n_isects, n_ref = totals.tolist()  # the one host sync of the front end
+    _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
     _lib.STATS["n_isects"].append(n_ref)        # the reference's (3-sigma box) intersection count
     _lib.STATS["n_emitted"].append(n_isects)    # what is actually sorted and blended
     if len(_lib.STATS["n_isects"]) > 4096:

@@ -238,8 +238,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         if getattr(args, "fused_front_end", True):
             # same fast exp as the fused front end -> filter and render agree on every cull;
             # filters AND the union of touched rows are selected on the GPU in one pass
-            filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
-                                                   gaussians._scaling.detach(), gaussians._rotation.detach())
+            with _lib.host_region("select_filters"):
+                filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
+                                                       gaussians._scaling.detach(), gaussians._rotation.detach())
         else:
             filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
                                               gaussians.get_scaling, gaussians.get_rotation)
@@ -249,11 +250,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     need_mask = touched_rows is None or args.sparse_adam or dp.world_size() > 1 or not lazy_mode
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
-        if touched_rows is not None:
-            touched[touched_rows] = True
+        if touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
+            touched.index_fill_(0, touched_rows, True)
         else:
             for f in filters:
-                touched[f] = True
+                touched.index_fill_(0, f, True)
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
         if dp.world_size() > 1:
@@ -362,15 +363,18 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # forwards run `depth` cameras ahead of the backwards: RF0 .. RF(depth) RB0 RF(depth+1) RB1 ...
             depth = max(1, int(getattr(args, "pipeline_depth", 1)))
             for micro_idx in range(bsz):
-                passes.append(camera_forward(
-                    gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, background,
-                    batched_cameras[micro_idx].original_image, small_packed=small_pk,
-                    streams=(s_front, s_mem, s_raster)))
+                with _lib.host_region("camera_forward"):
+                    passes.append(camera_forward(
+                        gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, background,
+                        batched_cameras[micro_idx].original_image, small_packed=small_pk,
+                        streams=(s_front, s_mem, s_raster)))
                 if micro_idx >= depth:
-                    losses.append(camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
-                                                  stats_delta=stats_d))
+                    with _lib.host_region("camera_backward"):
+                        losses.append(camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
+                                                      stats_delta=stats_d))
             for k in range(max(0, bsz - depth), bsz):
-                losses.append(camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d))
+                with _lib.host_region("camera_backward"):
+                    losses.append(camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d))
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
             gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)
@@ -431,7 +435,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     if not args.stop_update_param:
         row_update(touched_rows)
         if lazy:
-            gaussians._row_last_step[touched_rows.long()] = step
+            # index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host
+            # scalar to the device and block the host until the whole batch has drained
+            gaussians._row_last_step.index_fill_(0, touched_rows.long(), step)
     st["step"] = step
     if side_event is not None:
         default_stream.wait_event(side_event)
@@ -562,8 +568,9 @@ def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_gr
     bsz = len(batched_cameras)
     assert bsz > 1 and bsz in _BITMAP_DTYPE, "clm_offload supports bsz in (4, 8, 16, 32, 64)"
     if gaussians._parameters.is_cuda:
-        return _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer,
-                                    background, pipe_args, comm_stream, args)
+        with _lib.host_region("batch_total"):
+            return _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer,
+                                        background, pipe_args, comm_stream, args)
     return _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer,
                                  background, pipe_args, comm_stream, perm_generator, args)
 
