@@ -1,0 +1,37 @@
+"""The host constants a Camera caches at construction are exactly what fused._cam_host reads
+back from the device tensors (scene/cameras.py:39-126 convention)."""
+import numpy as np
+import torch
+
+
+def test_cached_host_constants_equal_device_readback():
+    from clm_gs_amd.cameras import Camera
+    from clm_gs_amd.fused import _cam_host
+    g = torch.Generator().manual_seed(0)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    w2c = torch.eye(4)
+    w2c[:3, :3] = q
+    w2c[:3, 3] = torch.randn(3, generator=g)
+    cam = Camera(3, w2c, 1.1, 0.7, 640, 480, device="cpu")
+    cached = cam._clmgs_host
+    del cam._clmgs_host
+    fresh = _cam_host(cam)
+    for a, b in zip(cached, fresh):
+        assert a.dtype == np.float32 and a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+
+
+def test_column_lr_table_is_cached_per_value_set():
+    """FusedCPUAdam._col_lr: one tensor per set of learning rates (its device copy must not be
+    rebuilt -- and re-uploaded, which blocks the host -- every batch), refreshed when a rate changes."""
+    from clm_gs_amd.cpu_adam import FusedCPUAdam
+    p = torch.nn.Parameter(torch.zeros(5, 48))
+    opt = FusedCPUAdam([p], columns_sizes=[3, 45], columns_lr=[0.0025, 0.000125],
+                       state_tensors=(torch.zeros(5, 48), torch.zeros(5, 48)))  # no pinned allocation on CPU
+    dev = torch.device("cpu")
+    a = opt._col_lr(dev)
+    assert a.shape == (48,) and torch.allclose(a[:3], torch.tensor(0.0025)) and torch.allclose(a[3:], torch.tensor(0.000125))
+    assert opt._col_lr(dev) is a
+    opt.columns_lr[0] = 0.001
+    b = opt._col_lr(dev)
+    assert b is not a and torch.allclose(b[:3], torch.tensor(0.001)) and torch.allclose(b[3:], torch.tensor(0.000125))
