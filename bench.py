@@ -249,17 +249,23 @@ def main():
     _lib.STATS["n_emitted"].clear()
     sparsities = []
     _lib.STATS["host_wait_s"] = 0.0
+    ms0 = torch.cuda.memory_stats()
     if os.environ.get("CLMGS_HOST_REGIONS") == "1":
         _lib.HOST_REGIONS = {}
     t0 = time.perf_counter()
+    step_marks = []
     for b in range(a.warmup, a.warmup + a.steps):
         losses, sp = step(b)
+        step_marks.append(time.perf_counter())
         if sp:
             sparsities += sp
     t_enq = time.perf_counter() - t0  # host: enqueue work + size readbacks, before the final fence
     fence()
     dt = time.perf_counter() - t0
     host_wait = _lib.STATS["host_wait_s"]
+    ms1 = torch.cuda.memory_stats()
+    dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
+    dev_frees = int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0))
     host_regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -352,6 +358,8 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "host_ms_per_step": {"enqueue": round((t_enq - host_wait) / a.steps * 1e3, 3),
                              "blocked_in_size_readbacks": round(host_wait / a.steps * 1e3, 3),
+                             "step_returns_ms": [round((t - t0) * 1e3, 2) for t in step_marks],
+                             "device_mallocs_in_timed_region": dev_allocs, "device_frees_in_timed_region": dev_frees,
                              **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
                                 if host_regions else {})},
         "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic",

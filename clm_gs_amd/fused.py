@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, utils
 from ._lib import check, dptr, stream
-from .gsplat import isect_tiles_two_level
+from .gsplat import isect2_begin, isect2_finish
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
@@ -46,7 +46,8 @@ class _CameraPass:
     until the streams involved have consumed it)."""
     __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
                  "packed", "fids", "offsets", "emit_slot", "order", "cum", "out", "alphas", "last_ids",
-                 "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux")
+                 "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux", "loss_partials",
+                 "lambda_dssim", "gt_u8", "background", "isect")
 
 
 def _sptr(torch_stream):
@@ -59,7 +60,17 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
     backward (stream `mem`) of one camera; returns the _CameraPass for camera_backward.  The three
     streams may be one and the same; distinct streams are chained by events, so the caller can put
     all cameras' tile kernels on one low-priority stream and order them RF0 RF1 RB0 RF2 RB1 ...
-    (software pipelining over the cameras of a batch: the tile stream never waits for a loss)."""
+    (software pipelining over the cameras of a batch: the tile stream never waits for a loss).
+    = camera_front (nothing blocks) + camera_forward_finish (waits for the intersection count)."""
+    return camera_forward_finish(gaussians, camera_front(
+        gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8, lambda_dssim,
+        small_packed, streams))
+
+
+def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
+                 lambda_dssim=0.2, small_packed=None, streams=None):
+    """Projection and the first half of the binning (depth order, per-row tile counts, asynchronous
+    readback of the intersection count) on stream `front`; no host wait."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -73,6 +84,7 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
     vm, K, campos = p.cam
     deg = p.deg = int(gaussians.active_sh_degree)
     p.sh_rows, p.sh_by_filter, p.small_packed = sh_rows, sh_by_filter, small_packed
+    p.gt_u8, p.lambda_dssim, p.background = gt_u8, float(lambda_dssim), background
     filt = p.filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
     if small_packed is not None:
         small_in = (dptr(small_packed, F32), None, None, None)
@@ -94,15 +106,28 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
             dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
             0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
             dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
+        p.isect = isect2_begin(means2d, radii, depths, TILE, tw, th, want_slots=True,
+                               packed=packed if getattr(args, "exact_tile_cull", True) else None)
+        p.aux = p.aux + (means2d, depths)
+    return p
+
+
+def camera_forward_finish(gaussians, p):
+    """Second half of the binning (waits for the count), alpha-blend forward, loss forward + backward."""
+    L = _lib.lib()
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    dev = gaussians._xyz.device
+    s_front, s_mem, s_raster = p.streams
+    V, packed, background, gt_u8, lambda_dssim = p.V, p.packed, p.background, p.gt_u8, p.lambda_dssim
+    tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
+    with torch.cuda.stream(s_front):
         with _lib.host_region("fwd_isect"):
-            p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect_tiles_two_level(
-                means2d, radii, depths, TILE, tw, th, want_slots=True,
-                packed=packed if getattr(args, "exact_tile_cull", True) else None)
+            p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect2_finish(p.isect)
+        p.isect = None
         p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
         p.alphas = torch.empty((H, W), dtype=F32, device=dev)
         p.last_ids = torch.empty((H, W), dtype=I32, device=dev)
         p.bg = background.reshape(1, 3).to(F32).contiguous() if background is not None else None
-        p.aux = p.aux + (means2d, depths)
     if s_raster is not s_front:
         s_raster.wait_stream(s_front)
     n_isects = p.fids.numel()
@@ -123,20 +148,32 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
         sm = _sptr(s_mem)
         check(L.clmgs_l1_ssim_loss_fwd(sm, H, W, dptr(p.out), sc, sy, sx, dptr(gt, U8), dptr(partials),
                                        dptr(maps[0]), dptr(maps[1]), dptr(maps[2])))
-        tot = partials.sum(dim=0) / float(3 * H * W)
-        loss = (1.0 - lambda_dssim) * tot[0] + lambda_dssim * (1.0 - tot[1])
-        one = torch.ones((1,), dtype=F32, device=dev)
+        # the loss VALUE is not needed by the backward (d loss / d loss = 1): its handful of tiny
+        # reduction kernels is enqueued by camera_loss(), off the forward -> backward chain
+        p.loss_partials, p.loss = partials, None
+        one = getattr(gaussians, "_clmgs_one", None)
+        if one is None or one.device != dev:
+            one = gaussians._clmgs_one = torch.ones((1,), dtype=F32, device=dev)
         p.v_out = torch.empty_like(p.out)
         check(L.clmgs_l1_ssim_loss_bwd(sm, H, W, dptr(p.out), sc, sy, sx, dptr(gt, U8), dptr(one),
                                        float(lambda_dssim), dptr(maps[0]), dptr(maps[1]), dptr(maps[2]),
                                        dptr(p.v_out)))
-        p.loss = loss.detach()
         p.ev_loss = None
         if s_raster is not s_mem:
             p.ev_loss = torch.cuda.Event()
             p.ev_loss.record(s_mem)
         p.aux = p.aux + (gt, one, partials)
     return p
+
+
+def camera_loss(p):
+    """The camera's loss value (0-dim tensor) from the partial sums its forward left; enqueued on
+    the CURRENT stream, which must be ordered after the camera's loss kernel."""
+    if p.loss is None:
+        W, H = int(utils.get_img_width()), int(utils.get_img_height())
+        tot = p.loss_partials.sum(dim=0) / float(3 * H * W)
+        p.loss = ((1.0 - p.lambda_dssim) * tot[0] + p.lambda_dssim * (1.0 - tot[1])).detach()
+    return p.loss
 
 
 def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True, stats_delta=None,
@@ -191,7 +228,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
             dptr(packed_grad), *small_out, dptr(g_sh_rows, F32, allow_host=True),
             *stat_ptrs, None, int(bool(stats_only_visible))))
     p.aux = p.aux + (packed_grad, partials)
-    return p.loss
+    return p
 
 
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
@@ -215,8 +252,9 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     cur = torch.cuda.current_stream()
     p = camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
                        lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur))
-    loss = camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
-                           stats_only_visible, visibility_out, accumulate_after)
+    camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
+                    stats_only_visible, visibility_out, accumulate_after)
+    loss = camera_loss(p)  # on `cur`, which the loss kernels ran on
     if keep is not None:
         keep.append(p)
     if return_event:

@@ -234,38 +234,73 @@ def isect_offset_encode(isect_ids, n_cameras, tile_width, tile_height):
     return offsets
 
 
+_PINNED_TOTALS = None  # ring of pinned int64[2] slots for the asynchronous size readbacks
+_PINNED_NEXT = 0
+
+
+def _pinned_totals_slot():
+    global _PINNED_TOTALS, _PINNED_NEXT
+    if _PINNED_TOTALS is None:
+        _PINNED_TOTALS = torch.empty((256, 2), dtype=I64).pin_memory()
+    _PINNED_NEXT = (_PINNED_NEXT + 1) % _PINNED_TOTALS.shape[0]
+    return _PINNED_TOTALS[_PINNED_NEXT]
+
+
+class _Isect2:
+    """State between isect2_begin and isect2_finish (one camera's binning in flight)."""
+    __slots__ = ("args", "V", "dev", "depths", "order", "cum", "boxes", "totals", "host", "event",
+                 "offsets", "temp", "means2d", "radii", "packed")
+
+
 @torch.no_grad()
-def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_height,
-                          want_isect_ids=False, want_slots=False, packed=None):
-    """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
-    sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
-    identical to isect_tiles + isect_offset_encode for C = 1.  want_slots: a 4th result
-    (emit_slot[I] i32, order[V] i32, cum[V] i64) for the atomic-free rasterize backward: rank j
-    (row order[j]) owns the contiguous emit range [cum[j-1], cum[j]).
-    packed: the [V,16] raster records -> EXACT per-tile culling (pairs whose tile cannot reach
-    alpha >= 1/255 are not emitted; image and gradients unchanged, the list gets ~29 % shorter)."""
+def isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height, want_isect_ids=False,
+                 want_slots=False, packed=None):
+    """First half of isect_tiles_two_level: depth order + per-row tile counts on the CURRENT stream,
+    then an asynchronous copy of the two totals into pinned memory and an event.  Nothing blocks:
+    the caller can enqueue other work (the next camera's projection) before isect2_finish waits for
+    the event -- unlike a `.tolist()`, which waits for everything enqueued on the stream so far."""
     L = _lib.lib()
-    V = radii.numel()
-    dev = radii.device
-    means2d, radii, depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
-    offsets = torch.empty((1, tile_height, tile_width), dtype=I32, device=dev)
+    c = _Isect2()
+    c.args = (int(tile_size), int(tile_width), int(tile_height), bool(want_isect_ids), bool(want_slots))
+    V = c.V = radii.numel()
+    dev = c.dev = radii.device
+    c.means2d, c.radii, c.depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    c.packed = packed
+    c.offsets = torch.empty((1, tile_height, tile_width), dtype=I32, device=dev)
+    c.event = None
     if V == 0:
-        offsets.zero_()
-        e = torch.empty(0, dtype=I32, device=dev)
-        res = (e, offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
-        return res + ((e, e.clone(), torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
-    order = torch.empty((V,), dtype=I32, device=dev)
-    cum = torch.empty((V,), dtype=I64, device=dev)
-    boxes = torch.empty((V, 2), dtype=I64, device=dev)
-    totals = torch.empty((2,), dtype=I64, device=dev)
+        return c
+    c.order = torch.empty((V,), dtype=I32, device=dev)
+    c.cum = torch.empty((V,), dtype=I64, device=dev)
+    c.boxes = torch.empty((V, 2), dtype=I64, device=dev)
+    c.totals = torch.empty((2,), dtype=I64, device=dev)
     tb = L.clmgs_isect2_order_temp_bytes(V)
-    temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
-    check(L.clmgs_isect2_order_count(stream(), V, dptr(means2d, F32), dptr(radii, I32), dptr(depths, F32),
-                                     int(tile_size), int(tile_width), int(tile_height),
-                                     dptr(packed, F32, True), dptr(order), dptr(cum), dptr(boxes),
-                                     dptr(totals), dptr(temp), tb))
+    c.temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    check(L.clmgs_isect2_order_count(stream(), V, dptr(c.means2d, F32), dptr(c.radii, I32), dptr(c.depths, F32),
+                                     c.args[0], c.args[1], c.args[2], dptr(packed, F32, True), dptr(c.order),
+                                     dptr(c.cum), dptr(c.boxes), dptr(c.totals), dptr(c.temp), tb))
+    c.host = _pinned_totals_slot()
+    c.host.copy_(c.totals, non_blocking=True)
+    c.event = torch.cuda.Event()
+    c.event.record(torch.cuda.current_stream())
+    return c
+
+
+@torch.no_grad()
+def isect2_finish(c):
+    """Second half: wait for the totals (the one host wait of the front end), then emit + tile sort +
+    offsets on the CURRENT stream (the stream isect2_begin ran on, or one ordered after it)."""
+    L = _lib.lib()
+    tile_size, tile_width, tile_height, want_isect_ids, want_slots = c.args
+    dev, V = c.dev, c.V
+    if V == 0:
+        c.offsets.zero_()
+        e = torch.empty(0, dtype=I32, device=dev)
+        res = (e, c.offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
+        return res + ((e, e.clone(), torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
     _t0 = time.perf_counter()
-    n_isects, n_ref = totals.tolist()  # the one host sync of the front end
+    c.event.synchronize()
+    n_isects, n_ref = int(c.host[0]), int(c.host[1])
     _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
     _lib.STATS["n_isects"].append(n_ref)        # the reference's (3-sigma box) intersection count
     _lib.STATS["n_emitted"].append(n_isects)    # what is actually sorted and blended
@@ -277,10 +312,25 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
     temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
     emit_slot = torch.empty((n_isects,), dtype=I32, device=dev) if want_slots else None
-    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(depths), dptr(order), dptr(cum), dptr(boxes),
-                                   int(tile_width), int(tile_height), dptr(fids), dptr(offsets),
+    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(c.depths), dptr(c.order), dptr(c.cum),
+                                   dptr(c.boxes), tile_width, tile_height, dptr(fids), dptr(c.offsets),
                                    dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb))
-    return (fids, offsets, ids, (emit_slot, order, cum)) if want_slots else (fids, offsets, ids)
+    return (fids, c.offsets, ids, (emit_slot, c.order, c.cum)) if want_slots else (fids, c.offsets, ids)
+
+
+@torch.no_grad()
+def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_height,
+                          want_isect_ids=False, want_slots=False, packed=None):
+    """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
+    sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
+    identical to isect_tiles + isect_offset_encode for C = 1.  want_slots: a 4th result
+    (emit_slot[I] i32, order[V] i32, cum[V] i64) for the atomic-free rasterize backward: rank j
+    (row order[j]) owns the contiguous emit range [cum[j-1], cum[j]).
+    packed: the [V,16] raster records -> EXACT per-tile culling (pairs whose tile cannot reach
+    alpha >= 1/255 are not emitted; image and gradients unchanged, the list gets ~29 % shorter).
+    = isect2_begin + isect2_finish back to back."""
+    return isect2_finish(isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height,
+                                      want_isect_ids, want_slots, packed))
 
 
 # ---------------------------------------------------------------------- rasterize

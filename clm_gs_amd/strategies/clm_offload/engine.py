@@ -316,7 +316,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # Two cameras in flight on two streams: the ALU-bound tile kernels of one overlap with the
         # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
         # events so the read-modify-write gradient sums stay ordered.
-        from ...fused import camera_backward, camera_forward, train_one_camera
+        from ...fused import (camera_backward, camera_forward_finish, camera_front, camera_loss,
+                              train_one_camera)
         mode = getattr(args, "overlap_cameras", True)
         mode = {True: "pipeline", False: "off"}.get(mode, mode)
         n_lanes = max(1, int(getattr(args, "overlap_lanes", 2)))
@@ -331,6 +332,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 "mem": [torch.cuda.Stream(priority=hi) for _ in range(max(2, n_lanes))],
                 "raster": [torch.cuda.Stream(priority=lo) for _ in range(max(2, n_lanes))]}
             sts["raster_masked"] = {}
+            sts["front2"] = torch.cuda.Stream(priority=hi)
         n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
         if mode == "pipeline":
             # Software pipeline over the cameras of the batch, streams by kernel TYPE:
@@ -354,7 +356,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 if reserve not in sts["raster_masked"]:
                     sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
                 s_raster = sts["raster_masked"][reserve]
-            for st_ in (s_front, s_mem, s_raster):
+            if getattr(gaussians, "_clmgs_one", None) is None:  # the loss cotangent (1.0), made on the
+                gaussians._clmgs_one = torch.ones((1,), dtype=torch.float32, device=params.device)  # default stream
+            for st_ in (s_front, sts["front2"], s_mem, s_raster):
                 st_.wait_stream(default_stream)
             # the previous batch's per-camera tensors: every stream that read them has been joined
             # into the default stream, which the three streams now wait for -> safe to recycle
@@ -362,21 +366,40 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             passes = []
             # forwards run `depth` cameras ahead of the backwards: RF0 .. RF(depth) RB0 RF(depth+1) RB1 ...
             depth = max(1, int(getattr(args, "pipeline_depth", 1)))
+            # front_ahead: the host stays one camera ahead of the device (projection + tile counting
+            # of camera k+1 enqueued on a second front stream before the host waits for camera k's
+            # intersection count; the wait is an event on an asynchronous readback either way).
+            # Measured 3 % SLOWER than the plain order (the early kernels co-run with camera k's
+            # tile sort, which is on the chain to RF_k), so it is off by default.
+            ahead = bool(getattr(args, "front_ahead", False))
+            fronts = (s_front, sts["front2"]) if ahead else (s_front, s_front)
+
+            def _front(k):
+                with _lib.host_region("camera_front"):
+                    return camera_front(
+                        gaussians, batched_cameras[k], filters[k], params.data, 1, background,
+                        batched_cameras[k].original_image, small_packed=small_pk,
+                        streams=(fronts[k % 2], s_mem, s_raster))
+
+            nxt = _front(0)
             for micro_idx in range(bsz):
+                if ahead:
+                    cur_pass, nxt = nxt, (_front(micro_idx + 1) if micro_idx + 1 < bsz else None)
+                else:
+                    cur_pass = nxt if micro_idx == 0 else _front(micro_idx)
                 with _lib.host_region("camera_forward"):
-                    passes.append(camera_forward(
-                        gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, background,
-                        batched_cameras[micro_idx].original_image, small_packed=small_pk,
-                        streams=(s_front, s_mem, s_raster)))
+                    passes.append(camera_forward_finish(gaussians, cur_pass))
                 if micro_idx >= depth:
                     with _lib.host_region("camera_backward"):
-                        losses.append(camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
-                                                      stats_delta=stats_d))
+                        camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
+                                        stats_delta=stats_d)
             for k in range(max(0, bsz - depth), bsz):
                 with _lib.host_region("camera_backward"):
-                    losses.append(camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d))
+                    camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d)
+            default_stream.wait_stream(fronts[1])
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
+            losses = [camera_loss(p_) for p_ in passes]  # loss values: after the join, off the chain
             gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)
         else:
             rasters = None

@@ -47,6 +47,8 @@ def default_args(**over):
         # False = the op-by-op gsplat/clm_kernels chain the reference engines spell out
         fused_front_end=True,
         overlap_cameras=True, overlap_lanes=2, packed_small=True, packed_stats=True, exact_tile_cull=True,
+        front_ahead=False,  # True: camera k+1's projection + tile counting enqueued (2nd front stream) before the
+                            # host waits for camera k's count; measured -3 %: they then co-run with camera k's sort
         pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
