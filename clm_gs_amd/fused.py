@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, utils
 from ._lib import check, dptr, stream
-from .gsplat import isect2_begin, isect2_finish
+from .gsplat import empty_bucketed, isect2_begin, isect2_finish
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
@@ -97,10 +97,11 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
     p.small_in = small_in
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
     with torch.cuda.stream(s_front):
-        radii = p.radii = torch.empty((1, V), dtype=I32, device=dev)
-        means2d = torch.empty((1, V, 2), dtype=F32, device=dev)
-        depths = torch.empty((1, V), dtype=F32, device=dev)
-        packed = p.packed = torch.empty((V, 16), dtype=F32, device=dev)
+        # data-dependent sizes -> bucketed capacity (gsplat.bucket_size): no hipMalloc mid-step
+        radii = p.radii = empty_bucketed(V, (), I32, dev).reshape(1, V)
+        means2d = empty_bucketed(V, (2,), F32, dev).reshape(1, V, 2)
+        depths = empty_bucketed(V, (), F32, dev).reshape(1, V)
+        packed = p.packed = empty_bucketed(V, (16,), F32, dev)
         check(L.clmgs_preprocess_fwd(
             _sptr(s_front), V, dptr(filt, torch.int64, True), *small_in,
             dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
@@ -196,9 +197,9 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
                      dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
     with torch.cuda.stream(s_mem):
-        packed_grad = torch.empty_like(p.packed)
+        packed_grad = empty_bucketed(V, (16,), F32, dev)
         # atomic-free accumulation: one 64 B line per intersection, summed per row afterwards
-        partials = torch.empty((max(n_isects, 1), 16), dtype=F32, device=dev)
+        partials = empty_bucketed(max(n_isects, 1), (16,), F32, dev)
     if p.ev_loss is not None:
         s_raster.wait_event(p.ev_loss)
     check(L.clmgs_rasterize_bwd(_sptr(s_raster), 1, V, n_isects, dptr(p.packed), dptr(p.bg, F32, True), W, H,

@@ -234,6 +234,24 @@ def isect_offset_encode(isect_ids, n_cameras, tile_width, tile_height):
     return offsets
 
 
+def bucket_size(n):
+    """n rounded up to 1/8 steps of its leading power of two (<= 12.5 % more).  The data-dependent
+    buffers of a camera (rows V, intersections I) are allocated at bucketed capacity and viewed
+    [:n]: the same few sizes then recur batch after batch and the caching allocator serves them
+    from its cache instead of calling hipMalloc in the middle of a step (a 9 ms stall when it
+    happened inside the 5 timed steps of the bench)."""
+    n = int(n)
+    if n <= 4096:
+        return 4096
+    sh = n.bit_length() - 4
+    return ((n + (1 << sh) - 1) >> sh) << sh
+
+
+def empty_bucketed(n, trailing, dtype, device):
+    """torch.empty((n, *trailing)) backed by a bucket_size(n)-row allocation."""
+    return torch.empty((bucket_size(n),) + tuple(trailing), dtype=dtype, device=device)[:n]
+
+
 _PINNED_TOTALS = None  # ring of pinned int64[2] slots for the asynchronous size readbacks
 _PINNED_NEXT = 0
 
@@ -270,12 +288,12 @@ def isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height, wan
     c.event = None
     if V == 0:
         return c
-    c.order = torch.empty((V,), dtype=I32, device=dev)
-    c.cum = torch.empty((V,), dtype=I64, device=dev)
-    c.boxes = torch.empty((V, 2), dtype=I64, device=dev)
+    c.order = empty_bucketed(V, (), I32, dev)
+    c.cum = empty_bucketed(V, (), I64, dev)
+    c.boxes = empty_bucketed(V, (2,), I64, dev)
     c.totals = torch.empty((2,), dtype=I64, device=dev)
     tb = L.clmgs_isect2_order_temp_bytes(V)
-    c.temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+    c.temp = empty_bucketed(tb, (), torch.uint8, dev)
     check(L.clmgs_isect2_order_count(stream(), V, dptr(c.means2d, F32), dptr(c.radii, I32), dptr(c.depths, F32),
                                      c.args[0], c.args[1], c.args[2], dptr(packed, F32, True), dptr(c.order),
                                      dptr(c.cum), dptr(c.boxes), dptr(c.totals), dptr(c.temp), tb))
@@ -307,11 +325,11 @@ def isect2_finish(c):
     if len(_lib.STATS["n_isects"]) > 4096:
         del _lib.STATS["n_isects"][:2048]
         del _lib.STATS["n_emitted"][:2048]
-    fids = torch.empty((n_isects,), dtype=I32, device=dev)
-    ids = torch.empty((n_isects,), dtype=I64, device=dev) if want_isect_ids else None
+    fids = empty_bucketed(n_isects, (), I32, dev)
+    ids = empty_bucketed(n_isects, (), I64, dev) if want_isect_ids else None
     sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
-    temp2 = torch.empty((sb,), dtype=torch.uint8, device=dev)
-    emit_slot = torch.empty((n_isects,), dtype=I32, device=dev) if want_slots else None
+    temp2 = empty_bucketed(sb, (), torch.uint8, dev)
+    emit_slot = empty_bucketed(n_isects, (), I32, dev) if want_slots else None
     check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(c.depths), dptr(c.order), dptr(c.cum),
                                    dptr(c.boxes), tile_width, tile_height, dptr(fids), dptr(c.offsets),
                                    dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb))

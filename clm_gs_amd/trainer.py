@@ -7,6 +7,7 @@ epilogue (:533-578), the end-to-end timer that pauses during evaluation (:438-44
 87-111), and the exact log strings release_scripts/log2csv.py:54-102 scrapes.  Dataset readers,
 checkpoint directories and CLI plumbing are out of scope: cameras are handed in as objects.
 """
+import gc
 import random
 import time
 
@@ -118,6 +119,10 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
                 gaussians.get_xyz, gaussians.get_opacity, gaussians.get_scaling, gaussians.get_rotation,
                 gaussians.get_features, gaussians.active_sh_degree, cam, background, mode="test")
             return img
+    # a full cyclic GC pass over torch's ~10^6 long-lived objects stalls the enqueueing thread for
+    # ~100 ms: freeze what exists now, later collections only see what the loop allocates
+    gc.collect()
+    gc.freeze()
     rng = random.Random(shuffle_seed)
     order = []
     timer = End2endTimer()

@@ -35,3 +35,20 @@ def test_column_lr_table_is_cached_per_value_set():
     opt.columns_lr[0] = 0.001
     b = opt._col_lr(dev)
     assert b is not a and torch.allclose(b[:3], torch.tensor(0.001)) and torch.allclose(b[3:], torch.tensor(0.000125))
+
+
+def test_bucket_size_properties():
+    """Capacity buckets of the data-dependent buffers: >= n, at most 12.5 % more (beyond the 4096
+    floor), monotone, idempotent, and few distinct values over a +-5 % spread of sizes."""
+    from clm_gs_amd.gsplat import bucket_size
+    prev = 0
+    for n in list(range(0, 20000, 37)) + [10 ** 6 + k * 9973 for k in range(200)] + [8631784, 12085881, 2 ** 31 - 1]:
+        b = bucket_size(n)
+        assert b >= n and bucket_size(b) == b
+        if n > 4096:
+            assert b <= n * 1.125 + 1
+    for n in range(0, 3_000_000, 1013):
+        b = bucket_size(n)
+        assert b >= prev
+        prev = b
+    assert len({bucket_size(int(8.6e6 * (1 + 0.05 * (k - 10) / 10))) for k in range(21)}) <= 3
