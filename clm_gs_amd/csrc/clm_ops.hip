@@ -217,7 +217,15 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
     if (missed <= 0) continue;
     const int64_t o = row * cols + k;
     float mm[VEC], vv[VEC], pp[VEC], lr[VEC];
-    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv);
+    {  // all-zero state (rows that never had a gradient): every replayed step is the identity
+       // (m, v stay 0 and p -= lr * 0 / (0 + eps)), so neither the loop nor the stores are needed
+      bool any_state = false;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) any_state |= (mm[c] != 0.f) | (vv[c] != 0.f);
+      if (!any_state) continue;
+    }
+    vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
     if (missed > max_replay) {
       const int d = missed - max_replay;
       const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
