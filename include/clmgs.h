@@ -258,8 +258,10 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
 /* Deferred dense Adam: replay, for the listed rows (NULL = rows 0..n_rows-1), the zero-gradient
  * updates of steps last_step[row]+1 .. to_step (moment decay + parameter step, same per-element
  * operations as clmgs_adam_rows with g == NULL, bias corrections from a running product).  The
- * caller then sets last_step[rows] = to_step.  Steps older than max_replay are folded into the
- * moments analytically (their parameter increments are below float resolution). */
+ * caller then sets last_step[rows] = to_step.  Only the first max_replay missed steps are replayed
+ * exactly; for the rest the moments are decayed analytically (the first moment has decayed by
+ * beta1^max_replay by then, the parameter increments are below float resolution).  Elements whose
+ * moments are both zero are left untouched (every replayed step is the identity for them). */
 /* The packed [N,12] mirror of the four GPU-resident parameter tensors, and their dense Adam when the
  * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
  * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a

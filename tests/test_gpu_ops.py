@@ -514,6 +514,41 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
         assert rel_l2(x.reshape(ref.grad.shape), ref.grad) < GRAD_TOL, name
 
 
+def test_adam_catch_up_equals_replayed_zero_gradient_steps(dev):
+    """clmgs_adam_catch_up == the eager zero-gradient updates it defers (clmgs_adam_rows with
+    g = NULL, step by step): rows at different staleness, rows whose moments are all zero (left
+    untouched, bit for bit), and the max_replay cut (first max_replay steps exact, then only the
+    moments decay)."""
+    from clm_gs_amd import clm_kernels as K
+    g = torch.Generator(device="cuda").manual_seed(2)
+    n, cols, b1, b2, eps = 3000, 48, 0.9, 0.999, 1e-15
+    col_lr = torch.cat([torch.full((3,), 2.5e-3), torch.full((45,), 1.25e-4)]).cuda()
+    p0 = torch.randn(n, cols, generator=g, device="cuda")
+    m0 = torch.randn(n, cols, generator=g, device="cuda") * 1e-3
+    v0 = torch.rand(n, cols, generator=g, device="cuda") * 1e-6
+    zero_rows = torch.arange(0, n, 7, device="cuda")
+    m0[zero_rows] = 0.0
+    v0[zero_rows] = 0.0
+    last = torch.randint(3, 12, (n,), generator=g, device="cuda", dtype=torch.int32)
+    to_step = 14
+    for max_replay in (256, 4):
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        K.adam_catch_up(p, m, v, last.clone(), None, col_lr, b1, b2, eps, to_step, True, max_replay=max_replay)
+        pe, me, ve = p0.clone(), m0.clone(), v0.clone()
+        pcut = None
+        for step in range(4, to_step + 1):           # eager: every step, rows that have missed it
+            rows = torch.nonzero(last < step).flatten().to(torch.int32)
+            if max_replay == 4:                      # p frozen after a row's first 4 replayed steps
+                frozen = rows[(step - last[rows.long()]) > 4]
+                keep = pe[frozen.long()].clone()
+            K.adam_rows(pe, None, me, ve, rows, col_lr, b1, b2, eps, step, True, 1.0, False)
+            if max_replay == 4:
+                pe[frozen.long()] = keep
+        assert torch.equal(p[zero_rows], p0[zero_rows]) and float(m[zero_rows].abs().max()) == 0.0
+        assert rel_l2(p, pe) < 1e-7 and rel_l2(m, me) < 1e-6 and rel_l2(v, ve) < 1e-6
+        assert (p - pe).abs().max() < 5e-6   # bias corrections: running product vs pow()
+
+
 def test_visibility_select_equals_radii_nonzero(dev):
     """GPU-side filter selection == nonzero(radii > 0) per camera, and its extra row == the union."""
     from clm_gs_amd import gsplat as G
