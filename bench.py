@@ -162,7 +162,7 @@ def main():
             dist.init_process_group(backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
 
-    from clm_gs_amd import _lib, dp, utils
+    from clm_gs_amd import _lib, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 
     N, W, H, bsz, vis_frac, desc = CONFIGS[a.config]

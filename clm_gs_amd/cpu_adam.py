@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import _lib
-from .host import is_pinned, pinned_empty
+from .host import pinned_empty
 
 
 def _p(t):

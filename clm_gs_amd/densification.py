@@ -1,5 +1,4 @@
 """Densification schedule and per-micro-batch statistics (reference: densification.py:5-147)."""
-import torch
 
 from . import dp, utils
 from .clm_kernels import densify_stats

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, utils
-from ._lib import check, dptr, stream
+from ._lib import check, dptr
 from .gsplat import empty_bucketed, isect2_begin, isect2_finish
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8

@@ -6,7 +6,6 @@ and return shapes, served by the gfx950 kernels of libclmgs_hip.so.
 Differentiable operators are ``torch.autograd.Function``s whose forward and
 backward call the C ABI; there is no eager fallback.
 """
-import math
 
 import time
 

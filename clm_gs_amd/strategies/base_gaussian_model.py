@@ -8,7 +8,6 @@ from abc import ABC, abstractmethod
 
 import numpy as np
 import torch
-from torch import nn
 
 from .. import utils
 from ..clm_kernels import densify_stats

@@ -1,6 +1,5 @@
 """GaussianModelNoOffload: all six parameter tensors live on the GPU
 (reference: strategies/no_offload/gaussian_model.py:27-813)."""
-import numpy as np
 import torch
 from torch import nn
 

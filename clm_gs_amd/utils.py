@@ -6,7 +6,6 @@ restates check_update_at_this_iter (:130-142), inverse_sigmoid (:145-146) and
 get_expon_lr_func (:259-292) so engine code reads like the reference's.
 """
 import io
-import math
 import time
 from types import SimpleNamespace
 

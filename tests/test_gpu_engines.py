@@ -6,7 +6,6 @@
   same way: strategy-vs-strategy agreement, release_scripts/mip360_README.md:52-62);
 * densification surgery keeps every tensor and optimizer state aligned.
 """
-import math
 
 import pytest
 import torch
