@@ -24,3 +24,12 @@ python $R/profiles/pmc_summary.py $(find /tmp/pmcW -name "*counter_collection.cs
 cd $R
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt overlap_cameras=false > gpurun_out/ab0.log 2>&1
 python profiles/show_bench.py gpurun_out/ab0.log | tail -18
+# SQ counters of the final build, single stream (solo kernels): VALU issue utilisation of the tile kernels
+cd /tmp
+for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+  rm -rf /tmp/pmcS
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcS -o s -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --prime-seconds 0 --opt overlap_cameras=false > $R/gpurun_out/pmcS.log 2>&1
+  echo "== $SET" >> $R/gpurun_out/pmc_sq.txt
+  python $R/profiles/pmc_summary.py $(find /tmp/pmcS -name "*counter_collection.csv" | head -1) >> $R/gpurun_out/pmc_sq.txt 2>&1
+done
+cd $R
