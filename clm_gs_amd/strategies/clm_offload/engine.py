@@ -449,6 +449,14 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
                                       gaussians._scaling.grad, gaussians._rotation.grad], average=False)
             dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
+    if getattr(args, "debug_skip_optimizer", False):
+        # test hook: the batch ran exactly as in production (packed tables, lazy catch-up, DP exchange)
+        # but no optimizer consumes the accumulated gradients; they stay in parameters_grad_buffer[:N],
+        # the packed small-gradient table / the four .grad tensors, UNSCALED (sum over the cameras)
+        row_adam.global_step -= 1
+        if side_event is not None:
+            default_stream.wait_event(side_event)
+        return losses, ordered_cams, sparsity
     if use_packed:
         gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()))
     else:
@@ -496,10 +504,12 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     signal = gaussians.signal_tensor_pinned
     torch.cuda.synchronize()
 
+    skip_opt = getattr(args, "debug_skip_optimizer", False)  # test hook, see _train_one_batch_hbm
     worker = threading.Thread(target=cpuadam_thread, args=(
         bsz, N, signal, finish_indices_filters, gaussians.optimizer.cpu_adam, gaussians._parameters,
         parameters_grad_buffer[:N, :], iteration, args))
-    worker.start()
+    if not skip_opt:
+        worker.start()
 
     _zero_small_grads(gaussians)
     default_stream = torch.cuda.current_stream()
@@ -575,6 +585,10 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
 
     assert args.lr_scale_mode == "sqrt", "Overlap CPUAdam only supports sqrt lr scaling"
     assert not args.stop_update_param, "Overlap CPUAdam does not support stop_update_param"
+    if skip_opt:
+        torch.cuda.synchronize()
+        del keep_alive
+        return losses, ordered_cams, sparsity
     _gpu_adam_step(gaussians, args, visibility_mask)
     gaussians.invalidate_small_packed()
     worker.join()

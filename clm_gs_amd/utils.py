@@ -40,6 +40,7 @@ def default_args(**over):
         lr_scale_mode="sqrt", bsz=1, exact_filter=True, log_cpu_adam_trailing_overhead=False,
         # Debug
         stop_update_param=False, drop_initial_3dgs_p=0.0,
+        debug_skip_optimizer=False,  # this build, tests only: run the batch, leave the gradients unconsumed
         # this build: where the SH rows + their optimizer state live
         sh_residency="hbm",
         # this build: fused front-end kernels + no autograd tape inside the engines (fused.py);

@@ -1,0 +1,182 @@
+"""CPU restatement (torch, index arithmetic) of the clm_kernels / cpu_adam / fast_tsp entry points
+the reference's clm_offload engine calls.  TEST INFRASTRUCTURE ONLY (see oracle/gs_oracle.py).
+
+Sources are ABSENT from /root/reference (`.gitmodules:1-15`, empty submodule directories, all
+unpinned); what each op must do is fixed by its call site, cited per function, and by the
+reference's own assertions around it.  Used (a) as the fake `clm_kernels` / `cpu_adam` / `fast_tsp`
+modules when the reference's own engine code is run in the build container
+(tests/golden/ref_harness.py) and (b) as the checker of the product's C-ABI ops in tests/.
+"""
+import itertools
+import time
+
+import torch
+
+from . import gs_oracle as O
+
+
+# ---- SH row movers (strategies/clm_offload/engine.py:499-505, 622-636, 789-802, 815-822)
+def send_shs2gpu_stream(shs, parameters, filter_idx, grid_size=0, block_size=256):
+    """shs[i] = parameters[filter[i]]"""
+    with torch.no_grad():
+        shs.copy_(parameters.detach()[filter_idx.long()])
+
+
+def send_shs2gpu_stream_retention(shs_next, parameters, shs_retent, host_indices_to_param,
+                                  rtnt_indices_to_param, param_indices_from_host, param_indices_from_rtnt,
+                                  grid_h=0, block_h=256, grid_d=0, block_d=256):
+    """shs_next[param_indices_from_host[i]] = parameters[host_indices_to_param[i]]        (H rows)
+    shs_next[param_indices_from_rtnt[j]] = shs_retent[rtnt_indices_to_param[j]]           (D rows)"""
+    with torch.no_grad():
+        shs_next[param_indices_from_host.long()] = parameters.detach()[host_indices_to_param.long()]
+        shs_next[param_indices_from_rtnt.long()] = shs_retent[rtnt_indices_to_param.long()]
+
+
+def send_shs2cpu_grad_buffer_stream(shs_grad, grad_buffer, filter_idx, accum=True, grid_size=0,
+                                    block_size=256):
+    """grad_buffer[filter[i]] (+)= shs_grad[i]"""
+    with torch.no_grad():
+        if accum:
+            grad_buffer.index_add_(0, filter_idx.long(), shs_grad)
+        else:
+            grad_buffer[filter_idx.long()] = shs_grad
+
+
+def send_shs2cpu_grad_buffer_stream_retention(shs_grad, grad_buffer, shs_grad_next, host_indices_from_grad,
+                                              rtnt_indices_from_grad, grad_indices_to_host,
+                                              grad_indices_to_rtnt, accum=True, grid_h=0, block_h=256,
+                                              grid_d=0, block_d=256):
+    """grad_buffer[host_indices_from_grad[i]] += shs_grad[grad_indices_to_host[i]]         (G rows)
+    shs_grad_next[rtnt_indices_from_grad[j]] = shs_grad[grad_indices_to_rtnt[j]]          (D rows)"""
+    with torch.no_grad():
+        src = shs_grad[grad_indices_to_host.long()]
+        if accum:
+            grad_buffer.index_add_(0, host_indices_from_grad.long(), src)
+        else:
+            grad_buffer[host_indices_from_grad.long()] = src
+        shs_grad_next[rtnt_indices_from_grad.long()] = shs_grad[grad_indices_to_rtnt.long()]
+
+
+def spherical_harmonics_bwd_inplace(degrees_to_use, dirs, coeffs, v_coeffs, v_colors):
+    """SH backward that ACCUMULATES the coefficient gradient into v_coeffs[n,48] and returns v_dirs
+    (strategies/clm_offload/engine.py:709-716)."""
+    d = dirs.detach().clone().requires_grad_(True)
+    c = coeffs.detach().clone().requires_grad_(True)
+    col = O.spherical_harmonics(degrees_to_use, d, c)
+    gd, gc = torch.autograd.grad(col, (d, c), v_colors)
+    with torch.no_grad():
+        v_coeffs += gc.reshape(v_coeffs.shape)
+    return gd
+
+
+# ---- bitmaps (strategies/clm_offload/engine.py:152-153, 200-204, 227-232)
+def scatter_to_bit(bitmap, filter_idx, bit):
+    """bitmap[filter[i]] |= 1 << bit   (two's-complement wrap for the sign bit of int8/16/32/64)"""
+    info = torch.iinfo(bitmap.dtype)
+    val = 1 << bit
+    if val > info.max:
+        val -= 1 << info.bits
+    bitmap[filter_idx.long()] |= val
+
+
+def extract_ffs(bitmap, ffs):
+    """ffs[i] = 1-based index of the least significant set bit of bitmap[i], 0 if none."""
+    bits = torch.iinfo(bitmap.dtype).bits
+    b = bitmap.to(torch.int64)
+    out = torch.zeros_like(b)
+    for k in range(bits - 1, -1, -1):
+        out = torch.where(((b >> k) & 1) != 0, torch.full_like(out, k + 1), out)
+    ffs.copy_(out.to(ffs.dtype))
+
+
+def compute_cnt_h(bitmap, tmp_buffer, grid_size=64, block_size=256):
+    """tmp_buffer[i, :] = per-thread partial counts whose sum over dim 1 is #{rows visible in BOTH
+    micro-batch i and i+1} (bit bsz-1-i and bit bsz-2-i; the engine sums dim 1 and calls it cnt_d:
+    strategies/clm_offload/engine.py:227-235).  Here: the total in column 0."""
+    bsz = tmp_buffer.shape[0] + 1
+    b = bitmap.to(torch.int64)
+    tmp_buffer.zero_()
+    for i in range(bsz - 1):
+        both = ((b >> (bsz - 1 - i)) & 1) & ((b >> (bsz - 2 - i)) & 1)
+        tmp_buffer[i, 0] = int(both.sum())
+
+
+def set_signal(signal_tensor_pinned, idx, value):
+    signal_tensor_pinned[idx] = value
+
+
+# ---- cpu_adam.FusedCPUAdam (optimizer.py:130-144; clm_offload/engine.py:316-328)
+class FusedCPUAdam(torch.optim.Optimizer):
+    """One [N,48] host tensor with per-column learning rates; DeepSpeed-style bias-corrected Adam with
+    ONE step counter per optimizer call; batched_sparse_step waits for signal[i] before row group i+1,
+    group 0 (rows no micro-batch touches) needs no signal, version 3 zeroes consumed gradient rows."""
+
+    def __init__(self, params, columns_sizes, columns_lr, lr=1e-3, bias_correction=True, betas=(0.9, 0.999),
+                 eps=1e-8, weight_decay=0, amsgrad=False, adamw_mode=False, fp32_optimizer_states=True):
+        super().__init__(params, dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps,
+                                      weight_decay=weight_decay, amsgrad=amsgrad))
+        self.columns_sizes = list(columns_sizes)
+        self.columns_lr = torch.tensor(list(columns_lr), dtype=torch.float32)
+        self.global_step = 0
+        p = self.param_groups[0]["params"][0]
+        st = self.state[p]
+        st["step"] = 0
+        st["exp_avg"] = torch.zeros_like(p.data)
+        st["exp_avg_sq"] = torch.zeros_like(p.data)
+
+    def _col_lr(self):
+        return torch.cat([torch.full((n,), float(l)) for n, l in zip(self.columns_sizes, self.columns_lr.tolist())])
+
+    def _update(self, rows, scale, zero, step):
+        g = self.param_groups[0]
+        p = g["params"][0]
+        st = self.state[p]
+        with torch.no_grad():
+            O.adam_rows(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], rows, self._col_lr(), g["betas"][0],
+                        g["betas"][1], g["eps"], step, scale, g["bias_correction"], zero)
+
+    def step(self, closure=None):
+        self.global_step += 1
+        self._update(None, 1.0, False, self.global_step)
+
+    def batched_sparse_step(self, batch_size, batched_sparse_indices, signal_tensor_pinned, version=3,
+                            scale=1.0, sparse_adam=False):
+        assert len(batched_sparse_indices) == batch_size + 1
+        self.global_step += 1
+        if not sparse_adam and batched_sparse_indices[0].numel():
+            self._update(batched_sparse_indices[0], scale, version == 3, self.global_step)
+        for i in range(batch_size):
+            while signal_tensor_pinned is not None and int(signal_tensor_pinned[i]) == 0:
+                time.sleep(0.0005)
+            if batched_sparse_indices[i + 1].numel():
+                self._update(batched_sparse_indices[i + 1], scale, version == 3, self.global_step)
+        self.state[self.param_groups[0]["params"][0]]["step"] = self.global_step
+
+    def zero_grad(self, set_to_none=False):
+        p = self.param_groups[0]["params"][0]
+        if p.grad is not None:
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.zero_()
+
+
+# ---- fast_tsp.find_tour (strategies/clm_offload/engine.py:179): any tour is valid (the upstream solver
+# is time-budgeted and not reproducible); here the optimal OPEN tour by brute force for small n,
+# greedy nearest neighbour otherwise.
+def find_tour(dist, duration_seconds=0.001):
+    n = len(dist)
+    if n <= 8:
+        best, best_c = None, None
+        for perm in itertools.permutations(range(n)):
+            c = sum(dist[perm[i]][perm[i + 1]] for i in range(n - 1))
+            if best_c is None or c < best_c:
+                best, best_c = list(perm), c
+        return best
+    tour, used = [0], {0}
+    while len(tour) < n:
+        cur = tour[-1]
+        nx = min((c for c in range(n) if c not in used), key=lambda c: dist[cur][c])
+        tour.append(nx)
+        used.add(nx)
+    return tour

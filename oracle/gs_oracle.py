@@ -16,9 +16,15 @@ tree allows it:
   * SSIM / L1 / PSNR   -> utils/loss_utils.py:18-85, utils/image_utils.py:19-21
   * quat -> R, R S     -> utils/general_utils.py:311-346
   * camera conventions -> utils/graphics_utils.py:42-84, scene/cameras.py:87-126
-  * engine call order  -> strategies/no_offload/engine.py:15-177 executed in the
-                          build container with this oracle plugged in as `gsplat`
-                          (tests/golden/make_golden.py)
+  * engine call order  -> the reference's own strategies/no_offload/engine.py:15-177,
+                          strategies/clm_offload/engine.py:30-979, base_engine.calculate_filters,
+                          densification.py and both GaussianModels executed in the build container
+                          with this oracle plugged in as `gsplat` / `clm_kernels` (+ oracle/clm_oracle.py
+                          as cpu_adam / fast_tsp): tests/golden/make_engine_golden.py ->
+                          tests/golden/engine_*.npz.  That pins the ORCHESTRATION (what is called
+                          with what, accumulation, optimizer scaling, densification); the arithmetic
+                          of projection / tile intersection / alpha blend / Adam stays pinned to
+                          nothing but the published algorithms (no reference-produced vector exists).
 
 Every function is differentiable through torch autograd; autograd of this
 restatement is the gradient oracle for the hand-written HIP backward kernels.
