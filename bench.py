@@ -77,14 +77,16 @@ def parse():
 
 
 def make_gt_images(cams, scene, args_ns, width, height):
-    """GT = render of a perturbed copy (xyz + N(0, 0.05^2)) quantised to uint8."""
+    """GT = render of a perturbed copy of the scene (synthetic.perturbed_copy: jittered positions + a
+    systematic opacity / size / colour error) quantised to uint8."""
     from clm_gs_amd import utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
+    from clm_gs_amd.synthetic import perturbed_copy
 
-    g = torch.Generator(device="cuda").manual_seed(99)
     gt_model = GaussianModelCLMOffload(3, only_for_rendering=True)
-    xyz = scene["xyz"] + torch.randn(scene["xyz"].shape, generator=g, device="cuda") * 0.05
-    gt_model.create_from_tensors(xyz, scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"])
+    t = perturbed_copy(scene)
+    gt_model.create_from_tensors(t["xyz"], t["shs48"], t["scaling"], t["rotation"], t["opacity"])
+    del t
     gt_model.active_sh_degree = 3
     for c in cams:
         img = clm_offload_eval_one_cam(c, gt_model, None, None)
@@ -99,6 +101,8 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     import numpy as np
 
     from clm_gs_amd.strategies.base_engine import calculate_filters
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable))  # all host cores this process may run on
     from oracle import c_oracle as C
 
     with torch.no_grad():
@@ -136,7 +140,7 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     frac2 = (cw2 * ch2) / float(width * height)
     return {
         "value": frac2 / t, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
-        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads of {os.cpu_count()} host cores): "
+        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads; {usable} usable of {os.cpu_count()} host cores): "
                    f"1 micro-batch (camera 0, V={len(means)} rows in), centred {cw2}x{ch2} crop = "
                    f"{frac2:.4f} of the {width}x{height} image, {vis} visible, {isects} intersections, "
                    f"forward+loss+backward in {t:.2f}s; value = crop fraction / time"),
@@ -152,7 +156,8 @@ def main():
     if os.environ.get("CLMGS_SHARE_GPU") == "1":  # test hook: several ranks on one device
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    under_torchrun = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_torchrun:  # a 1-rank launch through torch.distributed.run still builds the RCCL group
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CLMGS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -199,7 +204,7 @@ def main():
         from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload, baseline_accumGrads_impl
         gaussians = GaussianModelNoOffload(3)
     gaussians.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"],
-                                  scene["opacity"], spatial_lr_scale=scene["extent"])
+                                  scene["opacity"], spatial_lr_scale=scene["lr_extent"])
     extent = scene["extent"]
     del scene
     gaussians.active_sh_degree = 3
@@ -235,9 +240,11 @@ def main():
         state["iteration"] += bsz * world
         return losses, sparsity
 
+    grouped = world > 1 or under_torchrun
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -257,23 +264,25 @@ def main():
             clm_offload_eval_one_cam(cams[i % len(cams)], gaussians, None, None)
             i += 1
         torch.cuda.synchronize()
+    all_losses = []  # 0-dim device tensors, read after the timed region
     for b in range(a.warmup):
-        step(b)
+        all_losses += list(step(b)[0])
     fence()
     torch.cuda.reset_peak_memory_stats()
-    if not a.no_kernel_timing:
-        _lib.TIMING = {}
     _lib.STATS["n_isects"].clear()
     _lib.STATS["n_emitted"].clear()
+    _lib.STATS.setdefault("touched_rows", []).clear()
     sparsities = []
     _lib.STATS["host_wait_s"] = 0.0
     ms0 = torch.cuda.memory_stats()
     if os.environ.get("CLMGS_HOST_REGIONS") == "1":
         _lib.HOST_REGIONS = {}
+    # ---- the timed region: exactly K steps, NO per-kernel event instrumentation inside it
     t0 = time.perf_counter()
     step_marks = []
     for b in range(a.warmup, a.warmup + a.steps):
         losses, sp = step(b)
+        all_losses += list(losses)
         step_marks.append(time.perf_counter())
         if sp:
             sparsities += sp
@@ -285,10 +294,24 @@ def main():
     dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
     dev_frees = int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0))
     host_regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    peak = torch.cuda.max_memory_allocated()
+    loss_vals = [float(l) for l in all_losses]
+    # ---- the same K steps again (same cameras, the model has moved on) with an event pair around every
+    # C-ABI call on the stream it is launched on: the per-kernel table and the roofline entry.  Its
+    # throughput is reported as value_instrumented; `value` above never carries the instrumentation.
+    dt_instr = None
+    if not a.no_kernel_timing:
+        _lib.TIMING = {}
+        fence()
+        ti = time.perf_counter()
+        for b in range(a.warmup, a.warmup + a.steps):
+            step(b)
+        fence()
+        dt_instr = time.perf_counter() - ti
     peak = torch.cuda.max_memory_allocated()
     timing = _lib.timing_summary()
     _lib.TIMING = None
@@ -309,15 +332,22 @@ def main():
         del _lib.STATS["n_isects"][n_stat:]
         del _lib.STATS["n_emitted"][n_stat:]
     n_images = a.steps * bsz
-    isects = _lib.STATS["n_isects"][-n_images:] if a.strategy == "clm_offload" else _lib.STATS["n_isects"]
+    k2 = min(2 * bsz, max(bsz, len(loss_vals) // 2))
+    loss_first = sum(loss_vals[:k2]) / k2
+    loss_last = sum(loss_vals[-k2:]) / k2
+    train_ok = loss_last <= 1.05 * loss_first
+    tr = _lib.STATS.get("touched_rows", [])[:a.steps]
+    touched_avg = sum(tr) / max(1, len(tr)) if tr else float(N)
+    isects = _lib.STATS["n_isects"][:n_images] if a.strategy == "clm_offload" else _lib.STATS["n_isects"]
     I_avg = sum(isects) / max(1, len(isects))
-    emitted = _lib.STATS["n_emitted"][-n_images:] if a.strategy == "clm_offload" else _lib.STATS["n_emitted"]
+    emitted = _lib.STATS["n_emitted"][:n_images] if a.strategy == "clm_offload" else _lib.STATS["n_emitted"]
     I_emitted = sum(emitted) / max(1, len(emitted))
     V_avg = (sum(sparsities) / max(1, len(sparsities))) * N if sparsities else float(N)
     n_rows = V_avg if a.strategy == "clm_offload" else float(N)
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
 
-    if world > 1:
+    dist_backend = torch.distributed.get_backend() if grouped else None
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -330,23 +360,27 @@ def main():
             b = ALGO_BYTES[name](n_rows, V_avg, I_avg, P, T)
             kernels[name] = {"calls": calls, "avg_ms": round(avg_ms, 4),
                              "algo_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
-                             "share_of_step": round(ms / (dt * 1e3), 4)}
+                             "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
         elif calls:
             kernels[name] = {"calls": calls, "avg_ms": round(ms / calls, 4),
-                             "share_of_step": round(ms / (dt * 1e3), 4)}
+                             "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
     roofline = None
     if kernels:
         dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["calls"] * kernels[k]["avg_ms"])
         ach = kernels[dom]["algo_GBps"]
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(a.config, {}).get(dom, {}).get("traffic")
+                tj = json.load(open(tpath))
+                traffic = tj.get(a.config, {}).get(dom, {}).get("traffic")
+                traffic_src = ("NOT measured in this run: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc "
+                               "FETCH_SIZE / WRITE_SIZE passes, profiles/collect.sh")) + ")") if traffic is not None else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "algo_bytes_per_launch": ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T),
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "avg_launch_ms_solo": round(solo[dom], 4) if dom in solo else None,
@@ -361,7 +395,10 @@ def main():
     p_pass = 6
     A_img = 228 * n_rows + 636 * V_avg + (220 * V_avg if a.strategy == "clm_offload" else 0) + \
         (144 + 24 * p_pass) * I_avg + 143 * P + 4 * T
-    adam_img = 1652.0 * N / bsz
+    # Adam per batch = 28 B x 59 floats per row, row-sparse over the rows the batch touches
+    # (untouched rows have a zero gradient; this build defers their momentum decay, clm_offload hbm mode)
+    adam_rows = touched_avg if (a.strategy == "clm_offload" and a.residency == "hbm") else float(N)
+    adam_img = 1652.0 * adam_rows / bsz
     # published numbers of BASELINE.md section 1 for exactly this (config, strategy), single GPU
     published = {("rubble28m", "clm_offload"): 4.04, ("rubble28m", "naive_offload"): 2.45,
                  ("rubble10m", "clm_offload"): 8.08, ("rubble10m", "no_offload"): 8.55,
@@ -380,17 +417,24 @@ def main():
                              "device_mallocs_in_timed_region": dev_allocs, "device_frees_in_timed_region": dev_frees,
                              **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
                                 if host_regions else {})},
-        "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
         "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
                    "untimed_priming_s": a.prime_seconds},
+        "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
         "peak_gpu_bytes": int(peak),
+        "resident_input_bytes": {"gt_images_u8": int(len(cams) * 3 * H * W),
+                                 "note": "the bench keeps every camera's GT image in HBM (inputs resident before the timed "
+                                         "region); the reference streams them from host per batch (train.py:310-312)"},
         "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
-                     "I_emitted_avg": round(I_emitted, 1),
-                     "pixels": P, "tiles": T, "loss_last": float(losses[-1])},
-        "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1),
+                     "I_emitted_avg": round(I_emitted, 1), "touched_rows_per_batch": round(touched_avg, 1),
+                     "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
+                     "loss_per_batch": [round(sum(loss_vals[i:i + bsz]) / bsz, 5) for i in range(0, len(loss_vals), bsz)]},
+        "training_check": {"ok": bool(train_ok), "rule": "mean loss of the last 2 batches <= 1.05 x mean loss of the first 2 "
+                           "(warm-up included): the timed optimisation must not diverge"},
+        "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1), "adam_rows_per_batch": round(adam_rows, 1),
                            "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),
                            "frac_of_8TBps": round((A_img + adam_img) * value / world / 8e12, 5)},
         "baseline": {"img_s": ref_img_s, "source": "BASELINE.md section 1 (reference's own testbed: 1x RTX 4090 + "
@@ -405,6 +449,10 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     print(json.dumps(out))
+    sys.stdout.flush()
+    if not train_ok:
+        sys.stderr.write(f"bench: training check FAILED: loss {loss_first:.5f} -> {loss_last:.5f}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -549,7 +549,11 @@ extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
     CLMGS_LAUNCH_CHECK();
   }
   const int n_blocks = C * tile_width * tile_height;
+#ifdef CLMGS_PROFILE_BUILD  // occupancy experiments: extra dynamic LDS per workgroup
   static const int fwd_pad = getenv("CLMGS_FWD_LDS_PAD") ? atoi(getenv("CLMGS_FWD_LDS_PAD")) : 0;
+#else
+  const int fwd_pad = 0;
+#endif
   hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), fwd_pad, s, C, N, n_isects,
                      (const float4*)packed, backgrounds, width, height, tile_width, tile_height,
                      offsets, flatten_ids, render_colors, render_alphas, last_ids);
@@ -581,13 +585,21 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
   if (n_isects > 0) {
     CLMGS_CHECK_ARG(packed && offsets && flatten_ids && render_alphas && last_ids && v_render_colors);
     const int n_blocks = C * tile_width * tile_height;
+    // The product build launches <0, PART> only.  The profiling variants (skip the flush / skip the
+    // reduction / phase timers), which produce WRONG gradients by design, and the environment lookups
+    // that select them exist only in a -DCLMGS_PROFILE_BUILD library (make PROFILE=1).
+#ifdef CLMGS_PROFILE_BUILD
     static const int dbg = getenv("CLMGS_BWD_DEBUG") ? atoi(getenv("CLMGS_BWD_DEBUG")) : 0;
     static const int bwd_pad = getenv("CLMGS_BWD_LDS_PAD") ? atoi(getenv("CLMGS_BWD_LDS_PAD")) : 0;
+#else
+    const int bwd_pad = 0;
+#endif
 #define CLMGS_LAUNCH_BWD(D, P)                                                                     \
   hipLaunchKernelGGL((rasterize_bwd_kernel<D, P>), dim3(n_blocks), dim3(64), bwd_pad, s, C, N,     \
                      n_isects, (const float4*)packed, backgrounds, width, height, tile_width,      \
                      tile_height, offsets, flatten_ids, render_alphas, last_ids, v_render_colors,  \
                      v_render_alphas, (float*)packed_grad, emit_slot, (float4*)partials)
+#ifdef CLMGS_PROFILE_BUILD
     if (part) {
       if (dbg == 1) CLMGS_LAUNCH_BWD(1, true); else if (dbg == 3) CLMGS_LAUNCH_BWD(3, true);
       else CLMGS_LAUNCH_BWD(0, true);
@@ -595,6 +607,9 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
       if (dbg == 1) CLMGS_LAUNCH_BWD(1, false); else if (dbg == 2) CLMGS_LAUNCH_BWD(2, false);
       else if (dbg == 3) CLMGS_LAUNCH_BWD(3, false); else CLMGS_LAUNCH_BWD(0, false);
     }
+#else
+    if (part) CLMGS_LAUNCH_BWD(0, true); else CLMGS_LAUNCH_BWD(0, false);
+#endif
 #undef CLMGS_LAUNCH_BWD
     CLMGS_LAUNCH_CHECK();
     if (part) {

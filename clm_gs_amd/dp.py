@@ -11,8 +11,20 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def active():
+    """True when the engines must run the exchange: more than one rank, or CLMGS_DP_FORCE=1 with an
+    initialised process group (a 1-rank group runs every collective as the identity -- this is how the
+    RCCL path is exercised on a single-GPU box: tests/test_gpu_nccl.py)."""
+    if world_size() > 1:
+        return True
+    return os.environ.get("CLMGS_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def rank():
@@ -25,7 +37,7 @@ def allreduce_small_grads(grads, average=True):
     small gradients are 1.2 GB at 28 M: cat + split would move them three more times).
     average=False leaves the SUM; the engine folds 1/ranks into the Adam gradient scale."""
     ws = world_size()
-    if ws == 1:
+    if not active():
         return
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
     for w in works:
@@ -37,7 +49,7 @@ def allreduce_small_grads(grads, average=True):
 
 def allreduce_touched(touched):
     """bool[N] -> OR over ranks (as MAX over uint8)."""
-    if world_size() == 1:
+    if not active():
         return touched
     t = touched.to(torch.uint8)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -48,7 +60,7 @@ def allreduce_rows(grad_rows, touched_global, average=True, rows=None):
     """Sum (average) grad_rows[N,48] over ranks, moving only rows in the (global) touched set.
     `rows`: the index list of touched_global if the caller already has it."""
     ws = world_size()
-    if ws == 1:
+    if not active():
         return
     if rows is None:
         rows = torch.nonzero(touched_global).flatten()
@@ -77,7 +89,7 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
     is touched (pack + unpack cost 2 HBM passes; break-even at ~89 % touched): above `dense_above`
     the tables are reduced in place instead."""
     ws = world_size()
-    if ws == 1:
+    if not active():
         return
     n = rows.numel()
     if n == 0:
@@ -101,7 +113,7 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
 
 
 def allreduce_densify_stats(gaussians):
-    if world_size() == 1:
+    if not active():
         return
     dist.all_reduce(gaussians.xyz_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(gaussians.denom, op=dist.ReduceOp.SUM)

@@ -247,7 +247,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
     lazy_mode = gaussians.lazy_rows and not args.stop_update_param
-    need_mask = touched_rows is None or args.sparse_adam or dp.world_size() > 1 or not lazy_mode
+    need_mask = touched_rows is None or args.sparse_adam or dp.active() or not lazy_mode
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
         if touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
@@ -257,7 +257,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 touched.index_fill_(0, f, True)
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
-        if dp.world_size() > 1:
+        if dp.active():
             touched = dp.allreduce_touched(touched)
             touched_rows = None
     row_adam = gaussians.optimizer.cpu_adam
@@ -283,6 +283,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     if touched_rows is None:
         touched_rows = torch.nonzero(touched).flatten()
     touched_rows = touched_rows.to(torch.int32)
+    _lib.STATS.setdefault("touched_rows", []).append(int(touched_rows.shape[0]))  # shape known on the host
     lazy = gaussians.lazy_rows and not args.stop_update_param
     if lazy:
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
@@ -440,7 +441,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
-    if dp.world_size() > 1:  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
+    if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
         if use_packed:
             # one collective: packed small gradients + SH gradient rows of the globally touched set
@@ -491,7 +492,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
     dev = gaussians._xyz.device
-    assert dp.world_size() == 1, "camera-DP is built for sh_residency='hbm' (every rank holds a full replica)"
+    assert not dp.active(), "camera-DP is built for sh_residency='hbm' (every rank holds a full replica)"
     with torch.no_grad():
         filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
                                           gaussians.get_scaling, gaussians.get_rotation)

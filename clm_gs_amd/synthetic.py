@@ -10,6 +10,31 @@ import torch
 from .cameras import Camera
 
 
+# spatial_lr_scale of the synthetic scenes.  The reference scales the position learning rate by the
+# camera extent of the dataset (scene/__init__.py -> create_from_pcd(spatial_lr_scale=cameras_extent));
+# for a slab of n Gaussians at unit spacing the geometric extent is 0.5*sqrt(n) (2646 at 28 M), which
+# with position_lr_init 1.6e-4 and sqrt(bsz) scaling is a 0.85-unit Adam step on a scene whose nearest
+# neighbour spacing is 1.0 -- the step size of iteration 0 of a 100 k-point model, not of a 28 M one.
+# A 28 M-Gaussian model exists late in the reference's schedule (after densification, lr decayed);
+# LR_EXTENT = 5 gives 1.6e-3 units per step, the regime in which the synthetic optimisation converges.
+LR_EXTENT = 5.0
+
+
+def perturbed_copy(scene, seed=99, xyz_sigma=0.05, opacity_shift=0.8, log_scale_shift=0.15, dc_shift=0.3):
+    """The scene the ground-truth images are rendered from: positions jittered, and a SYSTEMATIC error in
+    opacity / size / base colour shared by all Gaussians, so that every training step sees a consistent
+    gradient and the loss of a converging optimisation falls within tens of batches."""
+    g = torch.Generator(device=scene["xyz"].device).manual_seed(seed)
+    out = dict(scene)
+    out["xyz"] = scene["xyz"] + torch.randn(scene["xyz"].shape, generator=g, device=scene["xyz"].device) * xyz_sigma
+    out["opacity"] = scene["opacity"] + opacity_shift
+    out["scaling"] = scene["scaling"] + log_scale_shift
+    shs = scene["shs48"].clone()
+    shs[:, :3] += dc_shift
+    out["shs48"] = shs
+    return out
+
+
 def synth_gaussians(n, seed=0, device="cuda", thickness=0.1):
     """xyz ~ U([-L,L]^2 x [0, thickness*L]) with L s.t. areal density = 1 / unit^2; log-scales
     ~ N(log 0.7, 0.4^2); quats ~ N(0,I) un-normalised; opacity logit ~ N(0,1.5^2);
@@ -26,7 +51,7 @@ def synth_gaussians(n, seed=0, device="cuda", thickness=0.1):
     shs = torch.randn((n, 16, 3), generator=g, device=device) * 0.1
     shs[:, 0, :] = torch.randn((n, 3), generator=g, device=device)
     return dict(xyz=xyz, scaling=scaling, rotation=rotation, opacity=opacity,
-                shs48=shs.reshape(n, 48), extent=L)
+                shs48=shs.reshape(n, 48), extent=L, lr_extent=LR_EXTENT)
 
 
 def nadir_cameras(n_cams, n_gaussians, width, height, visible_fraction, seed=0, device="cuda",

@@ -1,0 +1,103 @@
+"""Worker for tests/test_gpu_nccl.py: ONE rank under torch.distributed.run with the `nccl` backend
+(= RCCL on ROCm) bound to cuda:0.  A 1-rank group runs every collective as the identity, so
+(a) each dp.* collective must return its input unchanged, and (b) two training batches with the
+exchange forced on (CLMGS_DP_FORCE=1) must leave bit-identical parameters to the same batches with no
+process group in play.  This is the RCCL load / device-binding / stream-ordering check a single-GPU box
+allows before the driver's multi-GPU scaling run."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+W, H, N, BSZ = 128, 96, 6000, 4
+
+
+class _Scene:
+    cameras_extent = 5.0
+
+
+def _train(force):
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    os.environ["CLMGS_DP_FORCE"] = "1" if force else "0"
+    args = utils.default_args(bsz=BSZ)
+    args.clm_offload = True
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    sc = synth_gaussians(N, seed=4, device="cuda")
+    cams = nadir_cameras(2 * BSZ, N, W, H, 0.35, seed=4, device="cuda")
+    g = torch.Generator().manual_seed(11)
+    for c in cams:
+        c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+    m = GaussianModelCLMOffload(3)
+    m.create_from_tensors(sc["xyz"], sc["shs48"], sc["scaling"], sc["rotation"], sc["opacity"], spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(args)
+    comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+    it = 1
+    for b in range(2):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        clm_offload_train_one_batch(m, _Scene, cams[b * BSZ:(b + 1) * BSZ], m.parameters_grad_buffer, None, None, comm, gen)
+        it += BSZ
+    torch.cuda.synchronize()
+    m.flush_lazy_rows()
+    return [t.detach().clone() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters)]
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    from clm_gs_amd import dp
+    assert dist.get_backend() == "nccl" and dp.world_size() == 1
+    os.environ["CLMGS_DP_FORCE"] = "1"
+    assert dp.active()
+    res = {}
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n = 5000
+    grads = [torch.randn(n, d, generator=g, device="cuda") for d in (3, 1, 3, 4)]
+    ref = [x.clone() for x in grads]
+    dp.allreduce_small_grads(grads, average=False)
+    res["small_grads"] = all(torch.equal(a, b) for a, b in zip(grads, ref))
+    touched = torch.rand(n, generator=g, device="cuda") < 0.3
+    res["touched"] = bool(torch.equal(dp.allreduce_touched(touched), touched))
+    rows = torch.randn(n, 48, generator=g, device="cuda")
+    r0 = rows.clone()
+    dp.allreduce_rows(rows, touched, average=False)
+    res["rows_packed"] = bool(torch.equal(rows, r0))
+    dp.allreduce_rows(rows, torch.ones_like(touched), average=False)
+    res["rows_dense"] = bool(torch.equal(rows, r0))
+    t12, t48 = torch.randn(n, 12, generator=g, device="cuda"), torch.randn(n, 48, generator=g, device="cuda")
+    a12, a48 = t12.clone(), t48.clone()
+    idx = torch.nonzero(touched).flatten()
+    dp.allreduce_tables_rows([a12, a48], idx, n)
+    dp.allreduce_tables_rows([a12, a48], idx, n, dense_above=0.0)
+    res["tables"] = bool(torch.equal(a12, t12) and torch.equal(a48, t48))
+
+    class M:
+        pass
+    m = M()
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.rand(n, 1, device="cuda"), torch.ones(n, 1, device="cuda"), torch.rand(n, device="cuda")
+    keep = (m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone())
+    dp.allreduce_densify_stats(m)
+    res["densify_stats"] = all(torch.equal(a, b) for a, b in zip(keep, (m.xyz_gradient_accum, m.denom, m.max_radii2D)))
+    if hasattr(dp, "owner_exchange_tables"):
+        b12, b48 = t12.clone(), t48.clone()
+        dp.owner_exchange_tables([b12, b48], idx, n, lambda lo, hi: None)
+        res["owner_exchange"] = bool(torch.equal(b12, t12) and torch.equal(b48, t48))
+    forced = _train(True)
+    plain = _train(False)
+    res["train_forced_equals_plain"] = all(torch.equal(a, b) for a, b in zip(forced, plain))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("NCCLRESULT " + json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

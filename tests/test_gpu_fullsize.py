@@ -1,0 +1,235 @@
+"""-m gpu: every BASELINE.json configuration at FULL SIZE, through size-independent properties
+(the oracle cannot run at these sizes): finite outputs, bitwise-identical reruns (the engine path
+accumulates without float atomics), the two binning routes and the two filter-selection routes agree
+element for element, fused vs op-by-op renders agree to >= 60 dB, a sub-scene made of one camera's
+visible rows reproduces that camera's image and gradients (this is what exercises the 64-bit row
+arithmetic at 102 M x 48 floats), and a short optimisation lowers the loss.
+
+config 2  Bicycle ~6 M, 1237x822, no_offload          config 4  Rubble-4K 28 M, clm_offload
+config 3  Rubble-4K 10 M, 4608x3456, clm_offload      config 5  BigCity 102 M, 1920x1080, sparse Adam
+"""
+import math
+
+import pytest
+import torch
+
+from tests.scenes import psnr
+
+pytestmark = pytest.mark.gpu
+
+
+class _Scene:
+    cameras_extent = 5.0
+
+
+def _build(strategy, N, W, H, bsz, vis, n_cams=None, seed=0, **over):
+    from clm_gs_amd import utils
+    from clm_gs_amd.synthetic import nadir_cameras, perturbed_copy, synth_gaussians
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
+    args = utils.default_args(bsz=bsz, **over)
+    setattr(args, strategy, True)
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    sc = synth_gaussians(N, seed=seed, device="cuda")
+    cams = nadir_cameras(n_cams or bsz, N, W, H, vis, seed=seed, device="cuda")
+    gt = GaussianModelCLMOffload(3, only_for_rendering=True)
+    t = perturbed_copy(sc)
+    gt.create_from_tensors(t["xyz"], t["shs48"], t["scaling"], t["rotation"], t["opacity"])
+    del t
+    gt.active_sh_degree = 3
+    for c in cams:
+        c.original_image = (clm_offload_eval_one_cam(c, gt, None, None).clamp(0, 1) * 255.0).round().to(torch.uint8)
+    del gt
+    if strategy == "no_offload":
+        from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload as M
+    else:
+        M = GaussianModelCLMOffload
+    m = M(3)
+    m.create_from_tensors(sc["xyz"], sc["shs48"], sc["scaling"], sc["rotation"], sc["opacity"],
+                          spatial_lr_scale=sc["lr_extent"])
+    del sc
+    m.active_sh_degree = 3
+    m.training_setup(args)
+    torch.cuda.empty_cache()
+    return args, m, cams
+
+
+def _clm_batch(m, cams, args):
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+    out = clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None, comm, gen)
+    torch.cuda.synchronize()
+    return out
+
+
+def _op_properties(m, cam, W, H):
+    """One camera at full size through the op-by-op surface: binning routes and filter routes agree."""
+    from clm_gs_amd import gsplat as G
+    from clm_gs_amd.strategies.base_engine import calculate_filters, select_filters
+    with torch.no_grad():
+        filters, _, _ = calculate_filters([cam], m.get_xyz, m.get_opacity, m.get_scaling, m.get_rotation)
+        f2, touched = select_filters([cam], m._xyz.detach(), m._scaling.detach(), m._rotation.detach())
+        assert torch.equal(filters[0], f2[0]) and torch.equal(touched, f2[0])
+        f = filters[0]
+        vm = cam.world_view_transform.t().contiguous()
+        radii, m2, d, cn, _ = G.fully_fused_projection(m._xyz.detach()[f], None, m.get_rotation.detach()[f],
+                                                       m.get_scaling.detach()[f], vm[None], cam.K[None], W, H)
+        assert bool((radii > 0).all()), "calculate_filters == rows the projection keeps"
+        tw, th = math.ceil(W / 16), math.ceil(H / 16)
+        _, ids, fids = G.isect_tiles(m2, radii, d, 16, tw, th)
+        off = G.isect_offset_encode(ids, 1, tw, th)
+        fids2, off2, ids2 = G.isect_tiles_two_level(m2, radii, d, 16, tw, th, want_isect_ids=True)[:3]
+        assert torch.equal(fids, fids2) and torch.equal(off, off2) and torch.equal(ids, ids2)
+        assert bool((ids[1:] >= ids[:-1]).all()), "sorted by (tile, depth)"
+    return f
+
+
+def _fused_vs_opbyop_image(m, cam):
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_eval_one_cam
+    img = clm_offload_eval_one_cam(cam, m, None, _Scene)  # op-by-op chain (gsplat surface)
+    assert bool(torch.isfinite(img).all())
+    return img
+
+
+# ----------------------------------------------------------------------------- config 2
+def test_config2_bicycle6m_no_offload_full_size(dev):
+    from clm_gs_amd.strategies.no_offload import baseline_accumGrads_impl
+    N, W, H = 6_000_000, 1237, 822
+    args, m, cams = _build("no_offload", N, W, H, 4, 0.25)
+
+    def run():
+        m.optimizer.zero_grad(set_to_none=True)
+        for p in (m._xyz, m._opacity, m._scaling, m._rotation):
+            p.grad = None
+        m._reset_stats()
+        losses, _ = baseline_accumGrads_impl(m, _Scene, cams, None)
+        torch.cuda.synchronize()
+        return [l.item() for l in losses], [p.grad.clone() for p in m.all_parameters()]
+    l1, g1 = run()
+    l2, g2 = run()
+    assert all(math.isfinite(x) and 0 < x < 1 for x in l1)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2)), "bitwise reproducible"
+    assert all(bool(torch.isfinite(g).all()) for g in g1) and float(g1[0].abs().max()) > 0
+    _op_properties(m, cams[0], W, H)
+    # op-by-op engine path == fused engine path (same batch)
+    args.fused_front_end = False
+    m.optimizer.zero_grad(set_to_none=True)
+    for p in (m._xyz, m._opacity, m._scaling, m._rotation):
+        p.grad = None
+    losses, _ = baseline_accumGrads_impl(m, _Scene, cams[:1], None)
+    assert abs(losses[0].item() - l1[0]) < 2e-5
+
+
+# ------------------------------------------------------------------------ configs 3 and 4
+@pytest.mark.parametrize("N,vis", [(10_000_000, 0.15), (28_000_000, 0.10)])
+def test_config3_4_rubble4k_clm_offload_full_size(dev, N, vis):
+    from clm_gs_amd import fused, utils
+    W, H = 4608, 3456
+    args, m, cams = _build("clm_offload", N, W, H, 4, vis, n_cams=16, debug_skip_optimizer=True)
+    # (1) gradients of one batch: finite, bitwise reproducible (no optimizer consumes them)
+    l1, _, sp = _clm_batch(m, cams[:4], args)
+    g_sh, g_small = m.parameters_grad_buffer[:N].clone(), m.small_grad().clone()
+    st = (m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone())
+    m.parameters_grad_buffer[:N].zero_()
+    m.small_grad().zero_()
+    m._reset_stats()
+    m._stats_d = None
+    l2, _, _ = _clm_batch(m, cams[:4], args)
+    assert [x.item() for x in l1] == [x.item() for x in l2]
+    assert torch.equal(g_sh, m.parameters_grad_buffer[:N]) and torch.equal(g_small, m.small_grad())
+    assert all(torch.equal(a, b) for a, b in zip(st, (m.xyz_gradient_accum, m.denom, m.max_radii2D)))
+    assert bool(torch.isfinite(g_sh).all()) and bool(torch.isfinite(g_small).all())
+    assert float(g_sh.abs().max()) > 0 and all(0 < s < 0.5 for s in sp)
+    touched = torch.zeros(N, dtype=torch.bool, device="cuda")
+    f = _op_properties(m, cams[0], W, H)
+    # rows no camera of the batch sees carry no gradient
+    from clm_gs_amd.strategies.base_engine import select_filters
+    _, tr = select_filters(cams[:4], m._xyz.detach(), m._scaling.detach(), m._rotation.detach())
+    touched[tr] = True
+    assert float(g_sh[~touched].abs().max()) == 0.0 and float(g_small[~touched].abs().max()) == 0.0
+    del g_sh, g_small, touched
+    # (2) fused forward image == op-by-op forward image
+    m.parameters_grad_buffer[:N].zero_()
+    m.small_grad().zero_()
+    p = fused.camera_forward(m, cams[0], f, m._parameters.data, 1, None, cams[0].original_image)
+    torch.cuda.synchronize()
+    img_fused = p.out.permute(2, 0, 1)
+    img_ops = _fused_vs_opbyop_image(m, cams[0])
+    assert psnr(img_fused.cpu(), img_ops.cpu()) > 60.0
+    del p, img_fused, img_ops
+    # (3) a short optimisation lowers the loss (4 batches; production path)
+    args.debug_skip_optimizer = False
+    m.parameters_grad_buffer[:N].zero_()
+    m.small_grad().zero_()
+    losses = []
+    it = 1
+    for b in range(4):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        l, _, _ = _clm_batch(m, cams[4 * b:4 * b + 4], args)
+        losses.append(sum(x.item() for x in l) / 4)
+        it += 4
+    utils.set_cur_iter(it)
+    l, _, _ = _clm_batch(m, cams[:4], args)  # the first batch's cameras again
+    again = sum(x.item() for x in l) / 4
+    assert all(math.isfinite(x) for x in losses)
+    assert again < losses[0], (losses, again)
+
+
+# ----------------------------------------------------------------------------- config 5
+def test_config5_bigcity102m_one_batch_and_subscene(dev):
+    """102 231 360 Gaussians (bigcity.sh:54), 1920x1080, bsz 8, sparse Adam, no densification.  Rows
+    beyond 2^32 / 192 B = 22.4 M need 64-bit byte offsets in the [N,48] tables; the camera placed over
+    the LAST rows' region is re-rendered from a sub-scene holding only its visible rows, which must give
+    the same image and the same gradients."""
+    from clm_gs_amd import fused, utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload
+    N, W, H = 102_231_360, 1920, 1080
+    args, m, cams = _build("clm_offload", N, W, H, 8, 0.02, sparse_adam=True, disable_auto_densification=True,
+                           debug_skip_optimizer=True)
+    l1, _, sp = _clm_batch(m, cams, args)
+    assert all(math.isfinite(x.item()) for x in l1)
+    from clm_gs_amd.strategies.base_engine import select_filters
+    filters, tr = select_filters(cams, m._xyz.detach(), m._scaling.detach(), m._rotation.detach())
+    k = max(range(8), key=lambda i: int(filters[i].max()))
+    f = filters[k]
+    assert int(f.max()) * 48 > 2 ** 32, "the camera reaches rows whose element offset exceeds 32 bits"
+    g_sh = m.parameters_grad_buffer[:N]
+    assert float(g_sh[f].abs().max()) > 0 and bool(torch.isfinite(g_sh[tr]).all())
+    # sub-scene of camera k's rows
+    sub = GaussianModelCLMOffload(3)
+    sub.create_from_tensors(m._xyz.detach()[f], m._parameters.detach()[f], m._scaling.detach()[f],
+                            m._rotation.detach()[f], m._opacity.detach()[f], spatial_lr_scale=5.0)
+    sub.active_sh_degree = 3
+    sub.training_setup(args)
+    for p_ in (sub._xyz, sub._opacity, sub._scaling, sub._rotation):
+        p_.grad = torch.zeros_like(p_)
+    gs = torch.zeros((f.shape[0], 48), device="cuda")
+    p_sub = fused.camera_forward(sub, cams[k], None, sub._parameters.data, 1, None, cams[k].original_image)
+    fused.camera_backward(sub, p_sub, gs, update_stats=False)
+
+    def zero_small():
+        for p_ in (m._xyz, m._opacity, m._scaling, m._rotation):
+            p_.grad = torch.zeros_like(p_)
+    # (a) SH rows read and gradient rows accumulated BY ROW ID in the full [N,48] tables
+    zero_small()
+    m.parameters_grad_buffer[f] = 0
+    p_big = fused.camera_forward(m, cams[k], f, m._parameters.data, 1, None, cams[k].original_image)
+    fused.camera_backward(m, p_big, m.parameters_grad_buffer, update_stats=False)
+    torch.cuda.synchronize()
+    by_id = m.parameters_grad_buffer[f].clone()
+    small_by_id = [p_.grad[f].clone() for p_ in (m._xyz, m._opacity, m._scaling, m._rotation)]
+    # (b) the same camera with the rows gathered first (position layout)
+    zero_small()
+    big_gs = torch.zeros((f.shape[0], 48), device="cuda")
+    rows = m._parameters.data[f].contiguous()
+    p_big2 = fused.camera_forward(m, cams[k], f, rows, 0, None, cams[k].original_image)
+    fused.camera_backward(m, p_big2, big_gs, update_stats=False)
+    torch.cuda.synchronize()
+    assert torch.equal(p_sub.out, p_big.out) and torch.equal(p_sub.out, p_big2.out)
+    assert torch.equal(gs, big_gs) and torch.equal(gs, by_id)
+    for a, b, c in zip((sub._xyz, sub._opacity, sub._scaling, sub._rotation), small_by_id,
+                       (m._xyz, m._opacity, m._scaling, m._rotation)):
+        assert torch.equal(a.grad, b) and torch.equal(a.grad, c.grad[f])
