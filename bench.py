@@ -104,6 +104,7 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     os.environ.setdefault("OMP_NUM_THREADS", str(usable))  # all host cores this process may run on
     from oracle import c_oracle as C
+    C.set_num_threads(usable)
 
     with torch.no_grad():
         filters, _, _ = calculate_filters([cam], gaussians.get_xyz, gaussians.get_opacity,

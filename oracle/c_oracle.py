@@ -39,6 +39,10 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
 def render_forward(means, quats, scales, opac, shs48, sh_degree, viewmat, K, width, height,
                    background=None, radius_clip=0.0):
     """One camera, forward only.  All inputs numpy float32; quats/scales/opac ACTIVATED

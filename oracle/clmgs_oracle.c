@@ -32,6 +32,16 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* cpu_baseline leg: use every host core the process may run on (the OpenMP runtime may have been
+ * initialised earlier, by another library, with fewer). */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ A1 projection */
 static void quat_rot(const float* q, float* R) {
   float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);

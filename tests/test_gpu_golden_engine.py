@@ -131,14 +131,14 @@ def test_no_offload_pre_optimizer_matches_reference_engine(dev, fx, fused):
     assert vis is None
     tag = f"no_offload.{'fused' if fused else 'opbyop'}"
     for i, (a, b) in enumerate(zip(losses, d["losses"])):
-        assert _rec(f"{tag}.loss{i}.abs", abs(a.item() - b)) < 2e-5
+        assert _rec(f"{tag}.loss{i}.abs", abs(a.item() - b)) < 2e-6
     for name, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"),
                        ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation")):
         e = rel_l2(getattr(m, attr).grad.cpu(), _t(d[f"g_{name}"]))
-        assert _rec(f"{tag}.grad.{name}.rel_l2", e) < 1e-3, (name, e)
+        assert _rec(f"{tag}.grad.{name}.rel_l2", e) < 5e-5, (name, e)  # measured <= 4.1e-6
     assert torch.equal(m.max_radii2D.cpu(), _t(d["max_radii2D"]))
     assert torch.equal(m.denom.cpu(), _t(d["denom"]))
-    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 1e-3
+    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 5e-5
 
 
 def _adam_close(tag, name, p, m_, v, d, init):
@@ -149,10 +149,11 @@ def _adam_close(tag, name, p, m_, v, d, init):
     init = init.reshape(p_ref.shape)
     e_p = _rec(f"{tag}.{name}.delta.rel_l2", rel_l2(p.detach().cpu().reshape(p_ref.shape) - init, p_ref - init))
     e_abs = _rec(f"{tag}.{name}.param.rel_l2", rel_l2(p.detach().cpu().reshape(p_ref.shape), p_ref))
-    assert e_m < 2e-3, (tag, name, "exp_avg", e_m)
-    assert e_v < 4e-3, (tag, name, "exp_avg_sq", e_v)
-    assert e_p < 2e-2, (tag, name, "delta", e_p)
-    assert e_abs < 1e-4, (tag, name, "param", e_abs)
+    # measured on MI355X (profiles/r02_parity_report.json): <= 2.9e-5 / 7.7e-6 / 4.8e-5 / 1.2e-6
+    assert e_m < 3e-4, (tag, name, "exp_avg", e_m)
+    assert e_v < 1e-4, (tag, name, "exp_avg_sq", e_v)
+    assert e_p < 5e-4, (tag, name, "delta", e_p)
+    assert e_abs < 2e-5, (tag, name, "param", e_abs)
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -210,12 +211,12 @@ def test_clm_offload_pre_optimizer_gradients_match_reference(dev, fx, residency,
     tag = f"clm_pre.{residency}.{'fused' if fused else 'opbyop'}"
     N = m._xyz.shape[0]
     for k, l in zip(order, losses):
-        assert _rec(f"{tag}.loss{k}.abs", abs(l.item() - float(d["losses"][k]))) < 2e-5
+        assert _rec(f"{tag}.loss{k}.abs", abs(l.item() - float(d["losses"][k]))) < 2e-6
     counts = fx["filters"]["counts"]
     assert sorted(round(s * N) for s in sparsity) == sorted(counts.tolist())
     g_sh = m.parameters_grad_buffer[:N].detach().cpu().reshape(N, 16, 3)
     ref_sh = torch.cat((_t(d["g_f_dc"]), _t(d["g_f_rest"])), dim=1)
-    assert _rec(f"{tag}.grad.shs.rel_l2", rel_l2(g_sh, ref_sh)) < 1e-3
+    assert _rec(f"{tag}.grad.shs.rel_l2", rel_l2(g_sh, ref_sh)) < 5e-5  # measured 3.9e-6
     use_packed = residency == "hbm" and fused
     if use_packed:
         gk = m.small_grad().cpu()
@@ -226,12 +227,12 @@ def test_clm_offload_pre_optimizer_gradients_match_reference(dev, fx, residency,
                  "rotation": m._rotation.grad.cpu()}
     for name, g in small.items():
         e = rel_l2(g, _t(d[f"g_{name}"]))
-        assert _rec(f"{tag}.grad.{name}.rel_l2", e) < 1e-3, (name, e)
+        assert _rec(f"{tag}.grad.{name}.rel_l2", e) < 5e-5, (name, e)  # measured <= 4.1e-6
     # statistics: filter form == mask form on these inputs except max_radii2D/denom of rows inside the
     # filter whose radius is > 0 in both -- the filter IS radii > 0, so all three agree exactly / to fp32
     assert torch.equal(m.max_radii2D.cpu(), _t(d["max_radii2D"]))
     assert torch.equal(m.denom.cpu(), _t(d["denom"]))
-    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 1e-3
+    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 5e-5
 
 
 @pytest.mark.parametrize("residency,fused", CLM_MODES)
@@ -267,9 +268,9 @@ def test_clm_offload_three_batches_match_reference_engine(dev, fx, residency, fu
     _adam_close(tag, "parameters", m._parameters, st["exp_avg"], st["exp_avg_sq"], d, init["parameters"])
     assert torch.equal(m.denom.cpu(), _t(d["denom"]))
     assert torch.equal(m.max_radii2D.cpu(), _t(d["max_radii2D"]))
-    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 2e-3
+    assert _rec(f"{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(d["xyz_gradient_accum"]))) < 5e-5
     img = clm_offload_eval_one_cam(cams[0], m, None, Scene)
-    assert _rec(f"{tag}.eval_psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 55.0
+    assert _rec(f"{tag}.eval_psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 100.0
 
 
 def test_eval_and_forward_paths_match_reference_image(dev, fx):
@@ -288,7 +289,7 @@ def test_eval_and_forward_paths_match_reference_image(dev, fx):
         m._parameters.copy_(_t(d["p_parameters"]).cuda())
     m.invalidate_small_packed()
     img = clm_offload_eval_one_cam(cams[0], m, None, Scene)
-    assert _rec("eval.same_params.psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 60.0
+    assert _rec("eval.same_params.psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 100.0
 
 
 # ------------------------------------------------------------------ a13: densification
