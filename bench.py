@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--prime-seconds", type=float, default=2.0,
                     help="untimed evaluation renders before the warm-up steps (GPU clock / power ramp of a fresh box)")
+    ap.add_argument("--camera-order", default="shuffle", choices=["shuffle", "path"],
+                    help="shuffle: batches are seeded random draws from the survey, as the reference's DataLoader "
+                         "(shuffle=True, train.py:156-167); path: consecutive cameras of the lawn-mower path (neighbours "
+                         "overlap ~80 %%: far fewer distinct rows per batch than a shuffled loader sees)")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -192,6 +196,9 @@ def main():
     n_batches = a.warmup + a.steps
     # weak scaling: every rank owns its own cameras (seeded by rank)
     all_cams = nadir_cameras(n_batches * bsz * world, N, W, H, vis_frac, seed=0, device="cuda")
+    if a.camera_order == "shuffle":
+        perm = torch.randperm(len(all_cams), generator=torch.Generator().manual_seed(7)).tolist()
+        all_cams = [all_cams[i] for i in perm]
     cams = all_cams[rank::world]
     make_gt_images(cams, scene, args, W, H)
 
@@ -423,6 +430,7 @@ def main():
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
+                   "camera_order": a.camera_order,
                    "untimed_priming_s": a.prime_seconds},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
         "peak_gpu_bytes": int(peak),

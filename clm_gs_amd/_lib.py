@@ -34,15 +34,15 @@ SIGNATURES = {
     "clmgs_isect_emit_sort": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "clmgs_isect_offsets": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
     "clmgs_isect2_order_temp_bytes": (_sz, [_i]),
-    "clmgs_isect2_order_count": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "clmgs_isect2_order_count": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "clmgs_isect2_sort_temp_bytes": (_sz, [_i64]),
-    "clmgs_isect2_emit_sort": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "clmgs_isect2_emit_sort": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "clmgs_rasterize_pack_bytes": (_sz, [_i, _i]),
     "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_rasterize_partials_bytes": (_sz, [_i64]),
-    "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_preprocess_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "clmgs_preprocess_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "clmgs_preprocess_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "clmgs_ssim_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "clmgs_loss_slots": (_i, []),

@@ -226,20 +226,25 @@ __global__ void __launch_bounds__(256)
 isect2_keys_kernel(int V, const int32_t* __restrict__ radii, const float* __restrict__ depths,
                    const float* __restrict__ means2d, const float4* __restrict__ packed,
                    float tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys,
-                   int32_t* __restrict__ vals, unsigned long long* __restrict__ box_by_row) {
+                   int32_t* __restrict__ vals, unsigned long long* __restrict__ box_by_row,
+                   int64_t* __restrict__ row_cnt) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     const int r = radii[i];
     keys[i] = r > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
     vals[i] = i;
     unsigned long long b = 0ull, m = ~0ull;
+    int cnt = 0;
     if (r > 0) {
       const float2 mm = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
       const TileBox tb = tile_box(mm.x, mm.y, (float)r, tile_size, tile_w, tile_h);
       b = pack_box(tb);
       if (packed) m = exact_tile_mask(packed + 4 * (size_t)i, tb.x0, tb.y0, tb.x1, tb.y1);
+      const int nt = (tb.x1 - tb.x0) * (tb.y1 - tb.y0);
+      cnt = nt <= 64 ? __popcll(m & (nt == 64 ? ~0ull : ((1ull << nt) - 1ull))) : nt;
     }
     box_by_row[2 * (size_t)i] = b;
     box_by_row[2 * (size_t)i + 1] = m;
+    if (row_cnt) row_cnt[i] = cnt;  // emitted intersections of row i (same rule as isect2_count_kernel)
   }
 }
 
@@ -275,15 +280,18 @@ isect2_count_kernel(int V, const int32_t* __restrict__ order,
   }
 }
 
-// vals2 != NULL ("slot mode"): the sort payload is the pair (row id, EMIT index p).  A row's
-// intersections are emitted contiguously (emit range of rank j = [cum[j-1], cum[j])): the backward
-// tile kernel stores its per-(row, tile) partial gradients at p with plain stores and a pass in
-// rank order sums each contiguous range: no float atomics, deterministic.
+// vals2 != NULL ("slot mode"): the sort payload is the pair (row id, SLOT).  Slots are numbered in ROW
+// order: row i owns the contiguous range [row_cum[i-1], row_cum[i]) (its tiles in row-major tile
+// order).  The backward tile kernel stores its per-(row, tile) partial gradients at the slot with
+// plain stores; whoever consumes the row's gradient (clmgs_preprocess_bwd, or the row-sum kernel of
+// clmgs_rasterize_bwd) adds the row's range in ascending order: no float atomics, deterministic, and
+// both the partial lines and the consumer's rows are walked sequentially.
 __global__ void __launch_bounds__(256)
 isect2_emit_kernel(int V, const int32_t* __restrict__ order,
                    const unsigned long long* __restrict__ boxes,
                    const int64_t* __restrict__ cum, int tile_w, uint32_t* __restrict__ tkeys,
-                   int32_t* __restrict__ vals, int2* __restrict__ vals2) {
+                   int32_t* __restrict__ vals, int2* __restrict__ vals2,
+                   const int64_t* __restrict__ row_cum) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
     const unsigned long long b = boxes[2 * (size_t)j];
     if (b == 0ull) continue;
@@ -293,12 +301,13 @@ isect2_emit_kernel(int V, const int32_t* __restrict__ order,
     const bool masked = (x1 - x0) * (y1 - y0) <= 64;
     const int i = order[j];
     int64_t cur = (j == 0) ? 0 : cum[j - 1];
+    int slot = (vals2 && i > 0) ? (int)row_cum[i - 1] : 0;
     int t = 0;
     for (int ty = y0; ty < y1; ++ty)
       for (int tx = x0; tx < x1; ++tx, ++t) {
         if (masked && !((m >> t) & 1ull)) continue;
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
-        if (vals2) vals2[cur] = make_int2(i, (int)cur);
+        if (vals2) vals2[cur] = make_int2(i, slot++);
         else vals[cur] = i;
         ++cur;
       }
@@ -342,11 +351,13 @@ extern "C" size_t clmgs_isect2_order_temp_bytes(int V) {
 // boxes[2V] u64 (packed tile box + tile mask of every rank, box 0 = nothing to emit; input of
 // clmgs_isect2_emit_sort), totals[2] i64 device = {intersections to emit, un-culled count}.
 // packed != NULL (the [V,16] raster records): exact per-tile culling.
+// row_cum[V] i64 optional: inclusive emitted-intersection counts in ROW order (the slot ranges).
 extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2d,
                                         const int32_t* radii, const float* depths, int tile_size,
                                         int tile_width, int tile_height, const void* packed,
                                         int32_t* order, int64_t* cum, uint64_t* boxes,
-                                        int64_t* totals, void* temp, size_t temp_bytes) {
+                                        int64_t* totals, void* temp, size_t temp_bytes,
+                                        int64_t* row_cum) {
   CLMGS_CHECK_ARG(V >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
   CLMGS_CHECK_ARG(tile_width < 65536 && tile_height < 65536);
   if (V == 0) return 0;
@@ -365,11 +376,15 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   const int grid = min(ceil_div(V, 256), 256 * 16);
   hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, means2d,
                      (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a,
-                     box_by_row);
+                     box_by_row, row_cum);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
   if (rc) return rc;
+  if (row_cum) {
+    rc = inclusive_scan_i64(s, V, row_cum, scan_tmp);
+    if (rc) return rc;
+  }
   CLMGS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), s));
   hipLaunchKernelGGL(isect2_count_kernel, dim3(min(grid, 1024)), dim3(256), 0, s, V, order, box_by_row,
                      (unsigned long long*)boxes, cum, (unsigned long long*)(totals + 1));
@@ -389,7 +404,8 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
                                       const int32_t* order, const int64_t* cum,
                                       const uint64_t* boxes, int tile_width, int tile_height,
                                       int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
-                                      int32_t* emit_slot, void* temp, size_t temp_bytes) {
+                                      int32_t* emit_slot, void* temp, size_t temp_bytes,
+                                      const int64_t* row_cum) {
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
@@ -409,10 +425,11 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   char* v_f = base; base += 2 * a4;
   uint32_t* table = (uint32_t*)base;
   const bool slots = emit_slot != nullptr;
+  CLMGS_CHECK_ARG(!slots || row_cum);
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
                      order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
-                     slots ? (int2*)v_a : nullptr);
+                     slots ? (int2*)v_a : nullptr, row_cum);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc;

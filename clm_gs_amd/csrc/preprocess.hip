@@ -233,6 +233,11 @@ struct PreGrads {
   int packed_stats;      // 1: max_radii2D is a [N,4] table  max radius | grad accum | count | pad
   float* v_means2d_out;  // [V,2] or NULL: copy of the screen-space gradient (API parity)
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
+  // != NULL: the rasterize backward left one 64 B partial-gradient line per (row, tile) intersection;
+  // row i owns lines [row_cum[i-1], row_cum[i]) and its gradient line is their sum in ascending order
+  // (this kernel then takes the place of the row-sum pass: no [V,16] gradient table round trip)
+  const float4* partials;
+  const int64_t* row_cum;
 };
 
 template <int DEG, bool PK>
@@ -247,14 +252,19 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
   const int t = threadIdx.x;
   int chunk = blockIdx.x;
   int my_row = -1, my_radius = 0;
+  int64_t my_s0 = 0;
+  int my_cnt = 0;
   if (chunk < n_chunks && chunk * PP_ROWS + t < V) {
     const int i = chunk * PP_ROWS + t;
     my_row = a.filter ? (int)a.filter[i] : i;
     my_radius = radii[i];
+    if (o.partials) { my_s0 = i ? o.row_cum[i - 1] : 0; my_cnt = (int)(o.row_cum[i] - my_s0); }
   }
   for (; chunk < n_chunks; chunk += gridDim.x) {
     const int base = chunk * PP_ROWS;
     const int radius = my_radius;
+    const int64_t s0 = my_s0;
+    const int cnt = my_cnt;
     const bool mine = my_row >= 0;
     const bool vis = mine && radius > 0;
     const bool stat = mine && o.max_radii2D && (radius > 0 || !o.stats_only_visible);
@@ -265,9 +275,24 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t gl = vis ? g : (int64_t)__shfl((int)g, first);
     const int i = mine ? base + t : base;
     // ---- everything this lane needs from HBM, requested at once
-    const float4 ga = packed_grad[4 * (size_t)i];   // line: x y ca cb | cc r g b | o
-    const float4 gb = packed_grad[4 * (size_t)i + 1];
-    const float go = packed_grad[4 * (size_t)i + 2].x;
+    float4 ga, gb;   // line: x y ca cb | cc r g b | o
+    float go;
+    float4 pa[4], pb[4];
+    float po[4];
+    if (o.partials) {  // kernel-uniform.  The row's first four partial lines are requested here, with
+      // everything else the lane needs; longer ranges (rare: 2.6 lines per row on average) follow below
+      ga = make_float4(0.f, 0.f, 0.f, 0.f); gb = ga; go = 0.f;
+      const float4* src = o.partials + 4 * (size_t)s0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pa[u] = ga; pb[u] = ga; po[u] = 0.f;
+        if (mine && u < cnt) { pa[u] = src[4 * u]; pb[u] = src[4 * u + 1]; po[u] = src[4 * u + 2].x; }
+      }
+    } else {
+      ga = packed_grad[4 * (size_t)i];
+      gb = packed_grad[4 * (size_t)i + 1];
+      go = packed_grad[4 * (size_t)i + 2].x;
+    }
     const SmallRow sr = load_small<PK>(a, gl);
     const float m[3] = {sr.m[0], sr.m[1], sr.m[2]};
     const float4 q4 = sr.q4;
@@ -306,8 +331,39 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
   }
     {
       const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
-      my_row = -1; my_radius = 0;
-      if (ni < V) { my_row = a.filter ? (int)a.filter[ni] : ni; my_radius = radii[ni]; }
+      my_row = -1; my_radius = 0; my_s0 = 0; my_cnt = 0;
+      if (ni < V) {
+        my_row = a.filter ? (int)a.filter[ni] : ni; my_radius = radii[ni];
+        if (o.partials) { my_s0 = ni ? o.row_cum[ni - 1] : 0; my_cnt = (int)(o.row_cum[ni] - my_s0); }
+      }
+    }
+    if (o.partials) {
+      // ascending slot order = the order the row-sum kernel used -> bit-identical gradients.  Neighbouring
+      // lanes own neighbouring ranges: the wave streams one contiguous stretch of the buffer.
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // lines beyond cnt were loaded as zeros
+        ga.x += pa[u].x; ga.y += pa[u].y; ga.z += pa[u].z; ga.w += pa[u].w;
+        gb.x += pb[u].x; gb.y += pb[u].y; gb.z += pb[u].z; gb.w += pb[u].w;
+        go += po[u];
+      }
+      if (mine) {
+        const float4* src = o.partials + 4 * (size_t)s0;
+        for (int tt = 4; tt < cnt; tt += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = min(tt + u, cnt - 1);
+            pa[u] = src[4 * l]; pb[u] = src[4 * l + 1]; po[u] = src[4 * l + 2].x;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (tt + u < cnt) {
+              ga.x += pa[u].x; ga.y += pa[u].y; ga.z += pa[u].z; ga.w += pa[u].w;
+              gb.x += pb[u].x; gb.y += pb[u].y; gb.z += pb[u].z; gb.w += pb[u].w;
+              go += po[u];
+            }
+          }
+        }
+      }
     }
     // ---- statistics + projection VJP while the SH rows are in flight
     const float v_m2[2] = {ga.x, ga.y};
@@ -509,11 +565,14 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     const void* packed_grad, float* g_xyz, float* g_opacity,
                                     float* g_scaling, float* g_rotation, float* g_sh_rows,
                                     float* max_radii2D, float* grad_accum, float* denom,
-                                    float* v_means2d_out, int stats_only_visible) {
+                                    float* v_means2d_out, int stats_only_visible,
+                                    const void* partials, const int64_t* row_cum) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
-  CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && packed_grad &&
-                  g_xyz && g_sh_rows);
+  CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && g_xyz && g_sh_rows);
+  // exactly one source of the per-row raster gradient: the [V,16] table, or the partial lines + ranges
+  CLMGS_CHECK_ARG((packed_grad != nullptr) != (partials != nullptr));
+  CLMGS_CHECK_ARG(!partials || (row_cum && (((uintptr_t)partials & 63) == 0)));
   CLMGS_CHECK_ARG((opacity_raw && scaling_raw && rotation_raw) ||
                   (!opacity_raw && !scaling_raw && !rotation_raw && (((uintptr_t)xyz & 15) == 0)));
   const bool pg = !g_opacity && !g_scaling && !g_rotation;
@@ -527,7 +586,7 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
-             pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible};
+             pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible, (const float4*)partials, row_cum};
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_BWD(D)                                                                          \

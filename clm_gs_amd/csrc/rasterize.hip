@@ -466,19 +466,17 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   }
 }
 
-// Per-row sum of the tile partials, walked in RANK (depth) order: rank j owns the contiguous emit
-// range [cum[j-1], cum[j]), so a wave streams one contiguous stretch of the partials buffer;
-// fixed order (ascending emit index) -> the row's gradient line (one scattered 64 B store).
+// Per-row sum of the tile partials (API surface: the engine path folds this sum into
+// clmgs_preprocess_bwd).  Row i owns the contiguous slot range [row_cum[i-1], row_cum[i]); ranges and
+// gradient lines are both walked sequentially; fixed order (ascending slot).
 // partials line = gradient line: x y ca cb | cc r g b | o - - - | -
 __global__ void __launch_bounds__(256)
-raster_partials_sum_kernel(int64_t n_rows, const int32_t* __restrict__ order,
-                           const int64_t* __restrict__ cum, const float4* __restrict__ partials,
-                           float4* __restrict__ packed_grad) {
-  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n_rows;
-       j += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = order[j];
-    const int64_t s0 = j ? cum[j - 1] : 0;
-    const int cnt = (int)(cum[j] - s0);
+raster_partials_sum_kernel(int64_t n_rows, const int64_t* __restrict__ row_cum,
+                           const float4* __restrict__ partials, float4* __restrict__ packed_grad) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s0 = r ? row_cum[r - 1] : 0;
+    const int cnt = (int)(row_cum[r] - s0);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     float o = 0.f;
     const float4* src = partials + 4 * (size_t)s0;
@@ -569,18 +567,19 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
                                    const float* v_render_alphas, void* packed_grad,
                                    float* v_means2d, float* v_conics, float* v_colors,
                                    float* v_opacities, const int32_t* emit_slot,
-                                   const int32_t* order, const int64_t* cum, void* partials) {
+                                   const int64_t* row_cum, void* partials) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
   CLMGS_CHECK_ARG(!v_means2d || (v_conics && v_colors && v_opacities));
   const bool part = emit_slot != nullptr;
-  CLMGS_CHECK_ARG(!part || (C == 1 && order && cum && partials && (((uintptr_t)partials & 63) == 0)));
+  CLMGS_CHECK_ARG(!part || (C == 1 && partials && (((uintptr_t)partials & 63) == 0)));
+  // packed_grad == NULL (slot mode only): the caller sums the partial lines itself (clmgs_preprocess_bwd)
+  CLMGS_CHECK_ARG(packed_grad ? ((((uintptr_t)packed_grad & 63) == 0) && (!part || row_cum)) : (part && !v_means2d));
   hipStream_t s = (hipStream_t)stream;
   const int64_t CN = (int64_t)C * N;
   if (CN == 0) return 0;
-  CLMGS_CHECK_ARG(packed_grad && (((uintptr_t)packed_grad & 63) == 0));
-  if (!part || n_isects == 0)
+  if (packed_grad && (!part || n_isects == 0))
     CLMGS_HIP(hipMemsetAsync(packed_grad, 0, clmgs_rasterize_pack_bytes(C, N), s));
   if (n_isects > 0) {
     CLMGS_CHECK_ARG(packed && offsets && flatten_ids && render_alphas && last_ids && v_render_colors);
@@ -612,9 +611,9 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
 #endif
 #undef CLMGS_LAUNCH_BWD
     CLMGS_LAUNCH_CHECK();
-    if (part) {
+    if (part && packed_grad) {
       hipLaunchKernelGGL(raster_partials_sum_kernel, dim3(min(ceil_div(CN, 256), 256 * 16)), dim3(256),
-                         0, s, CN, order, cum, (const float4*)partials, (float4*)packed_grad);
+                         0, s, CN, row_cum, (const float4*)partials, (float4*)packed_grad);
       CLMGS_LAUNCH_CHECK();
     }
   }

@@ -45,7 +45,7 @@ class _CameraPass:
     """Everything one camera's forward leaves behind for its backward (kept alive by the caller
     until the streams involved have consumed it)."""
     __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
-                 "packed", "fids", "offsets", "emit_slot", "order", "cum", "out", "alphas", "last_ids",
+                 "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids",
                  "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux", "loss_partials",
                  "lambda_dssim", "gt_u8", "background", "isect")
 
@@ -123,7 +123,7 @@ def camera_forward_finish(gaussians, p):
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
     with torch.cuda.stream(s_front):
         with _lib.host_region("fwd_isect"):
-            p.fids, p.offsets, _, (p.emit_slot, p.order, p.cum) = isect2_finish(p.isect)
+            p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = isect2_finish(p.isect)
         p.isect = None
         p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
         p.alphas = torch.empty((H, W), dtype=F32, device=dev)
@@ -197,15 +197,15 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
                      dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
     with torch.cuda.stream(s_mem):
-        packed_grad = empty_bucketed(V, (16,), F32, dev)
-        # atomic-free accumulation: one 64 B line per intersection, summed per row afterwards
+        # atomic-free accumulation: the tile kernel stores one 64 B line per intersection (row-ordered
+        # slots); clmgs_preprocess_bwd sums each row's contiguous range while it gathers the row
         partials = empty_bucketed(max(n_isects, 1), (16,), F32, dev)
     if p.ev_loss is not None:
         s_raster.wait_event(p.ev_loss)
     check(L.clmgs_rasterize_bwd(_sptr(s_raster), 1, V, n_isects, dptr(p.packed), dptr(p.bg, F32, True), W, H,
                                 TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(p.alphas), dptr(p.last_ids),
-                                dptr(p.v_out), None, dptr(packed_grad), None, None, None, None,
-                                dptr(p.emit_slot), dptr(p.order), dptr(p.cum), dptr(partials)))
+                                dptr(p.v_out), None, None, None, None, None, None,
+                                dptr(p.emit_slot), dptr(p.row_cum), dptr(partials)))
     if s_mem is not s_raster:
         ev = torch.cuda.Event()
         ev.record(s_raster)
@@ -226,9 +226,9 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         check(L.clmgs_preprocess_bwd(
             _sptr(s_mem), V, dptr(p.filt, torch.int64, True), *p.small_in, dptr(p.sh_rows, F32, allow_host=True),
             int(p.sh_by_filter), _np(vm), _np(K), _np(campos), W, H, p.deg, 0.3, dptr(p.radii),
-            dptr(packed_grad), *small_out, dptr(g_sh_rows, F32, allow_host=True),
-            *stat_ptrs, None, int(bool(stats_only_visible))))
-    p.aux = p.aux + (packed_grad, partials)
+            None, *small_out, dptr(g_sh_rows, F32, allow_host=True),
+            *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum)))
+    p.aux = p.aux + (partials,)
     return p
 
 

@@ -266,7 +266,7 @@ def _pinned_totals_slot():
 class _Isect2:
     """State between isect2_begin and isect2_finish (one camera's binning in flight)."""
     __slots__ = ("args", "V", "dev", "depths", "order", "cum", "boxes", "totals", "host", "event",
-                 "offsets", "temp", "means2d", "radii", "packed")
+                 "offsets", "temp", "means2d", "radii", "packed", "row_cum")
 
 
 @torch.no_grad()
@@ -291,11 +291,13 @@ def isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height, wan
     c.cum = empty_bucketed(V, (), I64, dev)
     c.boxes = empty_bucketed(V, (2,), I64, dev)
     c.totals = torch.empty((2,), dtype=I64, device=dev)
+    c.row_cum = empty_bucketed(V, (), I64, dev) if want_slots else None
     tb = L.clmgs_isect2_order_temp_bytes(V)
     c.temp = empty_bucketed(tb, (), torch.uint8, dev)
     check(L.clmgs_isect2_order_count(stream(), V, dptr(c.means2d, F32), dptr(c.radii, I32), dptr(c.depths, F32),
                                      c.args[0], c.args[1], c.args[2], dptr(packed, F32, True), dptr(c.order),
-                                     dptr(c.cum), dptr(c.boxes), dptr(c.totals), dptr(c.temp), tb))
+                                     dptr(c.cum), dptr(c.boxes), dptr(c.totals), dptr(c.temp), tb,
+                                     dptr(c.row_cum, I64, True)))
     c.host = _pinned_totals_slot()
     c.host.copy_(c.totals, non_blocking=True)
     c.event = torch.cuda.Event()
@@ -314,7 +316,7 @@ def isect2_finish(c):
         c.offsets.zero_()
         e = torch.empty(0, dtype=I32, device=dev)
         res = (e, c.offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
-        return res + ((e, e.clone(), torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
+        return res + ((e, torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
     _t0 = time.perf_counter()
     c.event.synchronize()
     n_isects, n_ref = int(c.host[0]), int(c.host[1])
@@ -331,8 +333,9 @@ def isect2_finish(c):
     emit_slot = empty_bucketed(n_isects, (), I32, dev) if want_slots else None
     check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(c.depths), dptr(c.order), dptr(c.cum),
                                    dptr(c.boxes), tile_width, tile_height, dptr(fids), dptr(c.offsets),
-                                   dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb))
-    return (fids, c.offsets, ids, (emit_slot, c.order, c.cum)) if want_slots else (fids, c.offsets, ids)
+                                   dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb,
+                                   dptr(c.row_cum, I64, True)))
+    return (fids, c.offsets, ids, (emit_slot, c.row_cum)) if want_slots else (fids, c.offsets, ids)
 
 
 @torch.no_grad()
@@ -341,8 +344,8 @@ def isect_tiles_two_level(means2d, radii, depths, tile_size, tile_width, tile_he
     """Single-camera binning through the two-level sort (depth sort of the rows, then one stable
     sort on tile-id bits).  -> (flatten_ids[I] i32, offsets[1,th,tw] i32, isect_ids[I] i64 | None),
     identical to isect_tiles + isect_offset_encode for C = 1.  want_slots: a 4th result
-    (emit_slot[I] i32, order[V] i32, cum[V] i64) for the atomic-free rasterize backward: rank j
-    (row order[j]) owns the contiguous emit range [cum[j-1], cum[j]).
+    (emit_slot[I] i32, row_cum[V] i64) for the atomic-free rasterize backward: row i owns the
+    contiguous slot range [row_cum[i-1], row_cum[i]).
     packed: the [V,16] raster records -> EXACT per-tile culling (pairs whose tile cannot reach
     alpha >= 1/255 are not emitted; image and gradients unchanged, the list gets ~29 % shorter).
     = isect2_begin + isect2_finish back to back."""
@@ -398,7 +401,7 @@ class _Rasterize(torch.autograd.Function):
             stream(), C, N, fids.numel(), dptr(packed), dptr(bg, F32, True), width, height,
             tile_size, tw, th, dptr(offsets), dptr(fids), dptr(alphas), dptr(last_ids),
             dptr(v_out, F32), dptr(v_alphas, F32, True), dptr(packed_grad), dptr(v_means2d),
-            dptr(v_conics), dptr(v_colors), dptr(v_opacities), None, None, None, None))
+            dptr(v_conics), dptr(v_colors), dptr(v_opacities), None, None, None))
         return v_means2d, v_conics, v_colors, v_opacities, None, None, None, None, None, None
 
 

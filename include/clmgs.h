@@ -107,19 +107,22 @@ int clmgs_isect_offsets(void* stream, int64_t n_isects, const int64_t* isect_ids
  * in that order (order[V] i32, cum[V] i64 inclusive; caller reads cum[V-1] = I);
  * B = emit in depth order + ONE stable sort on the tile-id bits -> flatten_ids[I] i32 (row ids),
  * offsets[tile_w*tile_h] i32, and isect_ids[I] i64 if non-NULL.
- * emit_slot[I] (i32, optional): the emit index of every sorted intersection; a rank's emit range
- * is the contiguous [cum[j-1], cum[j]) -- hand emit_slot, order and cum to clmgs_rasterize_bwd
- * for the atomic-free (deterministic) gradient accumulation. */
+ * row_cum[V] (i64, optional, from order_count): inclusive counts of the EMITTED intersections in ROW
+ * order; with it emit_sort also returns emit_slot[I] (i32): the slot of every sorted intersection,
+ * row i owning the contiguous slots [row_cum[i-1], row_cum[i]) -- hand emit_slot to
+ * clmgs_rasterize_bwd (which STORES one partial-gradient line per slot) and row_cum to whoever sums the
+ * rows (clmgs_preprocess_bwd, or clmgs_rasterize_bwd's own row-sum pass): atomic-free, deterministic. */
 size_t clmgs_isect2_order_temp_bytes(int V);
 int clmgs_isect2_order_count(void* stream, int V, const float* means2d, const int32_t* radii,
                              const float* depths, int tile_size, int tile_width, int tile_height,
                              const void* packed, int32_t* order, int64_t* cum, uint64_t* boxes,
-                             int64_t* totals, void* temp, size_t temp_bytes);
+                             int64_t* totals, void* temp, size_t temp_bytes, int64_t* row_cum);
 size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects);
 int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
                            const int32_t* order, const int64_t* cum, const uint64_t* boxes,
                            int tile_width, int tile_height, int32_t* flatten_ids, int32_t* offsets,
-                           int64_t* isect_ids, int32_t* emit_slot, void* temp, size_t temp_bytes);
+                           int64_t* isect_ids, int32_t* emit_slot, void* temp, size_t temp_bytes,
+                           const int64_t* row_cum);
 
 /* ---- gsplat.rasterize_to_pixels  (base_engine.py:192-203)
  * means2d[C*N,2] conics[C*N,3] colors[C*N,3] opacities[C*N], backgrounds[C,3] or NULL ->
@@ -138,13 +141,15 @@ int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects, const floa
  * gradient line per Gaussian (x y ca cb | cc r g b | o).  Two accumulation modes:
  *   - emit_slot == NULL: packed_grad is zeroed here and the per-(Gaussian,tile) sums are added
  *     with float atomics (any flatten_ids / offsets, C >= 1);
- *   - emit_slot from clmgs_isect2_emit_sort, order / cum from clmgs_isect2_order_count (C == 1) + `partials` scratch of
+ *   - emit_slot from clmgs_isect2_emit_sort (C == 1) + `partials` scratch of
  *     clmgs_rasterize_partials_bytes(n_isects) bytes (64 B aligned): every (Gaussian,tile) sum is
- *     STORED at its emit slot and a pass in rank order adds each row's contiguous range in a fixed
- *     order -- no atomics (they bound the kernel: 4.05 -> ~2 ms at 12 M intersections), bitwise
- *     reproducible gradients.
+ *     STORED at its slot (every slot is written exactly once, zeros included) -- no atomics (they
+ *     bound the kernel: 4.05 -> ~2 ms at 12 M intersections), bitwise reproducible gradients.  With
+ *     packed_grad != NULL (+ row_cum from clmgs_isect2_order_count) a row-order pass then adds each row's
+ *     contiguous slot range into packed_grad; with packed_grad == NULL the partial lines are the
+ *     result and clmgs_preprocess_bwd(partials, row_cum) sums them on the fly (engine path).
  * v_means2d[C*N,2] v_conics[C*N,3] v_colors[C*N,3] v_opacities[C*N] are OVERWRITTEN;
- * v_means2d == NULL skips the unpack (the caller reads packed_grad). */
+ * v_means2d == NULL skips the unpack (the caller reads packed_grad / the partial lines). */
 size_t clmgs_rasterize_partials_bytes(int64_t n_isects);
 int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void* packed,
                         const float* backgrounds, int width, int height, int tile_size,
@@ -153,8 +158,7 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
                         const int32_t* last_ids, const float* v_render_colors,
                         const float* v_render_alphas, void* packed_grad, float* v_means2d,
                         float* v_conics, float* v_colors, float* v_opacities,
-                        const int32_t* emit_slot, const int32_t* order, const int64_t* cum,
-                        void* partials);
+                        const int32_t* emit_slot, const int64_t* row_cum, void* partials);
 
 /* ---- fused per-camera front end (engine-internal fast path; same arithmetic as the op chain
  * strategies/clm_offload/engine.py:650-691 forward and :703-742 + densification.py:59-102 backward)
@@ -163,7 +167,9 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * viewmat[16] (row-major world->camera), K[9], campos[3] are HOST pointers (copied into the launch).
  * fwd: exp / sigmoid, projection, SH colour, +0.5 clamp -> radii[V] means2d[V,2] depths[V]
  * conics[V,3] colors[V,3] opacities[V] and the packed raster records packed[V,16].
- * bwd: from packed_grad[V,16] ACCUMULATES into g_xyz[N,3] g_opacity[N] g_scaling[N,3]
+ * bwd: from packed_grad[V,16] -- or, packed_grad == NULL, from the partial lines `partials` of
+ * clmgs_rasterize_bwd, row i summing the lines [row_cum[i-1], row_cum[i]) in ascending order --
+ * ACCUMULATES into g_xyz[N,3] g_opacity[N] g_scaling[N,3]
  * g_rotation[N,4] (raw-parameter gradients) and g_sh_rows (indexed like sh_rows), and, if
  * max_radii2D != NULL, updates the densification statistics of every filter row (or, with
  * stats_only_visible, of the rows with radius > 0: densification.py:105-147). */
@@ -188,7 +194,8 @@ int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float
                          int width, int height, int degree, float eps2d, const int32_t* radii,
                          const void* packed_grad, float* g_xyz, float* g_opacity, float* g_scaling,
                          float* g_rotation, float* g_sh_rows, float* max_radii2D, float* grad_accum,
-                         float* denom, float* v_means2d_out, int stats_only_visible);
+                         float* denom, float* v_means2d_out, int stats_only_visible,
+                         const void* partials, const int64_t* row_cum);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
  * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes

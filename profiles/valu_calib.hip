@@ -1,0 +1,97 @@
+// VALU issue-rate calibration for gfx950 (MI355X): the compute-side roofline of the alpha-blend tile
+// kernels.  Each test runs the same wave64 instruction in long unrolled independent chains on every
+// SIMD of the chip (8 waves / SIMD and 4 waves / SIMD) and reports
+//   G wave-instructions / s (wall clock, whole chip)   and   shader cycles per instruction per SIMD.
+// Build + run:  hipcc -O3 --offload-arch=gfx950 profiles/valu_calib.hip -o /tmp/valu_calib && /tmp/valu_calib
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr int CHAINS = 8;
+constexpr int UNROLL = 16;  // instructions per chain per loop trip
+
+enum Op { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERMLANE32_SWAP, CNDMASK, LDS_B128_BCAST, FMA_WITH_SALU, MIN_CMP, N_OPS };
+static const char* NAMES[N_OPS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp(row_shr:1)",
+                                   "v_permlane32_swap_b32", "v_cndmask_b32(vcc)", "ds_read_b128(broadcast)", "v_fma_f32 + 1 s_add per 2",
+                                   "v_min_f32+v_cmp_ge_f32"};
+
+template <int OP>
+__global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned long long* cycles) {
+  __shared__ float4 lds[64];
+  if (threadIdx.x < 64) lds[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
+  __syncthreads();
+  float v[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) v[c] = 1.0f + 1e-3f * (float)(threadIdx.x + c);
+  const float a = 0.999f, b = 1e-4f;
+  int sacc = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int t = 0; t < trips; ++t) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+        if (OP == MUL_ADD) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[c]) : "v"(a)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[c]) : "v"(b)); }
+        if (OP == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(v[c]));
+        if (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[c]));
+        if (OP == DPP_ADD) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[c]));
+        if (OP == PERMLANE32_SWAP) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[c]), "+v"(v[(c + 1) % CHAINS]));
+        if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(a));
+        if (OP == LDS_B128_BCAST) {
+          float4 r;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((int)((u * 16) & 1008)));
+          asm volatile("s_waitcnt lgkmcnt(4)");
+          v[c] += r.x;
+        }
+        if (OP == FMA_WITH_SALU) {
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+          if (c & 1) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc));
+        }
+        if (OP == MIN_CMP) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[c]) : "v"(a)); asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(v[c]), "v"(b) : "vcc"); }
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = (float)sacc;
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) s += v[c];
+  if (s == 123.456f) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+}
+
+template <int OP>
+void run(int waves_per_simd, float* out, unsigned long long* cyc_d) {
+  const int trips = 2000;
+  const int blocks = 256 * waves_per_simd;  // 256-thread blocks = 4 waves = one per SIMD of a CU
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(calib<OP>, dim3(blocks), dim3(256), 0, 0, 10, out, cyc_d);  // warm-up
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(calib<OP>, dim3(blocks), dim3(256), 0, 0, trips, out, cyc_d);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long cyc = 0;
+  CHECK(hipMemcpy(&cyc, cyc_d, sizeof(cyc), hipMemcpyDeviceToHost));
+  int per = (OP == MUL_ADD || OP == MIN_CMP) ? 2 : 1;
+  const double instr_per_wave = (double)trips * UNROLL * CHAINS * per;
+  const double total = instr_per_wave * blocks * 4;
+  printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"G_wave_instr_per_s\": %.1f, \"cycles_per_instr_per_simd\": %.2f, \"ms\": %.3f}\n",
+         NAMES[OP], waves_per_simd, total / (ms * 1e-3) / 1e9, (double)cyc / (instr_per_wave * waves_per_simd), ms);
+}
+
+int main() {
+  float* out; unsigned long long* cyc;
+  CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&cyc, 64));
+  for (int w : {8, 4, 1}) {
+    run<FMA>(w, out, cyc); run<MUL_ADD>(w, out, cyc); run<EXP>(w, out, cyc); run<RCP>(w, out, cyc);
+    run<DPP_ADD>(w, out, cyc); run<PERMLANE32_SWAP>(w, out, cyc); run<CNDMASK>(w, out, cyc);
+    run<LDS_B128_BCAST>(w, out, cyc); run<FMA_WITH_SALU>(w, out, cyc); run<MIN_CMP>(w, out, cyc);
+  }
+  return 0;
+}

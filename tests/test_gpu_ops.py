@@ -466,20 +466,21 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
     colors = torch.rand(1, n, 3, generator=g)
     opac = s["opac"].reshape(1, -1)
     f0, o0, _ = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th)
-    fids, off, _, (slot, order, cum) = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th,
-                                                               want_slots=True)
+    fids, off, _, (slot, row_cum) = G.isect_tiles_two_level(m2.to(dev), radii.to(dev), d.to(dev), 16, tw, th,
+                                                            want_slots=True)
     assert torch.equal(fids, f0) and torch.equal(off, o0)
     I = fids.numel()
-    assert torch.equal(torch.sort(slot.long()).values.cpu(), torch.arange(I))  # a permutation of the emit order
-    assert int(cum[-1]) == I and torch.equal(torch.sort(order.long()).values.cpu(), torch.arange(n))
+    assert torch.equal(torch.sort(slot.long()).values.cpu(), torch.arange(I))  # the slots are a permutation
+    assert int(row_cum[-1]) == I and row_cum.numel() == n
     owner = torch.empty(I, dtype=torch.int64)
-    owner[slot.long().cpu()] = fids.long().cpu()  # row id stored at each emit slot
-    cu, od = cum.cpu(), order.long().cpu()
+    owner[slot.long().cpu()] = fids.long().cpu()  # row id stored at each slot
+    cu = row_cum.cpu()
     starts = torch.cat((torch.zeros(1, dtype=torch.int64), cu[:-1]))
     cnt = cu - starts
-    for j in torch.nonzero(cnt).flatten()[:200].tolist():  # rank j owns a contiguous range of its row
-        assert bool((owner[starts[j]:cu[j]] == od[j]).all())
-    assert bool((cnt[radii[0][od] <= 0] == 0).all())
+    for i in torch.nonzero(cnt).flatten()[:300].tolist():  # row i owns the contiguous slots [starts[i], cu[i])
+        assert bool((owner[starts[i]:cu[i]] == i).all())
+    assert bool((cnt[radii[0] <= 0] == 0).all())
+    assert torch.equal(cnt, torch.bincount(fids.long().cpu(), minlength=n))
 
     t = [x.to(dev).contiguous() for x in (m2, cn, colors, opac)]
     out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
@@ -498,8 +499,15 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
         assert L.clmgs_rasterize_partials_bytes(I) == parts.numel() * 4
         check(L.clmgs_rasterize_bwd(stream(), 1, n, I, dptr(packed), None, w, h, 16, tw, th, dptr(off), dptr(fids),
                                     dptr(al), dptr(last), dptr(vi), dptr(va), dptr(pg), *[dptr(x) for x in outs],
-                                    *((dptr(slot), dptr(order), dptr(cum), dptr(parts)) if slots else (None,) * 4)))
+                                    *((dptr(slot), dptr(row_cum), dptr(parts)) if slots else (None,) * 3)))
         torch.cuda.synchronize()
+        if slots:  # the sum the engine path folds into clmgs_preprocess_bwd: row ranges of the partial lines
+            ps, st = parts.cpu(), starts.tolist()
+            for i in torch.nonzero(cnt).flatten()[:100].tolist():
+                want = torch.zeros(16)
+                for l in range(st[i], int(cu[i])):
+                    want = want + ps[l]
+                assert torch.equal(want[:9], pg[i].cpu()[:9]), i
         return [x.cpu() for x in outs]
 
     ga, gs1, gs2 = bwd(False), bwd(True), bwd(True)
@@ -619,8 +627,8 @@ def test_rasterize_with_no_intersections(dev):
     m2 = torch.full((1, n, 2), -500.0, device=dev)           # far off screen
     radii = torch.zeros((1, n), dtype=torch.int32, device=dev)  # culled
     depths = torch.ones((1, n), device=dev)
-    fids, off, _, (slot, order, cum) = G.isect_tiles_two_level(m2, radii, depths, 16, tw, th, want_slots=True)
-    assert fids.numel() == 0 and int(off.abs().sum()) == 0 and int(cum[-1]) == 0
+    fids, off, _, (slot, row_cum) = G.isect_tiles_two_level(m2, radii, depths, 16, tw, th, want_slots=True)
+    assert fids.numel() == 0 and int(off.abs().sum()) == 0 and int(row_cum[-1]) == 0
     packed = torch.zeros(n, 16, device=dev)
     bg = torch.tensor([[0.25, 0.5, 0.75]], device=dev)
     out = torch.empty(1, h, w, 3, device=dev); al = torch.empty(1, h, w, device=dev)
@@ -636,7 +644,7 @@ def test_rasterize_with_no_intersections(dev):
                 torch.full((n, 3), 7.0, device=dev), torch.full((n,), 7.0, device=dev)]
         check(L.clmgs_rasterize_bwd(stream(), 1, n, 0, dptr(packed), dptr(bg), w, h, 16, tw, th, dptr(off), None,
                                     dptr(al), dptr(last), dptr(vi), None, dptr(pg), *[dptr(x) for x in outs],
-                                    *((dptr(slot, torch.int32, True), dptr(order), dptr(cum), dptr(parts)) if slots
-                                      else (None,) * 4)))
+                                    *((dptr(slot, torch.int32, True), dptr(row_cum), dptr(parts)) if slots
+                                      else (None,) * 3)))
         for x in outs:
             assert float(x.abs().max()) == 0.0
