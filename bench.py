@@ -76,6 +76,10 @@ def parse():
                     help="shuffle: batches are seeded random draws from the survey, as the reference's DataLoader "
                          "(shuffle=True, train.py:156-167); path: consecutive cameras of the lawn-mower path (neighbours "
                          "overlap ~80 %%: far fewer distinct rows per batch than a shuffled loader sees)")
+    ap.add_argument("--no-host-leg", action="store_true",
+                    help="skip the second leg (the same workload with the SH rows + Adam state in pinned host memory)")
+    ap.add_argument("--host-steps", type=int, default=5)
+    ap.add_argument("--host-warmup", type=int, default=2)
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -152,6 +156,108 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     }
 
 
+def gt_to_pinned_host(cams):
+    """Host-resident mode: the cameras' ground-truth images live in pinned host memory, as the reference's
+    OffloadSceneDataset keeps them (utils/camera_utils.py:75-126), and are uploaded per batch."""
+    from clm_gs_amd.host import pinned_empty
+    for c in cams:
+        if getattr(c, "image_host", None) is None and c.original_image is not None:
+            h = pinned_empty(tuple(c.original_image.shape), dtype=torch.uint8)
+            h.copy_(c.original_image)
+            c.image_host, c.original_image = h, None
+
+
+def upload_gt(batch, stream):
+    """train.py:310-312: the batch's GT images go to the GPU (here: asynchronously on the side stream)."""
+    cur = torch.cuda.current_stream()
+    with torch.cuda.stream(stream):
+        for c in batch:
+            c.original_image = c.image_host.to("cuda", non_blocking=True)
+    cur.wait_stream(stream)
+
+
+def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
+    """Second leg: the SAME workload with sh_residency="host" (SH rows, their gradients and Adam state in
+    pinned host memory; deferred host row optimizer; staging rows moved with hipMemcpyAsync on the side
+    stream) -> img/s and peak GPU bytes of the offloading configuration of the metric."""
+    import gc
+
+    from clm_gs_amd import _lib, utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+    from clm_gs_amd.synthetic import synth_gaussians
+    n_b = a.host_warmup + a.host_steps
+    cams = cams[:n_b * bsz]
+    gt_to_pinned_host(cams)
+    gc.collect()
+    torch.cuda.empty_cache()
+    args = utils.default_args(bsz=bsz, sh_residency="host")
+    args.clm_offload = True
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    scene = synth_gaussians(N, seed=0, device="cuda")
+    g = GaussianModelCLMOffload(3)
+    g.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"],
+                          spatial_lr_scale=lr_extent)
+    del scene
+    g.active_sh_degree = 3
+    g.training_setup(args)
+    gc.collect()
+    torch.cuda.empty_cache()
+    comm = torch.cuda.Stream()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    n_threads = _lib.lib().clmgs_host_pool_start(0)
+
+    class _Scene:
+        cameras_extent = extent
+    it = [1]
+    losses_all = []
+
+    def step(b):
+        batch = cams[b * bsz:(b + 1) * bsz]
+        upload_gt(batch, comm)
+        utils.set_cur_iter(it[0])
+        g.update_learning_rate(it[0])
+        ls, _, _ = clm_offload_train_one_batch(g, _Scene, batch, g.parameters_grad_buffer, None, None, comm, gen)
+        for c in batch:
+            c.original_image = None
+        it[0] += bsz
+        return ls
+    for b in range(a.host_warmup):
+        losses_all += list(step(b))
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    _lib.STATS.setdefault("touched_rows", []).clear()
+    _lib.HOST_REGIONS = {}
+    t0 = time.perf_counter()
+    for b in range(a.host_warmup, n_b):
+        losses_all += list(step(b))
+    torch.cuda.synchronize()
+    if g._host_grads_event is not None:
+        g._host_grads_event.synchronize()
+    dt = time.perf_counter() - t0
+    regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
+    peak = torch.cuda.max_memory_allocated()
+    tr = _lib.STATS.get("touched_rows", [])
+    T = sum(tr) / max(1, len(tr))
+    link_bytes = 2 * 192.0 * T + 4.0 * T + bsz * 3.0 * H * W  # rows down + gradient rows up + row list + GT images
+    vals = [float(x) for x in losses_all]
+    k2 = min(2 * bsz, max(bsz, len(vals) // 2))
+    out = {"value": round(a.host_steps * bsz / dt, 3), "unit": "img/s", "ms_per_step": round(dt / a.host_steps * 1e3, 2),
+           "steps": a.host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
+           "pinned_host_bytes": int(4 * g.parameters_buffer.shape[0] * 192),
+           "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
+           "host_ms_per_step": {k: round(v / a.host_steps * 1e3, 2) for k, v in regions.items()},
+           "link": {"bytes_per_batch": round(link_bytes, 1), "achieved_GBps": round(link_bytes * a.host_steps / dt / 1e9, 2),
+                    "peak_GBps": 57.0, "note": "peak = hipMemcpyAsync pinned<->HBM measured on this node type, EITHER direction or "
+                    "both together (profiles/r02_probe_host_link.json); every touched SH row crosses once per direction per batch"},
+           "loss_first": round(sum(vals[:k2]) / k2, 6), "loss_last": round(sum(vals[-k2:]) / k2, 6),
+           "gt_images": "pinned host, uploaded per batch (train.py:310-312)"}
+    del g
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,7 +319,7 @@ def main():
         gaussians = GaussianModelNoOffload(3)
     gaussians.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"],
                                   scene["opacity"], spatial_lr_scale=scene["lr_extent"])
-    extent = scene["extent"]
+    extent, lr_extent = scene["extent"], scene["lr_extent"]
     del scene
     gaussians.active_sh_degree = 3
     gaussians.training_setup(args)
@@ -226,8 +332,15 @@ def main():
 
     state = {"iteration": 1}
 
+    host_main = a.strategy == "clm_offload" and a.residency == "host"
+    if host_main:
+        gt_to_pinned_host(cams)
+        torch.cuda.empty_cache()
+
     def step(batch_idx):
         batch = cams[batch_idx * bsz:(batch_idx + 1) * bsz]
+        if host_main:
+            upload_gt(batch, comm_stream)
         utils.set_cur_iter(state["iteration"])
         gaussians.update_learning_rate(state["iteration"])
         if a.strategy == "clm_offload":
@@ -246,6 +359,9 @@ def main():
             gaussians.optimizer.zero_grad(set_to_none=True)
             sparsity = None
         state["iteration"] += bsz * world
+        if host_main:
+            for c in batch:
+                c.original_image = None
         return losses, sparsity
 
     grouped = world > 1 or under_torchrun
@@ -457,6 +573,13 @@ def main():
         except Exception as e:  # the baseline is reporting, never the product path
             out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
+    if (not a.no_host_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+            and a.config in ("rubble28m", "rubble10m", "small")):
+        try:
+            del gaussians
+            out["host_resident"] = host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
+        except Exception as e:  # reported, never fatal for the headline
+            out["host_resident"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
     sys.stdout.flush()
     if not train_ok:

@@ -41,8 +41,8 @@ SIGNATURES = {
     "clmgs_rasterize_fwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_rasterize_partials_bytes": (_sz, [_i64]),
     "clmgs_rasterize_bwd": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "clmgs_preprocess_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "clmgs_preprocess_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "clmgs_preprocess_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_preprocess_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "clmgs_ssim_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_ssim_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "clmgs_loss_slots": (_i, []),
@@ -59,6 +59,9 @@ SIGNATURES = {
     "clmgs_adam_small_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f]),
     "clmgs_adam_catch_up": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _d, _d, _i, _i, _i]),
     "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i, _vp, _i]),
+    "clmgs_host_pool_start": (_i, [_i]),
+    "clmgs_memcpy_async": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "clmgs_host_rows_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _i, _f, _i, _vp, _i]),
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_knn3_mean_dist2": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
@@ -104,7 +107,7 @@ class _Namespace:
 
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
-              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_tsp_tour",
+              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters"}
 
 

@@ -8,8 +8,14 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -28,15 +34,50 @@ void set_error(const char* fmt, ...) {
 extern "C" int clmgs_version(void) { return 100; }
 extern "C" const char* clmgs_last_error(void) { return clmgs::g_err; }
 
+// Number of NUMA nodes with memory (directories /sys/devices/system/node/nodeK).
+static int numa_nodes() {
+  int n = 0;
+  char path[64];
+  for (; n < 64; ++n) {
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d", n);
+    if (access(path, F_OK) != 0) break;
+  }
+  return n > 0 ? n : 1;
+}
+
 extern "C" void* clmgs_pinned_alloc(size_t bytes) {
   void* p = nullptr;
-  // mapped + portable: kernels may dereference it directly (zero-copy rows)
-  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable);
+  // mapped + portable: kernels may dereference it directly (zero-copy rows).  The row tables of the
+  // host-resident mode are walked by threads on every socket, so large allocations are interleaved
+  // over the NUMA nodes (MPOL_INTERLEAVE for the duration of the call, hipHostMallocNumaUser makes
+  // the runtime honour it): one socket's memory channels would otherwise bound the host optimizer.
+  const int nodes = numa_nodes();
+  const bool interleave = nodes > 1 && bytes >= ((size_t)64 << 20) && !getenv("CLMGS_PINNED_NO_INTERLEAVE");
+  unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
+  if (interleave) {
+    unsigned long mask = nodes >= 64 ? ~0ul : ((1ul << nodes) - 1ul);
+    if (syscall(SYS_set_mempolicy, 3 /* MPOL_INTERLEAVE */, &mask, (unsigned long)(sizeof(mask) * 8)) == 0)
+      flags |= hipHostMallocNumaUser;
+  }
+  hipError_t e = hipHostMalloc(&p, bytes, flags);
+  if (interleave) syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
   if (e != hipSuccess) {
     clmgs::set_error("hipHostMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
     return nullptr;
   }
   return p;
+}
+
+// hipMemcpyAsync between pinned host memory and HBM on `stream` (the side stream of the host-resident
+// mode): the copy runs on an SDMA engine and takes no compute unit away from the rendering kernels.
+// kind: 1 = host -> device, 2 = device -> host.
+extern "C" int clmgs_memcpy_async(void* stream, void* dst, const void* src, size_t bytes, int kind) {
+  if (bytes == 0) return 0;
+  if (!dst || !src || (kind != 1 && kind != 2)) { clmgs::set_error("clmgs_memcpy_async: invalid argument"); return CLMGS_EINVAL; }
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) { clmgs::set_error("hipMemcpyAsync -> %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }
 
 extern "C" int clmgs_pinned_free(void* p) {
@@ -100,6 +141,178 @@ extern "C" int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, cons
     if (lo < hi) th.emplace_back(work, lo, hi);
   }
   for (auto& t : th) t.join();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent host worker pool (the host-resident mode calls into it several times per batch; a
+// fresh std::thread pool per call cost more than the work at 64+ threads).
+namespace clmgs {
+class HostPool {
+ public:
+  explicit HostPool(int n) : stop_(false), gen_(0), pending_(0) {
+    for (int t = 0; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> l(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int size() const { return (int)workers_.size(); }
+  // Runs fn(begin, end) over [0, n) in dynamic chunks on all workers; returns when done.
+  void parallel_for(int64_t n, int64_t chunk, const std::function<void(int64_t, int64_t)>& fn) {
+    if (n <= 0) return;
+    std::unique_lock<std::mutex> l(mu_);
+    fn_ = &fn; n_ = n; chunk_ = chunk; next_.store(0);
+    pending_ = (int)workers_.size();
+    ++gen_;
+    cv_.notify_all();
+    done_cv_.wait(l, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop(int) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int64_t, int64_t)>* fn;
+      int64_t n, chunk;
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        fn = fn_; n = n_; chunk = chunk_;
+      }
+      if (fn) {
+        for (;;) {
+          const int64_t b = next_.fetch_add(chunk);
+          if (b >= n) break;
+          (*fn)(b, std::min(n, b + chunk));
+        }
+      }
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  bool stop_;
+  uint64_t gen_;
+  int pending_;
+  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+  int64_t n_ = 0, chunk_ = 1;
+  std::atomic<int64_t> next_{0};
+};
+static HostPool* g_pool = nullptr;
+static std::mutex g_pool_mu;   // one job at a time (the pool has one job slot)
+}  // namespace clmgs
+
+// Starts (or resizes) the pool; n_threads <= 0: one thread per two hardware threads (the row update
+// is memory bound; SMT siblings only add contention).  Returns the pool size.
+extern "C" int clmgs_host_pool_start(int n_threads) {
+  std::lock_guard<std::mutex> l(clmgs::g_pool_mu);
+  if (n_threads <= 0) {
+    const char* e = getenv("CLMGS_HOST_THREADS");
+    n_threads = e ? atoi(e) : (int)std::max(1u, std::thread::hardware_concurrency() / 2);
+  }
+  if (clmgs::g_pool && clmgs::g_pool->size() != n_threads) { delete clmgs::g_pool; clmgs::g_pool = nullptr; }
+  if (!clmgs::g_pool) clmgs::g_pool = new clmgs::HostPool(n_threads);
+  return clmgs::g_pool->size();
+}
+
+// Deferred row optimizer of the host-resident mode (SH rows + Adam state in pinned host memory).
+// Per row r two stamps: last_step[r] = optimizer step p/m/v are current as of, g_step[r] = step whose
+// gradient is waiting in g[r] (0 = none).  For every listed row this call
+//   1. replays the zero-gradient Adam steps last_step+1 .. g_step-1, applies Adam step g_step with
+//      g[r] * grad_scale, then replays g_step+1 .. to_step (all of it in registers: the row's p / m / v
+//      are read once and written once whatever the number of steps -- the dense reference optimizer
+//      streams all N rows every batch instead, clm_offload/engine.py:316-328);
+//   2. sets last_step[r] = to_step and g_step[r] = next_g_step (the step of the batch about to render
+//      the row, whose gradient will land in g[r]; 0 for a flush);
+//   3. copies the up-to-date parameter row into stage[k] (contiguous pinned staging buffer that a
+//      hipMemcpyAsync then moves to the GPU), unless stage == NULL.
+// sparse != 0 (--sparse_adam): only steps that carry a gradient exist for a row, nothing is replayed.
+// Same per-element operations and order as the eager update (clmgs_host_adam_rows) would have applied.
+extern "C" int clmgs_host_rows_prepare(float* p, const float* g, float* m, float* v, int32_t* last_step,
+                                       int32_t* g_step, const int32_t* rows, int64_t n_rows, int cols,
+                                       const float* col_lr, double beta1d, double beta2d, double epsd,
+                                       int to_step, int next_g_step, int bias_correction,
+                                       float grad_scale, int max_replay, float* stage, int sparse) {
+  if (n_rows < 0 || cols <= 0 || cols > 64 || to_step < 0 || max_replay < 1 ||
+      (n_rows > 0 && !(p && g && m && v && last_step && g_step && col_lr))) {
+    clmgs::set_error("clmgs_host_rows_prepare: invalid argument");
+    return CLMGS_EINVAL;
+  }
+  if (n_rows == 0) return 0;
+  clmgs_host_pool_start(clmgs::g_pool ? clmgs::g_pool->size() : 0);
+  const float beta1 = (float)beta1d, beta2 = (float)beta2d, eps = (float)epsd;
+  const float ob1 = (float)(1.0 - beta1d), ob2 = (float)(1.0 - beta2d);
+  // per-step scalars for steps 1 .. to_step (float, the same values the per-call variant computes)
+  std::vector<float> inv_bc1(to_step + 2, 1.f), inv_sqrt_bc2(to_step + 2, 1.f);
+  if (bias_correction)
+    for (int s = 1; s <= to_step + 1; ++s) {
+      inv_bc1[s] = (float)(1.0 / (1.0 - pow(beta1d, (double)s)));
+      inv_sqrt_bc2[s] = (float)(1.0 / sqrt(1.0 - pow(beta2d, (double)s)));
+    }
+  auto work = [&](int64_t lo, int64_t hi) {
+    float pp[64], mm[64], vv[64];
+    for (int64_t k = lo; k < hi; ++k) {
+      const int64_t r = rows ? (int64_t)rows[k] : k;
+      float* pr = p + r * cols;
+      int cur = last_step[r];
+      const int gs = g_step[r];
+      const bool pending = gs > cur && gs <= to_step;
+      if (cur < to_step || pending) {
+        float* mr = m + r * cols;
+        float* vr = v + r * cols;
+        bool any_state = pending;
+        for (int c = 0; c < cols; ++c) { mm[c] = mr[c]; vv[c] = vr[c]; any_state |= (mm[c] != 0.f) | (vv[c] != 0.f); }
+        if (any_state) {  // all-zero moments and no gradient: every step is the identity
+          for (int c = 0; c < cols; ++c) pp[c] = pr[c];
+          auto replay = [&](int from, int to) {  // zero-gradient steps from+1 .. to
+            int n = to - from;
+            if (n <= 0 || sparse) return;  // sparse Adam: rows without a gradient are not stepped at all
+            const int exact = std::min(n, max_replay);
+            for (int j = 1; j <= exact; ++j) {
+              const float a = inv_bc1[from + j], b = inv_sqrt_bc2[from + j];
+              for (int c = 0; c < cols; ++c) {
+                mm[c] *= beta1;
+                vv[c] *= beta2;
+                pp[c] -= (col_lr[c] * a) * (mm[c] / (sqrtf(vv[c]) * b + eps));
+              }
+            }
+            if (n > exact) {  // the moments have decayed below float resolution of p: decay only
+              const float f1 = powf(beta1, (float)(n - exact)), f2 = powf(beta2, (float)(n - exact));
+              for (int c = 0; c < cols; ++c) { mm[c] *= f1; vv[c] *= f2; }
+            }
+          };
+          if (pending) {
+            replay(cur, gs - 1);
+            const float* gr = g + r * cols;
+            const float a = inv_bc1[gs], b = inv_sqrt_bc2[gs];
+            for (int c = 0; c < cols; ++c) {
+              const float gg = gr[c] * grad_scale;
+              mm[c] = beta1 * mm[c] + ob1 * gg;
+              vv[c] = beta2 * vv[c] + ob2 * gg * gg;
+              pp[c] -= (col_lr[c] * a) * (mm[c] / (sqrtf(vv[c]) * b + eps));
+            }
+            cur = gs;
+          }
+          replay(cur, to_step);
+          for (int c = 0; c < cols; ++c) { pr[c] = pp[c]; mr[c] = mm[c]; vr[c] = vv[c]; }
+        }
+      }
+      last_step[r] = to_step;
+      g_step[r] = next_g_step;
+      if (stage) memcpy(stage + k * cols, pr, sizeof(float) * cols);
+    }
+  };
+  std::lock_guard<std::mutex> l(clmgs::g_pool_mu);
+  clmgs::g_pool->parallel_for(n_rows, 2048, work);
   return 0;
 }
 

@@ -31,6 +31,8 @@ struct PreArgs {
   const float* rotation_raw;    // [N,4]
   const float* sh_rows;         // [N,48] indexed by row id, or [V,48] indexed by i (sh_by_filter=0)
   int sh_by_filter;
+  const int32_t* sh_index;      // != NULL: SH row of position i is sh_rows[sh_index[i]] (a staging table that
+                                // holds only the rows a batch touches: host-resident mode); sh_by_filter = 1
   int packed_small;             // 1: `xyz` is the [N,12] table xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad
   float viewmat[16];
   float K[9];
@@ -124,13 +126,16 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
   const int n_chunks = (V + PP_ROWS - 1) / PP_ROWS;
   const int t = threadIdx.x;
   int chunk = blockIdx.x;
-  int my_row = -1;
-  if (chunk < n_chunks && chunk * PP_ROWS + t < V)
+  int my_row = -1, my_sh = 0;
+  if (chunk < n_chunks && chunk * PP_ROWS + t < V) {
     my_row = a.filter ? (int)a.filter[chunk * PP_ROWS + t] : chunk * PP_ROWS + t;
+    my_sh = a.sh_index ? a.sh_index[chunk * PP_ROWS + t] : my_row;
+  }
   for (; chunk < n_chunks; chunk += gridDim.x) {
     const int base = chunk * PP_ROWS;
     const bool mine = my_row >= 0;
     const int64_t g = mine ? my_row : 0;
+    const int sh_id = mine ? my_sh : 0;  // row of the SH table (= g unless a staging index is given)
     const SmallRow sr = load_small<PK>(a, g);
     const float m[3] = {sr.m[0], sr.m[1], sr.m[2]};
     const float4 q4 = sr.q4;
@@ -141,7 +146,7 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
 #define CLMGS_X(j)                                                                                  \
   if constexpr (j < NF4) {                                                                          \
     CLMGS_ELEM(j)                                                                                   \
-    const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, r) : (int64_t)min(base + r, V - 1); \
+    const int64_t src = a.sh_by_filter ? (int64_t)__shfl(sh_id, r) : (int64_t)min(base + r, V - 1); \
     st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
   }
       { CLMGS_LAUNDER_LANE
@@ -152,7 +157,7 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
     {  // row id of this wave's next chunk
       const int ni = (chunk + (int)gridDim.x) * PP_ROWS + t;
       my_row = -1;
-      if (ni < V) my_row = a.filter ? (int)a.filter[ni] : ni;
+      if (ni < V) { my_row = a.filter ? (int)a.filter[ni] : ni; my_sh = a.sh_index ? a.sh_index[ni] : my_row; }
     }
     Proj p;
     p.radius = 0; p.mx = p.my = p.depth = p.ca = p.cb = p.cc = 0.f;
@@ -183,7 +188,7 @@ preprocess_fwd_kernel(int V, PreArgs a, int32_t* __restrict__ radii, float* __re
         for (int j = 0; j < NF4; ++j) {
           const int e = t + PP_ROWS * j, r = e / NF4, k = e - r * NF4;
           const int rr = ((live >> r) & 1ull) ? r : first;  // dead rows re-read a live one (cache hit)
-          const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);
+          const int64_t src = a.sh_by_filter ? (int64_t)__shfl(sh_id, rr) : (int64_t)(base + rr);
           *reinterpret_cast<float4*>(lds + r * PP_PITCH + 4 * k) =
               *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);
         }
@@ -251,12 +256,13 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
   const int n_chunks = (V + PP_ROWS - 1) / PP_ROWS;
   const int t = threadIdx.x;
   int chunk = blockIdx.x;
-  int my_row = -1, my_radius = 0;
+  int my_row = -1, my_radius = 0, my_sh = 0;
   int64_t my_s0 = 0;
   int my_cnt = 0;
   if (chunk < n_chunks && chunk * PP_ROWS + t < V) {
     const int i = chunk * PP_ROWS + t;
     my_row = a.filter ? (int)a.filter[i] : i;
+    my_sh = a.sh_index ? a.sh_index[i] : my_row;
     my_radius = radii[i];
     if (o.partials) { my_s0 = i ? o.row_cum[i - 1] : 0; my_cnt = (int)(o.row_cum[i] - my_s0); }
   }
@@ -272,6 +278,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int first = live ? (int)__builtin_ctzll(live) : 0;
     // dead lanes redirect every gather to the chunk's first live row: no branches, cache hits
     const int64_t g = mine ? my_row : 0;
+    const int sh_id = mine ? my_sh : 0;
     const int64_t gl = vis ? g : (int64_t)__shfl((int)g, first);
     const int i = mine ? base + t : base;
     // ---- everything this lane needs from HBM, requested at once
@@ -326,7 +333,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
   if constexpr (j < NF4) {                                                                          \
     CLMGS_ELEM(j)                                                                                   \
     const int rr = ((live >> r) & 1ull) ? r : first;                                                \
-    const int64_t src = a.sh_by_filter ? (int64_t)__shfl((int)g, rr) : (int64_t)(base + rr);        \
+    const int64_t src = a.sh_by_filter ? (int64_t)__shfl(sh_id, rr) : (int64_t)(base + rr);         \
     st##j = *reinterpret_cast<const float4*>(a.sh_rows + src * 48 + 4 * k);                         \
   }
     {
@@ -334,6 +341,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       my_row = -1; my_radius = 0; my_s0 = 0; my_cnt = 0;
       if (ni < V) {
         my_row = a.filter ? (int)a.filter[ni] : ni; my_radius = radii[ni];
+        my_sh = a.sh_index ? a.sh_index[ni] : my_row;
         if (o.partials) { my_s0 = ni ? o.row_cum[ni - 1] : 0; my_cnt = (int)(o.row_cum[ni] - my_s0); }
       }
     }
@@ -472,7 +480,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     wave_lds_sync();
     // launder the row id: the addresses below are RE-computed here instead of 12 64-bit
     // pointers staying live across the SH VJP
-    int g_l = (int)g;
+    int g_l = sh_id;
     asm volatile("" : "+v"(g_l));
 #define CLMGS_X(j)                                                                                  \
   if constexpr (j < NF4) {                                                                          \
@@ -502,7 +510,7 @@ static void fill_args(PreArgs& a, const int64_t* filter, const float* xyz, const
                       int width, int height, int degree, float eps2d, float near_plane,
                       float far_plane, float radius_clip) {
   a.filter = filter; a.xyz = xyz; a.opacity_raw = opacity_raw; a.scaling_raw = scaling_raw;
-  a.rotation_raw = rotation_raw; a.sh_rows = sh_rows; a.sh_by_filter = sh_by_filter;
+  a.rotation_raw = rotation_raw; a.sh_rows = sh_rows; a.sh_by_filter = sh_by_filter; a.sh_index = nullptr;
   a.packed_small = (!opacity_raw && !scaling_raw && !rotation_raw) ? 1 : 0;
   for (int i = 0; i < 16; ++i) a.viewmat[i] = viewmat[i];
   for (int i = 0; i < 9; ++i) a.K[i] = K[i];
@@ -519,7 +527,7 @@ extern "C" int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, 
                                     int height, int degree, float eps2d, float near_plane,
                                     float far_plane, float radius_clip, int32_t* radii,
                                     float* means2d, float* depths, float* conics, float* colors,
-                                    float* opacities, void* packed) {
+                                    float* opacities, void* packed, const int32_t* sh_index) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && means2d &&
@@ -531,6 +539,8 @@ extern "C" int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, 
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, near_plane, far_plane,
             radius_clip);
+  CLMGS_CHECK_ARG(!sh_index || sh_by_filter);
+  a.sh_index = sh_index;
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_FWD(D, O)                                                                        \
@@ -566,7 +576,8 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     float* g_scaling, float* g_rotation, float* g_sh_rows,
                                     float* max_radii2D, float* grad_accum, float* denom,
                                     float* v_means2d_out, int stats_only_visible,
-                                    const void* partials, const int64_t* row_cum) {
+                                    const void* partials, const int64_t* row_cum,
+                                    const int32_t* sh_index) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && g_xyz && g_sh_rows);
@@ -585,6 +596,8 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   PreArgs a;
   fill_args(a, filter, xyz, opacity_raw, scaling_raw, rotation_raw, sh_rows, sh_by_filter,
             viewmat_host, K_host, campos_host, width, height, degree, eps2d, 0.f, 0.f, 0.f);
+  CLMGS_CHECK_ARG(!sh_index || sh_by_filter);
+  a.sh_index = sh_index;
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
              pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible, (const float4*)partials, row_cum};
   const size_t lds = 0;

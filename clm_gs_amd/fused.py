@@ -47,7 +47,7 @@ class _CameraPass:
     __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
                  "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids",
                  "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux", "loss_partials",
-                 "lambda_dssim", "gt_u8", "background", "isect")
+                 "lambda_dssim", "gt_u8", "background", "isect", "sh_index")
 
 
 def _sptr(torch_stream):
@@ -55,7 +55,7 @@ def _sptr(torch_stream):
 
 
 def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
-                   lambda_dssim=0.2, small_packed=None, streams=None):
+                   lambda_dssim=0.2, small_packed=None, streams=None, sh_index=None):
     """Projection + binning (stream `front`), alpha-blend forward (stream `raster`), loss forward +
     backward (stream `mem`) of one camera; returns the _CameraPass for camera_backward.  The three
     streams may be one and the same; distinct streams are chained by events, so the caller can put
@@ -64,11 +64,11 @@ def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgr
     = camera_front (nothing blocks) + camera_forward_finish (waits for the intersection count)."""
     return camera_forward_finish(gaussians, camera_front(
         gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8, lambda_dssim,
-        small_packed, streams))
+        small_packed, streams, sh_index))
 
 
 def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
-                 lambda_dssim=0.2, small_packed=None, streams=None):
+                 lambda_dssim=0.2, small_packed=None, streams=None, sh_index=None):
     """Projection and the first half of the binning (depth order, per-row tile counts, asynchronous
     readback of the intersection count) on stream `front`; no host wait."""
     L = _lib.lib()
@@ -84,6 +84,7 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
     vm, K, campos = p.cam
     deg = p.deg = int(gaussians.active_sh_degree)
     p.sh_rows, p.sh_by_filter, p.small_packed = sh_rows, sh_by_filter, small_packed
+    p.sh_index = sh_index  # int32[V]: SH row of position i in a staging table (host-resident mode)
     p.gt_u8, p.lambda_dssim, p.background = gt_u8, float(lambda_dssim), background
     filt = p.filt = this_filter.contiguous() if this_filter is not None else None  # None: all rows
     if small_packed is not None:
@@ -106,7 +107,8 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
             _sptr(s_front), V, dptr(filt, torch.int64, True), *small_in,
             dptr(sh_rows, F32, allow_host=True), int(sh_by_filter), _np(vm), _np(K), _np(campos), W, H, deg,
             0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
-            dptr(depths), None, None, None, dptr(packed)))  # conics/colours/opacities live in `packed`
+            dptr(depths), None, None, None, dptr(packed),  # conics/colours/opacities live in `packed`
+            dptr(sh_index, I32, True)))
         p.isect = isect2_begin(means2d, radii, depths, TILE, tw, th, want_slots=True,
                                packed=packed if getattr(args, "exact_tile_cull", True) else None)
         p.aux = p.aux + (means2d, depths)
@@ -227,7 +229,8 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
             _sptr(s_mem), V, dptr(p.filt, torch.int64, True), *p.small_in, dptr(p.sh_rows, F32, allow_host=True),
             int(p.sh_by_filter), _np(vm), _np(K), _np(campos), W, H, p.deg, 0.3, dptr(p.radii),
             None, *small_out, dptr(g_sh_rows, F32, allow_host=True),
-            *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum)))
+            *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum),
+            dptr(p.sh_index, I32, True)))
     p.aux = p.aux + (partials,)
     return p
 
@@ -235,7 +238,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
                      return_event=False, stats_only_visible=False, visibility_out=None,
-                     raster_stream=None, small_packed=None, small_grad=None, stats_delta=None):
+                     raster_stream=None, small_packed=None, small_grad=None, stats_delta=None, sh_index=None):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -252,7 +255,8 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     then gather one 48 B row per Gaussian and accumulate into one, instead of four pieces each."""
     cur = torch.cuda.current_stream()
     p = camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
-                       lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur))
+                       lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur),
+                       sh_index)
     camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
                     stats_only_visible, visibility_out, accumulate_after)
     loss = camera_loss(p)  # on `cur`, which the loss kernels ran on

@@ -247,7 +247,7 @@ class BaseGaussianModel(ABC):
         """Everything needed to resume training bit-for-bit in exact arithmetic: parameters,
         optimizer moments and step counters, densification statistics (scope row f3; the
         reference's capture/restore start with `assert False`, no_offload/gaussian_model.py:38-56)."""
-        if getattr(self, "lazy_rows", False):
+        if hasattr(self, "flush_lazy_rows"):  # deferred row optimizers (HBM lazy rows / host rows)
             self.flush_lazy_rows()
         opt = {}
         for g in self.optimizer.param_groups:
@@ -294,6 +294,9 @@ class BaseGaussianModel(ABC):
             row_adam.global_step = state["row_global_step"]
             if getattr(self, "lazy_rows", False):
                 self._row_last_step.fill_(row_adam.global_step)
+            if getattr(self, "deferred_host_rows", False):
+                self._host_last_step.fill_(row_adam.global_step)
+                self._host_g_step.zero_()
         self.xyz_gradient_accum = state["xyz_gradient_accum"].cuda()
         self.denom = state["denom"].cuda()
         self.max_radii2D = state["max_radii2D"].cuda()

@@ -17,6 +17,7 @@ Two residency modes for the [N,48] SH rows and their optimizer state (see gaussi
   (engine.py:568-571), TSP camera order, row groups by last use, pinned signal flags and a
   host Adam thread overlapped with rendering.
 """
+import ctypes
 import math
 import threading
 
@@ -486,116 +487,132 @@ def _bit_of(bitmap, ids, bit):
     return ((bitmap[ids].to(torch.int64) >> bit) & 1).to(torch.bool)
 
 
+_HOST_CHUNK_ROWS = 262144  # staging granularity: 48 MB of parameter rows per hipMemcpyAsync
+
+
+def _host_buffers(gaussians, T, dev):
+    """Per-batch buffers of the host-resident mode, kept between batches (bucketed capacity):
+    pinned row list + pinned staging rows on the host, staging parameter / gradient rows and the
+    row -> slot table on the GPU."""
+    from ...gsplat import bucket_size
+    hb = getattr(gaussians, "_host_bufs", None)
+    cap = bucket_size(max(T, 1))
+    N = gaussians._xyz.shape[0]
+    if hb is None or hb["cap"] < T or hb["N"] != N:
+        hb = gaussians._host_bufs = dict(
+            cap=cap, N=N,
+            rows_h=pinned_empty((cap,), dtype=torch.int32),
+            stage_h=pinned_empty((cap, 48)),
+            sh_stage=torch.empty((cap, 48), device=dev),
+            g_stage=torch.empty((cap, 48), device=dev),
+            slot_of=torch.zeros((N,), dtype=torch.int32, device=dev))
+    return hb
+
+
 def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
                           pipe_args, comm_stream, perm_generator, args):
-    iteration = utils.get_cur_iter()
+    """Host-resident SH rows + Adam state (sh_residency="host"): what the reference's retention pipeline
+    and cpu-adam thread do (clm_offload/engine.py:494-508, 622-641, 789-825, 301-335), re-shaped around
+    what this machine's host link rewards.
+
+    * Every row the batch touches crosses the link ONCE per direction (the minimum the H / D / G retention
+      sets aim at, reached without camera re-ordering): the union of the batch's filters is staged.
+    * Host -> GPU: the host thread pool brings the touched rows up to date (DEFERRED row optimizer:
+      the gradient a row received in an earlier batch is applied, and the zero-gradient Adam steps it has
+      skipped since are replayed, only now -- one read and one write of p / m / v per touched row and
+      batch, where the dense reference optimizer streams all N rows every batch) and copies them into a
+      contiguous pinned staging buffer, chunk by chunk; each finished chunk goes to the GPU with a
+      hipMemcpyAsync on the side stream (SDMA engine: no compute unit is taken from the renderer) while
+      the pool works on the next chunk.
+    * The cameras render from / accumulate into GPU staging tables ([T,48] parameters and gradients, row
+      -> slot through an index the fused front end follows).
+    * GPU -> host: one zero-copy scatter STORE of the gradient rows into the pinned gradient table (plain
+      stores, no read-modify-write over the link, no host pass); they wait there, stamped with this
+      batch's step, until the row is needed again.
+    """
+    from ...fused import train_one_camera
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
     dev = gaussians._xyz.device
     assert not dp.active(), "camera-DP is built for sh_residency='hbm' (every rank holds a full replica)"
-    with torch.no_grad():
-        filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
-                                          gaussians.get_scaling, gaussians.get_rotation)
-    (finish_indices_filters, batched_cameras, filters, sparsity, ordered_cams, cnt_h, cnt_d, cnt_g,
-     visibility_mask, bitmap) = order_calculation(filters, batched_cameras, N, bsz, perm_generator, args)
-
-    if not hasattr(gaussians, "signal_tensor_pinned") or gaussians.signal_tensor_pinned.numel() != bsz:
-        gaussians.signal_tensor_pinned = pinned_empty((bsz,), dtype=torch.int32)
-    gaussians.signal_tensor_pinned.zero_()
-    signal = gaussians.signal_tensor_pinned
-    torch.cuda.synchronize()
-
-    skip_opt = getattr(args, "debug_skip_optimizer", False)  # test hook, see _train_one_batch_hbm
-    worker = threading.Thread(target=cpuadam_thread, args=(
-        bsz, N, signal, finish_indices_filters, gaussians.optimizer.cpu_adam, gaussians._parameters,
-        parameters_grad_buffer[:N, :], iteration, args))
-    if not skip_opt:
-        worker.start()
-
-    _zero_small_grads(gaussians)
-    default_stream = torch.cuda.current_stream()
-    gH, gD = args.grid_size_H, args.grid_size_D
-    params_host = gaussians._parameters.data
-    grad_host = parameters_grad_buffer[:N, :]
-    keep_alive = []  # tensors touched by both streams live until the final synchronize
-    losses = []
-
-    with torch.cuda.stream(comm_stream), torch.no_grad():
-        shs = torch.empty((filters[0].shape[0], 48), device=dev)
-        send_shs2gpu_stream(shs, params_host, filters[0], gH, 256)
-        shs_grad = torch.zeros((filters[0].shape[0], 48), device=dev)
-        ready = torch.cuda.Event()
-        ready.record(comm_stream)
-        grad_ready = torch.cuda.Event()
-        grad_ready.record(comm_stream)
-    comm_stream.wait_stream(default_stream)
-
-    for i in range(bsz):
-        F = filters[i]
-        last = i == bsz - 1
-        nxt = None
-        if not last:
-            with torch.cuda.stream(comm_stream), torch.no_grad():
-                Fn = filters[i + 1]
-                # H = ~this & next, D = this & next, G = this & ~next  (engine.py:568-571);
-                # sizes are known, so nonzero_static never syncs
-                in_cur = _bit_of(bitmap, Fn, bsz - 1 - i)
-                d_pos_next = torch.nonzero_static(in_cur, size=cnt_d[i]).flatten()
-                h_pos_next = torch.nonzero_static(~in_cur, size=cnt_h[i]).flatten()
-                d_ids = Fn[d_pos_next]
-                d_pos_cur = torch.searchsorted(F, d_ids)
-                h_ids = Fn[h_pos_next].to(torch.int32)
-                in_next = _bit_of(bitmap, F, bsz - 2 - i)
-                g_pos_cur = torch.nonzero_static(~in_next, size=cnt_g[i]).flatten()
-                g_ids = F[g_pos_cur].to(torch.int32)
-                d_pos_next32, d_pos_cur32 = d_pos_next.to(torch.int32), d_pos_cur.to(torch.int32)
-                shs_next = torch.empty((Fn.shape[0], 48), device=dev)
-                send_shs2gpu_stream_retention(shs_next, params_host, shs, h_ids, d_pos_cur32,
-                                              h_pos_next.to(torch.int32), d_pos_next32, gH, 256,
-                                              gD, 256)
-                next_ready = torch.cuda.Event()
-                next_ready.record(comm_stream)
-                nxt = (shs_next, next_ready, g_ids, g_pos_cur.to(torch.int32), d_pos_next32, d_pos_cur32)
-                keep_alive += [in_cur, d_ids, h_ids, in_next]
-
-        default_stream.wait_event(ready)
-        loss = _render_and_backward(gaussians, scene, batched_cameras[i], background, pipe_args, F,
-                                    shs, shs_grad,
-                                    before_sh_backward=lambda: default_stream.wait_event(grad_ready))
-        losses.append(loss)
-        done = torch.cuda.Event()
-        done.record(default_stream)
-
-        with torch.cuda.stream(comm_stream), torch.no_grad():
-            comm_stream.wait_event(done)
-            if not last:
-                shs_next, next_ready, g_ids, g_pos_cur32, d_pos_next32, d_pos_cur32 = nxt
-                shs_grad_next = torch.zeros_like(shs_next)
-                send_shs2cpu_grad_buffer_stream_retention(
-                    shs_grad, grad_host, shs_grad_next, g_ids, d_pos_next32, g_pos_cur32,
-                    d_pos_cur32, True, gH, 256, gD, 256)
-                grad_ready = torch.cuda.Event()
-                grad_ready.record(comm_stream)
-            else:
-                send_shs2cpu_grad_buffer_stream(shs_grad, grad_host, F, True, gH, 256)
-            clm_kernels.set_signal(signal, i, 1)
-        keep_alive += [shs, shs_grad]
-        if not last:
-            keep_alive += list(nxt[2:])
-            shs, ready, shs_grad = shs_next, next_ready, shs_grad_next
-
+    assert gaussians.deferred_host_rows
+    assert getattr(args, "fused_front_end", True), "the host-resident mode runs the fused front end"
     assert args.lr_scale_mode == "sqrt", "Overlap CPUAdam only supports sqrt lr scaling"
     assert not args.stop_update_param, "Overlap CPUAdam does not support stop_update_param"
+    L = _lib.lib()
+    skip_opt = getattr(args, "debug_skip_optimizer", False)  # test hook, see _train_one_batch_hbm
+    default_stream = torch.cuda.current_stream()
+    with torch.no_grad():
+        with _lib.host_region("select_filters"):
+            filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
+                                                   gaussians._scaling.detach(), gaussians._rotation.detach())
+        T = int(touched_rows.shape[0])
+        _lib.STATS.setdefault("touched_rows", []).append(T)
+        sparsity = [len(f) / float(N) for f in filters]
+        ordered_cams = list(range(bsz))
+        hb = _host_buffers(gaussians, T, dev)
+        rows_h, stage_h = hb["rows_h"][:T], hb["stage_h"][:T]
+        sh_stage, g_stage, slot_of = hb["sh_stage"][:T], hb["g_stage"][:T], hb["slot_of"]
+        # row list to the host (asynchronous), row -> slot table, per-camera slot indices
+        rows32 = touched_rows.to(torch.int32)
+        check_rc = L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), T * 4, 2)
+        _lib.check(check_rc)
+        ev_rows = torch.cuda.Event()
+        ev_rows.record(default_stream)
+        slot_of[touched_rows] = torch.arange(T, dtype=torch.int32, device=dev)
+        sh_index = [slot_of[f] for f in filters]
+        prev = gaussians._host_grads_event
+        if prev is not None:  # the previous batch's scatter still reads g_stage
+            default_stream.wait_event(prev)
+        g_stage.zero_()
+        row_adam = gaussians.optimizer.cpu_adam
+        step = row_adam.global_step + 1
+        # ---- host -> GPU: prepare + stage + hipMemcpyAsync, chunk by chunk
+        with _lib.host_region("host_prepare"):
+            ev_rows.synchronize()
+            comm_stream.wait_stream(default_stream)
+            cs = ctypes.c_void_p(comm_stream.cuda_stream)
+            for c0 in range(0, T, _HOST_CHUNK_ROWS):
+                c1 = min(T, c0 + _HOST_CHUNK_ROWS)
+                gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
+                                            next_g_step=0 if skip_opt else step)
+                _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[c0:c1]), ctypes_ptr(stage_h[c0:c1]),
+                                                (c1 - c0) * 192, 1))
+            ev_h2d = torch.cuda.Event()
+            ev_h2d.record(comm_stream)
+        default_stream.wait_event(ev_h2d)
+        # ---- render: one camera after the other (the mode is bound by the host link, not by the GPU:
+        # the camera pipeline of the HBM mode would only add its per-camera buffers to the peak)
+        _zero_small_grads(gaussians)
+        losses = []
+        for i in range(bsz):
+            losses.append(train_one_camera(gaussians, batched_cameras[i], filters[i], sh_stage, 1, g_stage,
+                                           background, batched_cameras[i].original_image, sh_index=sh_index[i]))
+        # ---- GPU -> host: gradient rows, plain stores into the pinned table (side stream)
+        comm_stream.wait_stream(default_stream)
+        with torch.cuda.stream(comm_stream):
+            send_shs2cpu_grad_buffer_stream(g_stage, parameters_grad_buffer[:N, :], touched_rows, False)
+            ev_g = torch.cuda.Event()
+            ev_g.record(comm_stream)
+        gaussians._host_grads_event = ev_g
+        gaussians._host_keep = (rows32, sh_index, touched_rows, filters)  # until the streams are done with them
     if skip_opt:
         torch.cuda.synchronize()
-        del keep_alive
         return losses, ordered_cams, sparsity
+    visibility_mask = None
+    if args.sparse_adam:
+        visibility_mask = torch.zeros((N,), dtype=torch.bool, device=dev)
+        visibility_mask.index_fill_(0, touched_rows, True)
     _gpu_adam_step(gaussians, args, visibility_mask)
     gaussians.invalidate_small_packed()
-    worker.join()
-    torch.cuda.synchronize()
-    del keep_alive
+    row_adam.global_step = step
+    row_adam.state[gaussians._parameters]["step"] = step
     return losses, ordered_cams, sparsity
+
+
+def ctypes_ptr(t):
+    import ctypes as _c
+    return _c.c_void_p(t.data_ptr())
 
 
 def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_grad_buffer,
@@ -621,6 +638,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
         f = filters[0]
         if getattr(gaussians, "lazy_rows", False):
             gaussians.catch_up_rows(f.to(torch.int32))
+        if getattr(gaussians, "deferred_host_rows", False):  # host rows: apply what is waiting for them
+            gaussians.host_rows_prepare(f.to(torch.int32).cpu().contiguous(), None)
         xyz = gaussians._xyz.detach()[f]
         opa = gaussians.opacity_activation(gaussians._opacity.detach()[f])
         sca = gaussians.scaling_activation(gaussians._scaling.detach()[f])

@@ -101,6 +101,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self._row_last_step = None
         if (not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True):
             self._row_last_step = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        # host-resident rows: DEFERRED row optimizer (clmgs_host_rows_prepare).  Two host stamps per row:
+        # step the row is current as of, and step whose gradient waits in parameters_grad_buffer (0: none)
+        self._host_last_step = self._host_g_step = None
+        self._host_grads_event = None  # the last batch's gradient rows have landed in host memory
+        if self.sh_on_host:
+            self._host_last_step = pinned_empty((cap,), dtype=torch.int32).zero_()
+            self._host_g_step = pinned_empty((cap,), dtype=torch.int32).zero_()
 
     # ------------------------------------------- packed mirror of the small attributes
     def _small_tensors(self):
@@ -190,7 +197,46 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                       g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"])
 
     def flush_lazy_rows(self):
+        if self.deferred_host_rows:
+            self.host_rows_prepare(None, None)
+            return
         self.catch_up_rows(None)
+
+    # ---------------------------------------------------- deferred host row optimizer
+    @property
+    def deferred_host_rows(self):
+        return getattr(self, "_host_last_step", None) is not None
+
+    def host_rows_prepare(self, rows_host, stage_host, to_step=None, next_g_step=0, n_rows=None):
+        """Bring host rows (int32 pinned/CPU row list, None = all) up to `to_step` (default: the optimizer's
+        current step): waiting gradients are applied at their own step, skipped zero-gradient steps are
+        replayed; copies the current parameter rows into stage_host[k] when given.  Blocks until the rows
+        are done (host threads, GIL released)."""
+        import ctypes
+        from ... import _lib
+        assert self.deferred_host_rows
+        if self._host_grads_event is not None:  # the waiting gradients must have landed
+            self._host_grads_event.synchronize()
+            self._host_grads_event = None
+        opt = self.optimizer.cpu_adam
+        g = opt.param_groups[0]
+        p = self._parameters
+        st = opt.state[p]
+        n = p.shape[0]
+        to_step = opt.global_step if to_step is None else int(to_step)
+        col_lr = opt._col_lr(torch.device("cpu")).contiguous()
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        if rows_host is not None:
+            assert rows_host.dtype == torch.int32 and not rows_host.is_cuda and rows_host.is_contiguous()
+            n_rows = rows_host.numel() if n_rows is None else int(n_rows)
+        else:
+            n_rows = n
+        _lib.check(_lib.lib().clmgs_host_rows_prepare(
+            P(p.data), P(self.parameters_grad_buffer), P(st["exp_avg"]), P(st["exp_avg_sq"]),
+            P(self._host_last_step), P(self._host_g_step), P(rows_host), n_rows, p.shape[1], P(col_lr),
+            float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), to_step, int(next_g_step),
+            int(g["bias_correction"]), 1.0 / float(self.args.bsz), 256, P(stage_host),
+            int(bool(self.args.sparse_adam))))
 
     def _rebind_row_state(self, n):
         """Point the row optimizer at the [:n] views after append / prune."""
@@ -244,6 +290,15 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         n = self._parameters.shape[0]
         self.flush_lazy_rows()
         self._grow(n + k)
+        if self.deferred_host_rows:
+            cap2 = self.parameters_buffer.shape[0]
+            if self._host_last_step.shape[0] < cap2:
+                for attr in ("_host_last_step", "_host_g_step"):
+                    grown = pinned_empty((cap2,), dtype=torch.int32).zero_()
+                    grown[:n] = getattr(self, attr)[:n]
+                    setattr(self, attr, grown)
+            self._host_last_step[n:n + k] = self.optimizer.cpu_adam.global_step
+            self._host_g_step[n:n + k] = 0
         if self.lazy_rows:
             if self._row_last_step.shape[0] < self.parameters_buffer.shape[0]:
                 grown = torch.zeros((self.parameters_buffer.shape[0],), dtype=torch.int32, device="cuda")
@@ -270,6 +325,9 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self.flush_lazy_rows()  # afterwards every surviving row carries the same step stamp
         if self.lazy_rows:
             self._row_last_step[:m] = self.optimizer.cpu_adam.global_step
+        if self.deferred_host_rows:
+            self._host_last_step[:m] = self.optimizer.cpu_adam.global_step
+            self._host_g_step[:m] = 0
         keep_rows = keep.cpu() if self.sh_on_host else keep
         for attr in _ROW_BUFFERS:
             buf = getattr(self, attr)

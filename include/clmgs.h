@@ -179,14 +179,18 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * gradient outputs follow the same convention (g_opacity == g_scaling == g_rotation == NULL:
  * g_xyz is the packed [N,12] gradient table), and packed parameters go with packed gradients.
  * Statistics: grad_accum == denom == NULL with max_radii2D != NULL means max_radii2D is a 16 B-aligned
- * [N,4] table  max radius | grad accum | count | pad  (one row instead of three scattered floats). */
+ * [N,4] table  max radius | grad accum | count | pad  (one row instead of three scattered floats).
+ * sh_index[V] (i32, optional, with sh_by_filter = 1): position i reads SH row sh_rows[sh_index[i]] and
+ * accumulates into g_sh_rows[sh_index[i]] -- sh_rows is then a staging table holding only the rows a
+ * batch touches (host-resident mode: clm_offload/engine.py:494-508 moves rows host -> GPU per batch). */
 int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,
                          const float* viewmat_host, const float* K_host, const float* campos_host,
                          int width, int height, int degree, float eps2d, float near_plane,
                          float far_plane, float radius_clip, int32_t* radii, float* means2d,
-                         float* depths, float* conics, float* colors, float* opacities, void* packed);
+                         float* depths, float* conics, float* colors, float* opacities, void* packed,
+                         const int32_t* sh_index);
 int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,
@@ -195,7 +199,7 @@ int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float
                          const void* packed_grad, float* g_xyz, float* g_opacity, float* g_scaling,
                          float* g_rotation, float* g_sh_rows, float* max_radii2D, float* grad_accum,
                          float* denom, float* v_means2d_out, int stats_only_visible,
-                         const void* partials, const int64_t* row_cum);
+                         const void* partials, const int64_t* row_cum, const int32_t* sh_index);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
  * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes
@@ -291,6 +295,26 @@ int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, const int32_t* 
                          int64_t n_rows, int cols, const float* col_lr, double beta1,
                          double beta2, double eps, int step, int bias_correction, float grad_scale,
                          int zero_grad, const volatile int32_t* signal, int n_threads);
+
+/* Host-resident mode, this build's form of the cpu_adam worker (clm_offload/engine.py:301-335,
+ * optimizer.py:130-144): a persistent pool of host threads and a DEFERRED row optimizer.  Per row two
+ * int32 stamps: last_step (step p/m/v are current as of) and g_step (step whose gradient waits in g,
+ * 0 = none).  clmgs_host_rows_prepare brings the listed rows (rows == NULL: rows 0..n_rows-1) to
+ * `to_step` -- zero-gradient steps are replayed in registers, the waiting gradient is applied at its
+ * own step with grad_scale -- sets last_step = to_step, g_step = next_g_step, and copies each
+ * up-to-date parameter row into stage[k] (contiguous pinned staging for a hipMemcpyAsync; NULL to skip).
+ * sparse != 0 (sparse_adam): rows are stepped only when they carry a gradient, nothing is replayed.
+ * Arithmetic per element and step = clmgs_host_adam_rows'. */
+int clmgs_host_pool_start(int n_threads);
+/* hipMemcpyAsync of `bytes` between pinned host memory and HBM on `stream` (SDMA engine; kind 1 = host
+ * -> device, 2 = device -> host): how the host-resident mode moves its contiguous staging chunks
+ * (replaces clm_kernels.send_shs2gpu_stream's zero-copy gather, clm_offload/engine.py:499-505). */
+int clmgs_memcpy_async(void* stream, void* dst, const void* src, size_t bytes, int kind);
+int clmgs_host_rows_prepare(float* p, const float* g, float* m, float* v, int32_t* last_step,
+                            int32_t* g_step, const int32_t* rows, int64_t n_rows, int cols,
+                            const float* col_lr, double beta1, double beta2, double eps, int to_step,
+                            int next_g_step, int bias_correction, float grad_scale, int max_replay,
+                            float* stage, int sparse);
 
 /* ---- densification statistics  (clm_offload/gaussian_model.py:833-851;
  *      no_offload/gaussian_model.py:767-783; densification.py:59-147)

@@ -255,8 +255,7 @@ def test_clm_offload_three_batches_match_reference_engine(dev, fx, residency, fu
             assert abs(l.item() - ref[k]) < 5e-5, (b, k)
         it += bsz
     torch.cuda.synchronize()
-    if m.lazy_rows:
-        m.flush_lazy_rows()
+    m.flush_lazy_rows()
     tag = f"clm3.{residency}.{'fused' if fused else 'opbyop'}"
     init = {"xyz": _t(d0["xyz"]), "opacity": _t(d0["opacity"]), "scaling": _t(d0["scaling"]),
             "rotation": _t(d0["rotation"]), "parameters": _t(d0["shs48"])}
