@@ -20,6 +20,7 @@ Two residency modes for the [N,48] SH rows and their optimizer state (see gaussi
 import ctypes
 import math
 import threading
+import time
 
 import torch
 
@@ -513,22 +514,25 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                           pipe_args, comm_stream, perm_generator, args):
     """Host-resident SH rows + Adam state (sh_residency="host"): what the reference's retention pipeline
     and cpu-adam thread do (clm_offload/engine.py:494-508, 622-641, 789-825, 301-335), re-shaped around
-    what this machine's host link rewards.
+    what this machine's host link and host cores reward.
 
     * Every row the batch touches crosses the link ONCE per direction (the minimum the H / D / G retention
-      sets aim at, reached without camera re-ordering): the union of the batch's filters is staged.
-    * Host -> GPU: the host thread pool brings the touched rows up to date (DEFERRED row optimizer:
-      the gradient a row received in an earlier batch is applied, and the zero-gradient Adam steps it has
-      skipped since are replayed, only now -- one read and one write of p / m / v per touched row and
-      batch, where the dense reference optimizer streams all N rows every batch) and copies them into a
-      contiguous pinned staging buffer, chunk by chunk; each finished chunk goes to the GPU with a
-      hipMemcpyAsync on the side stream (SDMA engine: no compute unit is taken from the renderer) while
-      the pool works on the next chunk.
+      sets aim at, reached without camera re-ordering): the union of the batch's filters is staged, grouped
+      by the camera that uses a row FIRST (host -> GPU) and LAST (GPU -> host), so camera k renders as soon
+      as its own new rows have arrived while the rows only later cameras need are still being prepared,
+      and a row's gradient leaves right after the last camera that contributes to it.
+    * Host -> GPU: a feeder thread drives the host thread pool, which brings the touched rows up to date
+      (DEFERRED row optimizer: the gradient a row received in an earlier batch is applied, and the
+      zero-gradient Adam steps it has skipped since are replayed, only now -- one read and one write of
+      p / m / v per touched row and batch, where the dense reference optimizer streams all N rows every
+      batch) and copies them into a contiguous pinned staging buffer, chunk by chunk; each finished chunk
+      goes to the GPU with a hipMemcpyAsync on the side stream (SDMA engine: no compute unit is taken from
+      the renderer) while the pool works on the next chunk.
     * The cameras render from / accumulate into GPU staging tables ([T,48] parameters and gradients, row
       -> slot through an index the fused front end follows).
-    * GPU -> host: one zero-copy scatter STORE of the gradient rows into the pinned gradient table (plain
-      stores, no read-modify-write over the link, no host pass); they wait there, stamped with this
-      batch's step, until the row is needed again.
+    * GPU -> host: zero-copy scatter STORES of the gradient rows into the pinned gradient table (plain
+      stores, no read-modify-write over the link, no host pass), on a second side stream; they wait there,
+      stamped with this batch's step, until the row is needed again.
     """
     from ...fused import train_one_camera
     bsz = len(batched_cameras)
@@ -542,6 +546,9 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     L = _lib.lib()
     skip_opt = getattr(args, "debug_skip_optimizer", False)  # test hook, see _train_one_batch_hbm
     default_stream = torch.cuda.current_stream()
+    if getattr(gaussians, "_host_out_stream", None) is None:
+        gaussians._host_out_stream = torch.cuda.Stream()
+    out_stream = gaussians._host_out_stream
     with torch.no_grad():
         with _lib.host_region("select_filters"):
             filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
@@ -553,49 +560,100 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         hb = _host_buffers(gaussians, T, dev)
         rows_h, stage_h = hb["rows_h"][:T], hb["stage_h"][:T]
         sh_stage, g_stage, slot_of = hb["sh_stage"][:T], hb["g_stage"][:T], hb["slot_of"]
-        # row list to the host (asynchronous), row -> slot table, per-camera slot indices
-        rows32 = touched_rows.to(torch.int32)
-        check_rc = L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), T * 4, 2)
-        _lib.check(check_rc)
-        ev_rows = torch.cuda.Event()
-        ev_rows.record(default_stream)
-        slot_of[touched_rows] = torch.arange(T, dtype=torch.int32, device=dev)
-        sh_index = [slot_of[f] for f in filters]
+        # ---- group the union by first use (slot order) and by last use (gradient hand-back order)
+        with _lib.host_region("host_groups"):
+            bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
+            bm = (bitmap[touched_rows].to(torch.int32) & ((1 << bsz) - 1)) if bsz < 32 else None
+            if bm is not None:
+                first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float32))).to(torch.int64)   # earliest camera
+                low = bm & (-bm)
+                last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float32))).to(torch.int64)   # latest camera
+            else:  # bsz 32 / 64: per-camera membership instead of float log2 on wide words
+                first = torch.full((T,), bsz, dtype=torch.int64, device=dev)
+                last = torch.zeros((T,), dtype=torch.int64, device=dev)
+                pos = torch.empty((N,), dtype=torch.int64, device=dev)
+                pos[touched_rows] = torch.arange(T, device=dev)
+                for i, f in enumerate(filters):
+                    pf = pos[f]
+                    first[pf] = torch.minimum(first[pf], torch.full_like(pf, i))
+                    last[pf] = i
+            ord_first = torch.sort(first, stable=True).indices
+            union = touched_rows[ord_first]                               # slot k holds row union[k]
+            rows32 = union.to(torch.int32)
+            counts = torch.cat((torch.bincount(first, minlength=bsz), torch.bincount(last, minlength=bsz)))
+            _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), T * 4, 2))
+            slot_of[union] = torch.arange(T, dtype=torch.int32, device=dev)
+            sh_index = [slot_of[f] for f in filters]
+            ord_last = torch.sort(last, stable=True).indices
+            rows_by_last = touched_rows[ord_last]
+            slots_by_last = slot_of[rows_by_last]
+            _t0 = time.perf_counter()
+            cl = counts.tolist()                                          # one host read: 2*bsz group sizes
+            _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
+        n_first, n_last = cl[:bsz], cl[bsz:]
         prev = gaussians._host_grads_event
         if prev is not None:  # the previous batch's scatter still reads g_stage
             default_stream.wait_event(prev)
         g_stage.zero_()
         row_adam = gaussians.optimizer.cpu_adam
         step = row_adam.global_step + 1
-        # ---- host -> GPU: prepare + stage + hipMemcpyAsync, chunk by chunk
-        with _lib.host_region("host_prepare"):
-            ev_rows.synchronize()
-            comm_stream.wait_stream(default_stream)
-            cs = ctypes.c_void_p(comm_stream.cuda_stream)
-            for c0 in range(0, T, _HOST_CHUNK_ROWS):
-                c1 = min(T, c0 + _HOST_CHUNK_ROWS)
-                gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
-                                            next_g_step=0 if skip_opt else step)
-                _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[c0:c1]), ctypes_ptr(stage_h[c0:c1]),
-                                                (c1 - c0) * 192, 1))
-            ev_h2d = torch.cuda.Event()
-            ev_h2d.record(comm_stream)
-        default_stream.wait_event(ev_h2d)
-        # ---- render: one camera after the other (the mode is bound by the host link, not by the GPU:
-        # the camera pipeline of the HBM mode would only add its per-camera buffers to the peak)
+        comm_stream.wait_stream(default_stream)
+        cs = ctypes.c_void_p(comm_stream.cuda_stream)
+        # ---- feeder: prepare + stage + hipMemcpyAsync chunk by chunk, one event per first-use group
+        ready = [threading.Event() for _ in range(bsz)]
+        ev_group = [None] * bsz
+        err = []
+
+        def feeder():
+            try:
+                k0 = 0
+                for i in range(bsz):
+                    k1 = k0 + n_first[i]
+                    for c0 in range(k0, k1, _HOST_CHUNK_ROWS):
+                        c1 = min(k1, c0 + _HOST_CHUNK_ROWS)
+                        gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
+                                                    next_g_step=0 if skip_opt else step)
+                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[c0:c1]), ctypes_ptr(stage_h[c0:c1]),
+                                                        (c1 - c0) * 192, 1))
+                    ev = torch.cuda.Event()
+                    ev.record(comm_stream)
+                    ev_group[i] = ev
+                    ready[i].set()
+                    k0 = k1
+            except BaseException as e:  # surface in the main thread
+                err.append(e)
+                for r in ready:
+                    r.set()
+
+        worker = threading.Thread(target=feeder, name="clmgs-host-feeder")
+        worker.start()
+        # ---- render: one camera after the other (the mode is bound by the host side, not by the GPU: the
+        # camera pipeline of the HBM mode would only add its per-camera buffers to the peak)
         _zero_small_grads(gaussians)
         losses = []
+        l0 = 0
         for i in range(bsz):
+            with _lib.host_region("wait_rows"):
+                ready[i].wait()
+            if err:
+                worker.join()
+                raise err[0]
+            default_stream.wait_event(ev_group[i])
             losses.append(train_one_camera(gaussians, batched_cameras[i], filters[i], sh_stage, 1, g_stage,
                                            background, batched_cameras[i].original_image, sh_index=sh_index[i]))
-        # ---- GPU -> host: gradient rows, plain stores into the pinned table (side stream)
-        comm_stream.wait_stream(default_stream)
-        with torch.cuda.stream(comm_stream):
-            send_shs2cpu_grad_buffer_stream(g_stage, parameters_grad_buffer[:N, :], touched_rows, False)
-            ev_g = torch.cuda.Event()
-            ev_g.record(comm_stream)
+            # rows whose LAST camera this was: their gradient rows go home now (plain stores, side stream)
+            l1 = l0 + n_last[i]
+            if l1 > l0:
+                out_stream.wait_stream(default_stream)
+                with torch.cuda.stream(out_stream):
+                    clm_kernels._rows("clmgs_rows_gather", parameters_grad_buffer[:N, :], g_stage,
+                                      rows_by_last[l0:l1], slots_by_last[l0:l1].to(torch.int64), 0)
+            l0 = l1
+        worker.join()
+        ev_g = torch.cuda.Event()
+        ev_g.record(out_stream)
         gaussians._host_grads_event = ev_g
-        gaussians._host_keep = (rows32, sh_index, touched_rows, filters)  # until the streams are done with them
+        gaussians._host_keep = (rows32, sh_index, touched_rows, filters, rows_by_last, slots_by_last, union)
     if skip_opt:
         torch.cuda.synchronize()
         return losses, ordered_cams, sparsity

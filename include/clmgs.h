@@ -305,7 +305,8 @@ int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, const int32_t* 
  * up-to-date parameter row into stage[k] (contiguous pinned staging for a hipMemcpyAsync; NULL to skip).
  * sparse != 0 (sparse_adam): rows are stepped only when they carry a gradient, nothing is replayed.
  * Arithmetic per element and step = clmgs_host_adam_rows'. */
-int clmgs_host_pool_start(int n_threads);
+int clmgs_host_pool_start(int n_threads);  /* <= 0: sized to the CPUs the process may use (cgroup quota aware) */
+int clmgs_host_usable_cpus(void);
 /* hipMemcpyAsync of `bytes` between pinned host memory and HBM on `stream` (SDMA engine; kind 1 = host
  * -> device, 2 = device -> host): how the host-resident mode moves its contiguous staging chunks
  * (replaces clm_kernels.send_shs2gpu_stream's zero-copy gather, clm_offload/engine.py:499-505). */

@@ -187,7 +187,7 @@ def test_no_offload_three_batches_match_reference_training(dev, fx, fused):
 
 
 # ------------------------------------------------------------------ a4 / a7 / a8 / a9 / a11 / a16: clm_offload
-CLM_MODES = [("hbm", True), ("hbm", False), ("host", True), ("host", False)]
+CLM_MODES = [("hbm", True), ("hbm", False), ("host", True)]  # the host-resident mode runs the fused front end only
 
 
 def _clm_batch(m, Scene, batch, comm, gen):
