@@ -231,9 +231,9 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     t0 = time.perf_counter()
     for b in range(a.host_warmup, n_b):
         losses_all += list(step(b))
+    t_batches = time.perf_counter() - t0
+    g.flush_lazy_rows()  # the deferred row steps still waiting after the last batch: inside the timed region
     torch.cuda.synchronize()
-    if g._host_grads_event is not None:
-        g._host_grads_event.synchronize()
     dt = time.perf_counter() - t0
     regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
     peak = torch.cuda.max_memory_allocated()
@@ -246,6 +246,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
            "steps": a.host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
            "pinned_host_bytes": int(4 * g.parameters_buffer.shape[0] * 192),
            "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
+           "final_flush_ms": round((dt - t_batches) * 1e3, 1),
            "host_ms_per_step": {k: round(v / a.host_steps * 1e3, 2) for k, v in regions.items()},
            "link": {"bytes_per_batch": round(link_bytes, 1), "achieved_GBps": round(link_bytes * a.host_steps / dt / 1e9, 2),
                     "peak_GBps": 57.0, "note": "peak = hipMemcpyAsync pinned<->HBM measured on this node type, EITHER direction or "
@@ -410,6 +411,10 @@ def main():
         step_marks.append(time.perf_counter())
         if sp:
             sparsities += sp
+    # deferred row optimizers (clm_offload): the SH-row Adam step of a batch is applied at the rows' next
+    # touch; whatever is still waiting after the K-th batch is applied HERE, inside the timed region
+    if hasattr(gaussians, "flush_lazy_rows"):
+        gaussians.flush_lazy_rows()
     t_enq = time.perf_counter() - t0  # host: enqueue work + size readbacks, before the final fence
     fence()
     dt = time.perf_counter() - t0

@@ -204,53 +204,85 @@ __global__ void __launch_bounds__(256)
 adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                      const int32_t* __restrict__ last_step, const void* __restrict__ rows,
                      int64_t n_rows, int cols, const float* __restrict__ col_lr, float beta1,
-                     float beta2, float eps, int to_step, int bias_correction, int max_replay) {
+                     float beta2, float eps, int to_step, int bias_correction, int max_replay,
+                     float* __restrict__ g, const int32_t* __restrict__ g_step, float grad_scale) {
   const int cv = cols / VEC;
   const int64_t total = n_rows * cv;
+  const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cv;
     const int k = (int)(i - r * cv) * VEC;
     const int64_t row = row_of<IdxT>(rows, r);
     int a = last_step[row];
-    int missed = to_step - a;
-    if (missed <= 0) continue;
+    // DEFERRED gradient step: g[row] holds the gradient of optimizer step g_step[row] (> last_step: not
+    // applied yet).  It is applied here, at its own step, between the zero-gradient replays before and
+    // after it -- the same operations in the same order as an eager update at the end of that batch, but
+    // the row's p / m / v make ONE round trip per touch instead of two (catch-up + end-of-batch Adam).
+    const int gs = g_step ? g_step[row] : 0;
+    const bool pending = gs > a && gs <= to_step;
+    if (to_step - a <= 0) continue;
     const int64_t o = row * cols + k;
     float mm[VEC], vv[VEC], pp[VEC], lr[VEC];
     vload<VEC>(m + o, mm); vload<VEC>(v + o, vv);
-    {  // all-zero state (rows that never had a gradient): every replayed step is the identity
-       // (m, v stay 0 and p -= lr * 0 / (0 + eps)), so neither the loop nor the stores are needed
+    if (!pending) {  // all-zero state (rows that never had a gradient): every replayed step is the identity
+      // (m, v stay 0 and p -= lr * 0 / (0 + eps)), so neither the loop nor the stores are needed
       bool any_state = false;
 #pragma unroll
       for (int c = 0; c < VEC; ++c) any_state |= (mm[c] != 0.f) | (vv[c] != 0.f);
       if (!any_state) continue;
     }
     vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
-    // the first max_replay missed steps are replayed exactly; by then the first moment has decayed
-    // by beta1^max_replay (1e-12 at 0.9^256, far less with the batch-scaled betas), the remaining
+    // zero-gradient steps from+1 .. to: the first max_replay are replayed exactly; by then the first moment
+    // has decayed by beta1^max_replay (1e-12 at 0.9^256, far less with the batch-scaled betas), the remaining
     // parameter increments are below float resolution and only the moments' decay is applied
-    const int replay = min(missed, max_replay);
-    float pw1 = powf(beta1, (float)(a + 1)), pw2 = powf(beta2, (float)(a + 1));
-    for (int j = 0; j < replay; ++j) {
+    auto replay = [&](int from, int to) {
+      const int missed = to - from;
+      if (missed <= 0) return;
+      const int n = min(missed, max_replay);
+      float pw1 = powf(beta1, (float)(from + 1)), pw2 = powf(beta2, (float)(from + 1));
+      for (int j = 0; j < n; ++j) {
+        float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+        if (bias_correction) {
+          inv_bc1 = 1.f / (1.f - pw1);
+          inv_sqrt_bc2 = 1.f / sqrtf(1.f - pw2);
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          mm[c] *= beta1;
+          vv[c] *= beta2;
+          pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
+        }
+        pw1 *= beta1; pw2 *= beta2;
+      }
+      if (missed > n) {
+        const int d = missed - n;
+        const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
+      }
+    };
+    if (pending) {
+      replay(a, gs - 1);
+      float gg[VEC];
+      vload<VEC>(g + o, gg);
       float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
       if (bias_correction) {
-        inv_bc1 = 1.f / (1.f - pw1);
-        inv_sqrt_bc2 = 1.f / sqrtf(1.f - pw2);
+        inv_bc1 = 1.f / (1.f - powf(beta1, (float)gs));
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(beta2, (float)gs));
       }
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
-        mm[c] *= beta1;
-        vv[c] *= beta2;
+        const float gsc = gg[c] * grad_scale;
+        mm[c] = beta1 * mm[c] + ob1 * gsc;
+        vv[c] = beta2 * vv[c] + ob2 * gsc * gsc;
         pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
+        gg[c] = 0.f;
       }
-      pw1 *= beta1; pw2 *= beta2;
+      vstore<VEC>(g + o, gg);  // consumed
+      a = gs;
     }
-    if (missed > replay) {
-      const int d = missed - replay;
-      const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
-    }
+    replay(a, to_step);
     vstore<VEC>(m + o, mm); vstore<VEC>(v + o, vv); vstore<VEC>(p + o, pp);
   }
 }
@@ -474,16 +506,17 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
                                    const int32_t* last_step, const void* rows, int idx_is_64,
                                    int64_t n_rows, int cols, const float* col_lr, double beta1,
                                    double beta2, double eps, int to_step, int bias_correction,
-                                   int max_replay) {
+                                   int max_replay, float* g, const int32_t* g_step, float grad_scale) {
   CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && to_step >= 0 && max_replay >= 1);
   if (n_rows == 0) return 0;
-  CLMGS_CHECK_ARG(p && m && v && last_step && col_lr);
-  const bool v4 = (cols % 4 == 0) && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)col_lr) & 15) == 0;
+  CLMGS_CHECK_ARG(p && m && v && last_step && col_lr && ((g != nullptr) == (g_step != nullptr)));
+  const bool v4 = (cols % 4 == 0) &&
+                  (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)col_lr | (uintptr_t)g) & 15) == 0;
   const int grid = (int)min(ceil_div(n_rows * (cols / (v4 ? 4 : 1)), 256), (int64_t)256 * 16);
 #define CLMGS_CATCH_UP(I, VEC)                                                                     \
   hipLaunchKernelGGL((adam_catch_up_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
                      p, m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,   \
-                     (float)eps, to_step, bias_correction, max_replay)
+                     (float)eps, to_step, bias_correction, max_replay, g, g_step, grad_scale)
   if (idx_is_64) { if (v4) CLMGS_CATCH_UP(int64_t, 4); else CLMGS_CATCH_UP(int64_t, 1); }
   else { if (v4) CLMGS_CATCH_UP(int32_t, 4); else CLMGS_CATCH_UP(int32_t, 1); }
 #undef CLMGS_CATCH_UP

@@ -166,6 +166,11 @@ def camera_forward_finish(gaussians, p):
             p.ev_loss = torch.cuda.Event()
             p.ev_loss.record(s_mem)
         p.aux = p.aux + (gt, one, partials)
+        # the three derivative maps (573 MB at 4K) were allocated, written and read on s_mem only: dropping
+        # them here hands the block back to that stream's pool, where the next camera's maps reuse it in
+        # stream order (they used to stay alive until the next batch: 4 x 573 MB)
+        p.maps = None
+        del maps
     return p
 
 
@@ -231,7 +236,11 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
             None, *small_out, dptr(g_sh_rows, F32, allow_host=True),
             *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum),
             dptr(p.sh_index, I32, True)))
-    p.aux = p.aux + (partials,)
+    # partials (64 B per intersection) and the loss cotangent image were allocated on s_mem; their last
+    # readers (preprocess_bwd on s_mem; the tile kernel on s_raster, which s_mem has just waited for) are
+    # ordered before anything s_mem runs from here on, so the blocks can go back to s_mem's pool now
+    del partials
+    p.v_out = None
     return p
 
 

@@ -294,6 +294,7 @@ class BaseGaussianModel(ABC):
             row_adam.global_step = state["row_global_step"]
             if getattr(self, "lazy_rows", False):
                 self._row_last_step.fill_(row_adam.global_step)
+                self._row_g_step.zero_()
             if getattr(self, "deferred_host_rows", False):
                 self._host_last_step.fill_(row_adam.global_step)
                 self._host_g_step.zero_()

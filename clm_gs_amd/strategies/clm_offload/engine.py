@@ -466,12 +466,16 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
                        grad_div=bsz * dp.world_size())
         gaussians.invalidate_small_packed()
-    if not args.stop_update_param:
+    if lazy:
+        # DEFERRED: the touched rows' Adam step of this batch is not run now.  Their (reduced) gradient
+        # rows stay in the gradient table, stamped with this step, and catch_up_rows applies them -- at
+        # this step, before the zero-gradient replays -- the next time a row is rendered / evaluated /
+        # saved / densified: p, m, v of a row make one round trip per touch instead of two.
+        # (index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host scalar
+        # to the device and block the host until the whole batch has drained)
+        gaussians._row_g_step.index_fill_(0, touched_rows.long(), step)
+    elif not args.stop_update_param:
         row_update(touched_rows)
-        if lazy:
-            # index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host
-            # scalar to the device and block the host until the whole batch has drained
-            gaussians._row_last_step.index_fill_(0, touched_rows.long(), step)
     st["step"] = step
     if side_event is not None:
         default_stream.wait_event(side_event)

@@ -98,9 +98,11 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if training_args.lr_scale_mode in ("linear", "sqrt"):
             self.optimizer.columns_lr *= lr_scale
         # deferred dense Adam (HBM rows only): optimizer step each row is current as of
-        self._row_last_step = None
+        self._row_last_step = self._row_g_step = None
         if (not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True):
             self._row_last_step = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+            # step whose gradient waits in parameters_grad_buffer[row] (applied at the row's next touch)
+            self._row_g_step = torch.zeros((cap,), dtype=torch.int32, device="cuda")
         # host-resident rows: DEFERRED row optimizer (clmgs_host_rows_prepare).  Two host stamps per row:
         # step the row is current as of, and step whose gradient waits in parameters_grad_buffer (0: none)
         self._host_last_step = self._host_g_step = None
@@ -193,8 +195,11 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if to_step <= 0:
             return
         col_lr = opt._col_lr(p.device)
+        from ... import dp
         adam_catch_up(p.data, st["exp_avg"], st["exp_avg_sq"], self._row_last_step, rows, col_lr,
-                      g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"])
+                      g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"],
+                      g=self.parameters_grad_buffer[:p.shape[0]], g_step=self._row_g_step,
+                      grad_scale=1.0 / (self.args.bsz * dp.world_size()))
 
     def flush_lazy_rows(self):
         if self.deferred_host_rows:
@@ -304,6 +309,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                 grown = torch.zeros((self.parameters_buffer.shape[0],), dtype=torch.int32, device="cuda")
                 grown[:n] = self._row_last_step[:n]
                 self._row_last_step = grown
+                self._row_g_step = torch.zeros_like(grown)  # nothing waits after the flush above
+            self._row_g_step[n:n + k] = 0
             self._row_last_step[n:n + k] = self.optimizer.cpu_adam.global_step
         self.parameters_buffer[n:n + k].copy_(new["shs48"])
         self.parameters_grad_buffer[n:n + k].zero_()
@@ -325,6 +332,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self.flush_lazy_rows()  # afterwards every surviving row carries the same step stamp
         if self.lazy_rows:
             self._row_last_step[:m] = self.optimizer.cpu_adam.global_step
+            self._row_g_step[:m] = 0
         if self.deferred_host_rows:
             self._host_last_step[:m] = self.optimizer.cpu_adam.global_step
             self._host_g_step[:m] = 0

@@ -272,7 +272,12 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
  * caller then sets last_step[rows] = to_step.  Only the first max_replay missed steps are replayed
  * exactly; for the rest the moments are decayed analytically (the first moment has decayed by
  * beta1^max_replay by then, the parameter increments are below float resolution).  Elements whose
- * moments are both zero are left untouched (every replayed step is the identity for them). */
+ * moments are both zero are left untouched (every replayed step is the identity for them).
+ * g / g_step (both or neither): DEFERRED gradient step.  g_step[row] (i32) is the optimizer step whose
+ * gradient waits in g[row, cols]; if it lies in (last_step, to_step] it is applied here at its own step
+ * with grad_scale, between the replays before and after it, and the gradient row is zeroed: the same
+ * operations in the same order as the eager update at the end of that batch (optimizer.py:130-144 /
+ * clm_offload/engine.py:316-328), in one pass over the row instead of two. */
 /* The packed [N,12] mirror of the four GPU-resident parameter tensors, and their dense Adam when the
  * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
  * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a
@@ -287,7 +292,8 @@ int clmgs_adam_small_packed(void* stream, int64_t n, float* const* params, float
 int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v, const int32_t* last_step,
                         const void* rows, int idx_is_64, int64_t n_rows, int cols,
                         const float* col_lr, double beta1, double beta2, double eps, int to_step,
-                        int bias_correction, int max_replay);
+                        int bias_correction, int max_replay, float* g, const int32_t* g_step,
+                        float grad_scale);
 /* Host (OpenMP) variant on pinned/pageable host memory: cpu_adam.FusedCPUAdam row group
  * update (clm_offload/engine.py:316-328).  If signal != NULL, busy-waits until
  * *signal != 0 before touching the rows. */

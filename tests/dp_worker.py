@@ -44,6 +44,7 @@ def _train(m, batches, args, world=1):
         m.update_learning_rate(it)
         clm_offload_train_one_batch(m, _Scene, batch, m.parameters_grad_buffer, None, None, comm, gen)
         it += len(batch) * world  # the image counter strides by the global batch
+    m.flush_lazy_rows()
     torch.cuda.synchronize()
     return [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
             m._rotation.detach().clone(), m._parameters.detach().clone()]
@@ -73,6 +74,7 @@ def trainer_mode(rank, world):
     n0t = n.clone()
     dist.broadcast(n0t, src=0)
     same = bool(n0t.item() == n.item())
+    m.flush_lazy_rows()
     if same:
         for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters):
             other = t.detach().clone()

@@ -370,6 +370,7 @@ def test_naive_offload_equals_clm_offload_after_two_steps(dev, sparse):
             lo[k] = v.item()
         ref_losses.append(lo)
         if it == 1:
+            ref.flush_lazy_rows()  # the SH-row step of a batch is applied at the rows' next touch (or here)
             ref_shs_step1 = ref._parameters.detach().clone()
 
     args2 = utils.default_args(bsz=BSZ, sparse_adam=sparse)
