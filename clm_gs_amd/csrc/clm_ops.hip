@@ -205,10 +205,10 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
                      const int32_t* __restrict__ last_step, const void* __restrict__ rows,
                      int64_t n_rows, int cols, const float* __restrict__ col_lr, float beta1,
                      float beta2, float eps, int to_step, int bias_correction, int max_replay,
-                     float* __restrict__ g, const int32_t* __restrict__ g_step, float grad_scale) {
+                     float* __restrict__ g, const int32_t* __restrict__ g_step, float grad_scale,
+                     float ob1, float ob2) {  // 1 - beta, rounded from double like the eager kernel's
   const int cv = cols / VEC;
   const int64_t total = n_rows * cv;
-  const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cv;
@@ -516,7 +516,8 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
 #define CLMGS_CATCH_UP(I, VEC)                                                                     \
   hipLaunchKernelGGL((adam_catch_up_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
                      p, m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,   \
-                     (float)eps, to_step, bias_correction, max_replay, g, g_step, grad_scale)
+                     (float)eps, to_step, bias_correction, max_replay, g, g_step, grad_scale,     \
+                     (float)(1.0 - beta1), (float)(1.0 - beta2))
   if (idx_is_64) { if (v4) CLMGS_CATCH_UP(int64_t, 4); else CLMGS_CATCH_UP(int64_t, 1); }
   else { if (v4) CLMGS_CATCH_UP(int32_t, 4); else CLMGS_CATCH_UP(int32_t, 1); }
 #undef CLMGS_CATCH_UP

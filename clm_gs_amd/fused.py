@@ -203,9 +203,10 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
     else:
         small_out = (dptr(gaussians._xyz.grad, F32), dptr(gaussians._opacity.grad, F32),
                      dptr(gaussians._scaling.grad, F32), dptr(gaussians._rotation.grad, F32))
-    with torch.cuda.stream(s_mem):
+    with torch.cuda.stream(s_raster):
         # atomic-free accumulation: the tile kernel stores one 64 B line per intersection (row-ordered
-        # slots); clmgs_preprocess_bwd sums each row's contiguous range while it gathers the row
+        # slots); clmgs_preprocess_bwd sums each row's contiguous range while it gathers the row.
+        # Allocated on the stream of its WRITER (the caching allocator orders reuse by allocation stream).
         partials = empty_bucketed(max(n_isects, 1), (16,), F32, dev)
     if p.ev_loss is not None:
         s_raster.wait_event(p.ev_loss)
@@ -236,9 +237,13 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
             None, *small_out, dptr(g_sh_rows, F32, allow_host=True),
             *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum),
             dptr(p.sh_index, I32, True)))
-    # partials (64 B per intersection) and the loss cotangent image were allocated on s_mem; their last
-    # readers (preprocess_bwd on s_mem; the tile kernel on s_raster, which s_mem has just waited for) are
-    # ordered before anything s_mem runs from here on, so the blocks can go back to s_mem's pool now
+    # partials (64 B per intersection, 576 MB at 4K) and the loss cotangent image are dead once the two
+    # kernels above have run: hand them back now instead of at the next batch.  Each was used on a second
+    # stream (partials: written on s_raster, read on s_mem; v_out: written on s_mem, read on s_raster), so
+    # the allocator is told (record_stream) and delays the reuse until that stream has passed this point.
+    if s_mem is not s_raster:
+        partials.record_stream(s_mem)
+        p.v_out.record_stream(s_raster)
     del partials
     p.v_out = None
     return p
