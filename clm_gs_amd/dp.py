@@ -112,6 +112,91 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
         t[rows] = piece
 
 
+# ------------------------------------------------------------------ owner-computes exchange
+# Rank q OWNS the rows whose id lies in [q*N/G, (q+1)*N/G): only the owner keeps a row's Adam state
+# current and runs its optimizer steps (1/G of the row-optimizer work per rank; the state of the other
+# rows on a rank is dead weight that a later round can drop: ZeRO-1 for the [N,48] tables).  Per batch,
+# for the globally touched rows R (identical, ascending, on every rank):
+#   before rendering  all-gather   : owners send the up-to-date parameter rows of R, every rank fills R
+#   after rendering   reduce-scatter: every rank sends its gradient rows of R, owners receive the sums
+# -- the same bytes on the wire as the all-reduce of the gradient rows (a ring all-reduce IS a
+# reduce-scatter + an all-gather), but the second half carries parameters instead of gradients, so no
+# rank ever applies an optimizer step to a row it does not own.  Segments are padded to the longest one
+# so that the tensor forms of the collectives apply (full-mesh xGMI: 7 peers in parallel).
+class OwnerPlan:
+    __slots__ = ("rows", "bounds", "chunk", "pos", "lo", "hi", "n_ranks")
+
+
+def owner_range(n_total, q=None, n_ranks=None):
+    n_ranks = world_size() if n_ranks is None else n_ranks
+    q = rank() if q is None else q
+    return (q * n_total) // n_ranks, ((q + 1) * n_total) // n_ranks
+
+
+def owner_plan(rows, n_total):
+    """rows: ascending int64 row ids (the same on every rank).  One host read (the G+1 segment bounds)."""
+    G, r = world_size(), rank()
+    cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(rows.device)
+    b = torch.searchsorted(rows, cuts).tolist()
+    b[0], b[-1] = 0, int(rows.numel())
+    lens = [b[q + 1] - b[q] for q in range(G)]
+    pl = OwnerPlan()
+    pl.rows, pl.bounds, pl.n_ranks = rows, b, G
+    pl.chunk = max(1, max(lens))
+    shift = torch.repeat_interleave(torch.tensor([q * pl.chunk - b[q] for q in range(G)], dtype=torch.int64),
+                                    torch.tensor(lens, dtype=torch.int64)).to(rows.device)
+    pl.pos = torch.arange(rows.numel(), device=rows.device) + shift   # row k of `rows` -> row of the padded buffer
+    pl.lo, pl.hi = b[r], b[r + 1]
+    return pl
+
+
+def owner_gather_rows(table, pl):
+    """Every rank's table[pl.rows] <- the owners' rows (owners' own rows are unchanged)."""
+    if not active():
+        return
+    W = table.shape[1]
+    send = torch.zeros((pl.chunk, W), dtype=table.dtype, device=table.device)
+    if pl.hi > pl.lo:
+        send[: pl.hi - pl.lo] = table[pl.rows[pl.lo:pl.hi]]
+    recv = torch.empty((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
+    dist.all_gather_into_tensor(recv, send)
+    table[pl.rows] = recv[pl.pos]
+
+
+def owner_reduce_rows(table, pl):
+    """Sum of table[pl.rows] over the ranks, delivered to each row's OWNER; on the other ranks the rows
+    are zeroed (the gradient has been handed over)."""
+    if not active():
+        return
+    W = table.shape[1]
+    buf = torch.zeros((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
+    buf[pl.pos] = table[pl.rows]
+    mine = torch.empty((pl.chunk, W), dtype=table.dtype, device=table.device)
+    dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
+    table[pl.rows] = 0
+    if pl.hi > pl.lo:
+        table[pl.rows[pl.lo:pl.hi]] = mine[: pl.hi - pl.lo]
+
+
+def owner_gather_dense(tables, n_total):
+    """All rows of every table <- their owners' (flush: evaluation, saving, densification)."""
+    if not active():
+        return
+    G = world_size()
+    lo, hi = owner_range(n_total)
+    chunk = max(((q + 1) * n_total) // G - (q * n_total) // G for q in range(G))
+    for t in tables:
+        t2 = t.reshape(t.shape[0], -1)
+        send = torch.zeros((chunk, t2.shape[1]), dtype=t.dtype, device=t.device)
+        send[: hi - lo] = t2[lo:hi]
+        recv = torch.empty((G * chunk, t2.shape[1]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(recv, send)
+        for q in range(G):
+            a, b = owner_range(n_total, q, G)
+            if q != rank():
+                t2[a:b] = recv[q * chunk: q * chunk + (b - a)]
+
+
 def allreduce_densify_stats(gaussians):
     if not active():
         return

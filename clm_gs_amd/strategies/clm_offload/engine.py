@@ -287,7 +287,15 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     touched_rows = touched_rows.to(torch.int32)
     _lib.STATS.setdefault("touched_rows", []).append(int(touched_rows.shape[0]))  # shape known on the host
     lazy = gaussians.lazy_rows and not args.stop_update_param
-    if lazy:
+    owner = None  # owner-computes camera-DP (dp.py): rows owned by index range
+    if lazy and dp.active() and getattr(args, "dp_owner_computes", False):
+        owner = dp.owner_plan(touched_rows.long(), N)
+        gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
+        own_rows = touched_rows[owner.lo:owner.hi]
+        if owner.hi > owner.lo:  # waiting gradient step + replays, on the rows this rank owns
+            gaussians.catch_up_rows(own_rows, to_step=step - 1)
+        dp.owner_gather_rows(params.data, owner)  # every rank renders from the owners' current rows
+    elif lazy:
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
@@ -445,7 +453,17 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
 
     if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
-        if use_packed:
+        if owner is not None:
+            # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
+            # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);
+            # SH gradient rows: summed AT THEIR OWNER, which alone will step them
+            if use_packed:
+                dp.allreduce_tables_rows([small_gk], touched_rows, N, average=False)
+            else:
+                dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
+                                          gaussians._scaling.grad, gaussians._rotation.grad], average=False)
+            dp.owner_reduce_rows(grad_buf, owner)
+        elif use_packed:
             # one collective: packed small gradients + SH gradient rows of the globally touched set
             dp.allreduce_tables_rows([small_gk, grad_buf], touched_rows, N, average=False)
         else:
@@ -473,7 +491,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # saved / densified: p, m, v of a row make one round trip per touch instead of two.
         # (index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host scalar
         # to the device and block the host until the whole batch has drained)
-        gaussians._row_g_step.index_fill_(0, touched_rows.long(), step)
+        stamp = touched_rows[owner.lo:owner.hi] if owner is not None else touched_rows
+        if stamp.numel():
+            gaussians._row_g_step.index_fill_(0, stamp.long(), step)
     elif not args.stop_update_param:
         row_update(touched_rows)
     st["step"] = step
@@ -699,6 +719,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
                                           gaussians.get_scaling, gaussians.get_rotation)
         f = filters[0]
         if getattr(gaussians, "lazy_rows", False):
+            if dp.active() and getattr(utils.get_args(), "dp_owner_computes", False):
+                gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
             gaussians.catch_up_rows(f.to(torch.int32))
         if getattr(gaussians, "deferred_host_rows", False):  # host rows: apply what is waiting for them
             gaussians.host_rows_prepare(f.to(torch.int32).cpu().contiguous(), None)

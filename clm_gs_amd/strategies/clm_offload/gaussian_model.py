@@ -205,6 +205,23 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if self.deferred_host_rows:
             self.host_rows_prepare(None, None)
             return
+        from ... import dp
+        if self.lazy_rows and dp.active() and getattr(self.args, "dp_owner_computes", False):
+            # owner-computes camera-DP: every rank brings the rows it OWNS up to date, then all ranks
+            # exchange parameters, moments and stamps, after which each replica is complete and current
+            if not getattr(self, "_owner_dirty", True):
+                return
+            self._owner_dirty = False
+            n = self._parameters.shape[0]
+            lo, hi = dp.owner_range(n)
+            if hi > lo:
+                self.catch_up_rows(torch.arange(lo, hi, dtype=torch.int32, device=self._xyz.device))
+            st = self.optimizer.cpu_adam.state[self._parameters]
+            dp.owner_gather_dense([self._parameters.data, st["exp_avg"], st["exp_avg_sq"],
+                                   self.parameters_grad_buffer[:n]], n)
+            self._row_last_step[:n] = self.optimizer.cpu_adam.global_step
+            self._row_g_step[:n] = 0
+            return
         self.catch_up_rows(None)
 
     # ---------------------------------------------------- deferred host row optimizer

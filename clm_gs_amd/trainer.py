@@ -155,6 +155,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         log_file.write((" sparsity: " + " ".join("%.4f" % s for s in sparsity) + "\n") if sparsity else "\n")
         if any(iteration <= t < iteration + gbsz for t in test_iterations):
             timer.stop()  # evaluation is excluded from the throughput figure
+            if hasattr(gaussians, "flush_lazy_rows"):  # deferred row steps (and, owner-computes DP, the exchange)
+                gaussians.flush_lazy_rows()
             evaluate("train", iteration, train_cameras, render_fn, log_file, max_images=5)
             if test_cameras:
                 evaluate("test", iteration, test_cameras, render_fn, log_file)

@@ -52,6 +52,8 @@ def default_args(**over):
         pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
+        dp_owner_computes=False,  # camera-DP: rows are owned by index range; all-gather of parameter rows before
+                                  # rendering, reduce-scatter of gradient rows after it, only the owner steps a row
         lazy_dense_adam=True,   # HBM rows: replay zero-gradient Adam steps on demand (exact)   # two cameras of a batch in flight on two HIP streams
     )
     for k, v in over.items():

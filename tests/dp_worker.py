@@ -50,7 +50,7 @@ def _train(m, batches, args, world=1):
             m._rotation.detach().clone(), m._parameters.detach().clone()]
 
 
-def trainer_mode(rank, world):
+def trainer_mode(rank, world, owner=False):
     """Both ranks run trainer.training (engine exchange + reduced densification statistics + the
     shared split generator); after clone / split / prune the replicas must still be identical."""
     import io
@@ -58,7 +58,7 @@ def trainer_mode(rank, world):
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
     n0, w, h = 6000, 128, 96
     args = utils.default_args(bsz=4, sh_residency="hbm", densify_from_iter=16, densification_interval=16,
-                              densify_until_iter=48, densify_grad_threshold=0.00002)
+                              densify_until_iter=48, densify_grad_threshold=0.00002, dp_owner_computes=owner)
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(h, w)
@@ -96,8 +96,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
-    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
-        return trainer_mode(rank, world)
+    if len(sys.argv) > 1 and sys.argv[1].startswith("trainer"):
+        return trainer_mode(rank, world, owner=sys.argv[1] == "trainer_owner")
     from clm_gs_amd import dp, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 
@@ -113,6 +113,8 @@ def main():
     G = BSZ * world
     global_batches = [cams[s * G:(s + 1) * G] for s in range(STEPS)]
 
+    if len(sys.argv) > 1 and sys.argv[1] == "owner":
+        args.dp_owner_computes = True  # rows owned by index range: all-gather params / reduce-scatter grads
     mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
     # replicas identical bit for bit (same reduced gradients, same optimizer arithmetic)
     same = True

@@ -87,10 +87,13 @@ def main():
     keep = (m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone())
     dp.allreduce_densify_stats(m)
     res["densify_stats"] = all(torch.equal(a, b) for a, b in zip(keep, (m.xyz_gradient_accum, m.denom, m.max_radii2D)))
-    if hasattr(dp, "owner_exchange_tables"):
-        b12, b48 = t12.clone(), t48.clone()
-        dp.owner_exchange_tables([b12, b48], idx, n, lambda lo, hi: None)
-        res["owner_exchange"] = bool(torch.equal(b12, t12) and torch.equal(b48, t48))
+    pl = dp.owner_plan(idx, n)  # owner-computes exchange on RCCL: reduce_scatter_tensor / all_gather_into_tensor
+    b48 = t48.clone()
+    dp.owner_reduce_rows(b48, pl)
+    dp.owner_gather_rows(b48, pl)
+    dense = [t48.clone(), torch.arange(n, device="cuda", dtype=torch.float32)]
+    dp.owner_gather_dense(dense, n)
+    res["owner_exchange"] = bool(torch.equal(b48, t48) and torch.equal(dense[0], t48) and pl.lo == 0 and pl.hi == idx.numel())
     forced = _train(True)
     plain = _train(False)
     res["train_forced_equals_plain"] = all(torch.equal(a, b) for a, b in zip(forced, plain))

@@ -51,9 +51,30 @@ def _worker(rank, world, port, out):
     dp.allreduce_tables_rows([a_small, a_rows], rows_g, N)                    # packed branch
     b_small, b_rows = t_small.clone(), t_rows.clone()
     dp.allreduce_tables_rows([b_small, b_rows], rows_g, N, dense_above=0.0)   # in-place branch
+    # owner-computes exchange: reduce-scatter of the globally touched rows to their owners (index ranges),
+    # all-gather of the owners' rows
+    pl = dp.owner_plan(rows_g, N)
+    o_rows = t_rows.clone()
+    dp.owner_reduce_rows(o_rows, pl)
+    lo, hi = dp.owner_range(N)
+    own = (rows_g >= lo) & (rows_g < hi)
+    owner_ok = bool((o_rows[rows_g[~own]] == 0).all())          # handed over
+    owner_ok &= pl.hi - pl.lo == int(own.sum()) and sum(pl.bounds[q + 1] - pl.bounds[q] for q in range(world)) == rows_g.numel()
+    p_rows = torch.full((N, 48), float(rank + 1))                  # "parameters": owners hold value rank+1
+    dp.owner_gather_rows(p_rows, pl)
+    want_owner = torch.zeros(N, dtype=torch.long)
+    for q in range(world):
+        a, b = dp.owner_range(N, q, world)
+        want_owner[a:b] = q + 1
+    owner_ok &= bool((p_rows[rows_g] == want_owner[rows_g, None].float()).all())
+    untouched = torch.ones(N, dtype=torch.bool); untouched[rows_g] = False
+    owner_ok &= bool((p_rows[untouched] == float(rank + 1)).all())
+    dense = [torch.full((N, 48), float(rank + 1)), torch.full((N,), float(rank + 1))]
+    dp.owner_gather_dense(dense, N)
+    owner_ok &= bool((dense[0] == want_owner[:, None].float()).all() and (dense[1] == want_owner.float()).all())
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(ref=ref, rows_ref=rows_ref, touched_ref=touched_ref,
-                                          ts_ref=ts_ref, tr_ref=tr_ref))
+                                          ts_ref=ts_ref, tr_ref=tr_ref, o_rows=o_rows, owner_ok=owner_ok))
     if rank == 0:
         want_small = [sum(gd["ref"][i] for gd in gathered) / world for i in range(4)]
         want_t = gathered[0]["touched_ref"] | gathered[1]["touched_ref"]
@@ -66,6 +87,9 @@ def _worker(rank, world, port, out):
         for got_s, got_r in ((a_small, a_rows), (b_small, b_rows)):
             ok &= torch.allclose(got_s, want_ts, atol=1e-6) and torch.allclose(got_r, want_tr, atol=1e-6)
         ok &= bool((m.xyz_gradient_accum == 3.0).all() and (m.denom == 2.0).all() and (m.max_radii2D == 5.0).all())
+        # the owners' reduced rows, put together, are the all-reduced table
+        ok &= all(gd["owner_ok"] for gd in gathered)
+        ok &= torch.allclose(sum(gd["o_rows"] for gd in gathered), want_tr, atol=1e-6)
         out.put(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -41,6 +41,29 @@ def test_two_ranks_equal_one_rank_with_double_batch(dev):
     assert max(res["rel_l2_vs_single"]) < 2e-4, res
 
 
+def test_owner_computes_exchange_equals_allreduce_and_single_rank(dev):
+    """dp_owner_computes (rows owned by index range, all-gather of parameter rows before
+    rendering, reduce-scatter of gradient rows after it, only the owner steps a row): after the flush the
+    replicas are identical and equal the single-rank run on the doubled batch."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "owner"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True
+    assert max(res["rel_l2_vs_single"]) < 2e-4, res
+
+
+def test_trainer_owner_computes_densify_keeps_replicas_identical(dev):
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "trainer_owner"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert res["n_after"] != res["n_before"] and res["split"], res
+
+
 def test_trainer_two_ranks_densify_keeps_replicas_identical(dev):
     """trainer.training under camera-DP: global-batch image stride, reduced densification
     statistics, shared split samples -> bit-identical replicas after clone / split / prune."""
