@@ -93,6 +93,8 @@ def trainer_mode(rank, world, owner=False):
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DPW_WATCHDOG_S", "200")), exit=True)  # a hang prints its stacks
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
@@ -118,10 +120,14 @@ def main():
     mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
     # replicas identical bit for bit (same reduced gradients, same optimizer arithmetic)
     same = True
-    for t in mine:
+    for i, t in enumerate(mine):
         other = t.clone()
         dist.broadcast(other, src=0)
-        same &= bool(torch.equal(other, t))
+        eq = bool(torch.equal(other, t))
+        if not eq:
+            print(f"DPDIFF rank {rank} tensor {i}: max abs {float((other - t).abs().max()):.3e} "
+                  f"rows differing {int(((other - t).abs().reshape(t.shape[0], -1).max(dim=1).values > 0).sum())}", flush=True)
+        same &= eq
     flags = [None] * world
     dist.all_gather_object(flags, same)
     dist.barrier()

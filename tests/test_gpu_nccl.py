@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _torchrun(script_args, timeout=900, env=None):
+def _torchrun(script_args, timeout=400, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
