@@ -57,6 +57,10 @@ ALGO_BYTES = {
     "clmgs_ssim_bwd": lambda n, V, I, P, T: (36 + 24 + 12) * P,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# Calibrated wave64 VALU issue rate of the whole chip (profiles/valu_calib.hip -> profiles/r02_valu_calib.jsonl:
+# independent v_fma_f32 chains, 4-8 waves / SIMD: 856-896 G wave-instructions/s; v_exp / v_rcp / v_permlane32_swap
+# issue at ~1/3 of that rate, DPP adds at ~2/3): the compute-side roofline of the alpha-blend tile kernels
+VALU_PEAK_G = 880.0
 
 
 def parse():
@@ -497,12 +501,13 @@ def main():
     if kernels:
         dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["calls"] * kernels[k]["avg_ms"])
         ach = kernels[dom]["algo_GBps"]
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(a.config, {}).get(dom, {}).get("traffic")
+                valu = tj.get(a.config, {}).get(dom, {}).get("valu_insts")
                 traffic_src = ("NOT measured in this run: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc "
                                "FETCH_SIZE / WRITE_SIZE passes, profiles/collect.sh")) + ")") if traffic is not None else None
             except Exception:
@@ -515,6 +520,17 @@ def main():
                     "avg_launch_ms_solo": round(solo[dom], 4) if dom in solo else None,
                     "frac_solo": round(ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T) / (solo[dom] * 1e-3) / 1e9
                                        / HBM_PEAK_GBS, 5) if dom in solo else None,
+                    "compute": ({"unit": "G wave-instr/s (VALU)", "peak": VALU_PEAK_G,
+                                 "valu_insts_per_launch": valu,
+                                 "achieved": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9, 1),
+                                 "frac": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / VALU_PEAK_G, 4),
+                                 "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
+                                 "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
+                                 "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
+                                         "durations from this run; peak = calibrated plain-FMA issue rate -- the kernel's "
+                                         "exp / rcp / DPP / permlane instructions cost 1.5-3 slots each, so frac "
+                                         "UNDER-states how busy the VALU pipes are (DESIGN.md section 3)"}
+                                if valu else None),
                     "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
                     "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "
                             "HBM fraction is structurally low, pairs/s reported beside it. achieved/frac use "
