@@ -12,10 +12,10 @@
 constexpr int CHAINS = 8;
 constexpr int UNROLL = 16;  // instructions per chain per loop trip
 
-enum Op { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERMLANE32_SWAP, CNDMASK, LDS_B128_BCAST, FMA_WITH_SALU, MIN_CMP, N_OPS };
+enum Op { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERMLANE32_SWAP, CNDMASK, LDS_B128_BCAST, FMA_WITH_SALU, MIN_CMP, PK_FMA, PK_MUL, PK_ADD, N_OPS };
 static const char* NAMES[N_OPS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp(row_shr:1)",
                                    "v_permlane32_swap_b32", "v_cndmask_b32(vcc)", "ds_read_b128(broadcast)", "v_fma_f32 + 1 s_add per 2",
-                                   "v_min_f32+v_cmp_ge_f32"};
+                                   "v_min_f32+v_cmp_ge_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned long long* cycles) {
@@ -23,8 +23,11 @@ __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned lon
   if (threadIdx.x < 64) lds[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
   __syncthreads();
   float v[CHAINS];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 w[CHAINS];
 #pragma unroll
-  for (int c = 0; c < CHAINS; ++c) v[c] = 1.0f + 1e-3f * (float)(threadIdx.x + c);
+  for (int c = 0; c < CHAINS; ++c) { v[c] = 1.0f + 1e-3f * (float)(threadIdx.x + c); w[c] = f2{v[c], v[c] * 0.5f}; }
+  const f2 a2 = f2{0.999f, 0.998f}, b2 = f2{1e-4f, 2e-4f};
   const float a = 0.999f, b = 1e-4f;
   int sacc = 0;
   const unsigned long long t0 = __builtin_readcyclecounter();
@@ -50,6 +53,9 @@ __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned lon
           asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
           if (c & 1) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sacc));
         }
+        if (OP == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[c]) : "v"(a2), "v"(b2));
+        if (OP == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w[c]) : "v"(a2));
+        if (OP == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(w[c]) : "v"(b2));
         if (OP == MIN_CMP) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[c]) : "v"(a)); asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(v[c]), "v"(b) : "vcc"); }
       }
     }
@@ -57,7 +63,7 @@ __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned lon
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = (float)sacc;
 #pragma unroll
-  for (int c = 0; c < CHAINS; ++c) s += v[c];
+  for (int c = 0; c < CHAINS; ++c) s += v[c] + w[c].x + w[c].y;
   if (s == 123.456f) out[0] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
 }
@@ -88,10 +94,11 @@ void run(int waves_per_simd, float* out, unsigned long long* cyc_d) {
 int main() {
   float* out; unsigned long long* cyc;
   CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&cyc, 64));
-  for (int w : {8, 4, 1}) {
+  for (int w : {8, 4}) {
     run<FMA>(w, out, cyc); run<MUL_ADD>(w, out, cyc); run<EXP>(w, out, cyc); run<RCP>(w, out, cyc);
     run<DPP_ADD>(w, out, cyc); run<PERMLANE32_SWAP>(w, out, cyc); run<CNDMASK>(w, out, cyc);
-    run<LDS_B128_BCAST>(w, out, cyc); run<FMA_WITH_SALU>(w, out, cyc); run<MIN_CMP>(w, out, cyc);
+    run<LDS_B128_BCAST>(w, out, cyc); run<MIN_CMP>(w, out, cyc);
+    run<PK_FMA>(w, out, cyc); run<PK_MUL>(w, out, cyc); run<PK_ADD>(w, out, cyc);
   }
   return 0;
 }
