@@ -113,8 +113,13 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     import numpy as np
 
     from clm_gs_amd.strategies.base_engine import calculate_filters
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(usable))  # all host cores this process may run on
+    from clm_gs_amd import _lib
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # all host cores this process may run on: the affinity mask AND the cgroup CPU quota -- the
+    # GPU boxes show 256 hardware threads but grant 16 CPUs (cpu.max); 256 threads on a 16-CPU quota ran the
+    # same sample 36x slower than 16 threads
+    usable = max(1, min(affinity, _lib.lib().clmgs_host_usable_cpus()))
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable))
     from oracle import c_oracle as C
     C.set_num_threads(usable)
 
@@ -153,7 +158,8 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     frac2 = (cw2 * ch2) / float(width * height)
     return {
         "value": frac2 / t, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
-        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads; {usable} usable of {os.cpu_count()} host cores): "
+        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads = the CPUs this container may use: cgroup quota / "
+                   f"affinity, of {os.cpu_count()} hardware threads): "
                    f"1 micro-batch (camera 0, V={len(means)} rows in), centred {cw2}x{ch2} crop = "
                    f"{frac2:.4f} of the {width}x{height} image, {vis} visible, {isects} intersections, "
                    f"forward+loss+backward in {t:.2f}s; value = crop fraction / time"),
