@@ -141,3 +141,21 @@ def test_clm_standins_against_definitions():
     dist = [[0, 5, 9, 1], [5, 0, 2, 8], [9, 2, 0, 7], [1, 8, 7, 0]]
     t = CO.find_tour(dist)
     assert sum(dist[t[i]][t[i + 1]] for i in range(3)) == 8
+
+
+def test_trainer_log_lines_are_what_the_reference_scraper_parses():
+    """Row f1: the lines clm_gs_amd.trainer writes were fed to the reference's OWN
+    release_scripts/log2csv.py (build container, tests/golden/make_log_golden.py); the fixture holds the
+    lines and what the reference parsed.  Here: the formatters still produce exactly those lines, and the
+    parsed values are the ones put in."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_log_golden", os.path.join(G, "make_log_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fx = json.load(open(os.path.join(G, "log_contract.json")))
+    assert mod.sample_log() == fx["log"]
+    p = fx["parsed_by_reference"]
+    assert p["test_psnr"] == 32.101051330566406 and p["train_psnr"] == 33.42594528198242
+    assert p["num_3dgs"] == 1215377 and p["iterations"] == 30001
+    assert abs(p["total_time_s"] - 351.06) < 1e-9 and abs(p["throughput"] - 85.46) < 1e-9
+    assert p["max_gpu_memory_gb"] == 1.75 and p["pinned_cpu_memory_gb"] is not None
