@@ -8,8 +8,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+
+#include <map>
 
 #include <immintrin.h>
 
@@ -47,8 +50,49 @@ static int numa_nodes() {
   return n > 0 ? n : 1;
 }
 
+// Large tables (>= 64 MB): anonymous mapping advised to transparent huge pages, touched (so the pages
+// exist, interleaved over the NUMA nodes) and then registered with the runtime (pinned + device-mapped).
+// The host row optimizer walks these tables with gappy 192 B accesses: with 4 KB pages every row costs
+// TLB misses in four tables; 2 MB pages remove most of them.  CLMGS_PINNED_NO_THP=1 restores plain
+// hipHostMalloc.  Returns nullptr (caller falls back) if any step is refused.
+static std::map<void*, size_t> g_registered;
+static std::mutex g_registered_mu;
+
+static void* thp_alloc(size_t bytes, int nodes) {
+  const size_t huge = (size_t)2 << 20;
+  const size_t len = (bytes + huge - 1) / huge * huge;
+  void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return nullptr;
+  madvise(p, len, MADV_HUGEPAGE);
+  if (nodes > 1) {
+    unsigned long mask = nodes >= 64 ? ~0ul : ((1ul << nodes) - 1ul);
+    syscall(SYS_mbind, p, len, 3 /* MPOL_INTERLEAVE */, &mask, (unsigned long)(sizeof(mask) * 8), 0u);
+  }
+  // fault the pages in now, from several threads (first touch of 20+ GB by one thread takes seconds)
+  const int nt = 8;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([=] {
+      char* c = (char*)p;
+      for (size_t o = (size_t)t * 4096; o < len; o += (size_t)nt * 4096) c[o] = 0;
+    });
+  for (auto& t : th) t.join();
+  if (hipHostRegister(p, len, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    munmap(p, len);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> l(g_registered_mu);
+  g_registered[p] = len;
+  return p;
+}
+
 extern "C" void* clmgs_pinned_alloc(size_t bytes) {
   void* p = nullptr;
+  if (bytes >= ((size_t)64 << 20) && !getenv("CLMGS_PINNED_NO_THP")) {
+    p = thp_alloc(bytes, getenv("CLMGS_PINNED_NO_INTERLEAVE") ? 1 : numa_nodes());
+    if (p) return p;
+  }
   // mapped + portable: kernels may dereference it directly (zero-copy rows).  The row tables of the
   // host-resident mode are walked by threads on every socket, so large allocations are interleaved
   // over the NUMA nodes (MPOL_INTERLEAVE for the duration of the call, hipHostMallocNumaUser makes
@@ -84,6 +128,18 @@ extern "C" int clmgs_memcpy_async(void* stream, void* dst, const void* src, size
 
 extern "C" int clmgs_pinned_free(void* p) {
   if (!p) return 0;
+  {
+    std::lock_guard<std::mutex> l(g_registered_mu);
+    auto it = g_registered.find(p);
+    if (it != g_registered.end()) {
+      const size_t len = it->second;
+      g_registered.erase(it);
+      hipError_t e = hipHostUnregister(p);
+      munmap(p, len);
+      if (e != hipSuccess) { clmgs::set_error("hipHostUnregister -> %s", hipGetErrorString(e)); return (int)e; }
+      return 0;
+    }
+  }
   hipError_t e = hipHostFree(p);
   if (e != hipSuccess) {
     clmgs::set_error("hipHostFree -> %s", hipGetErrorString(e));

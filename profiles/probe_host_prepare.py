@@ -33,7 +33,7 @@ rows = torch.randperm(N)[:V].sort().values.to(torch.int32).contiguous()
 col_lr = torch.full((48,), 1e-3)
 print(json.dumps({"kind": kind, "interleave": os.environ.get("CLMGS_PINNED_NO_INTERLEAVE") is None, "alloc_s": round(t_alloc, 2)}))
 step = 0
-for nt in (16, 32, 48, 64, 96, 128, 192):
+for nt in (8, 16):
     L.clmgs_host_pool_start(nt)
     best = 1e9
     for rep in range(3):
