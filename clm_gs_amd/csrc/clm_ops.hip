@@ -223,8 +223,11 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
     const bool pending = gs > a && gs <= to_step;
     if (to_step - a <= 0) continue;
     const int64_t o = row * cols + k;
-    float mm[VEC], vv[VEC], pp[VEC], lr[VEC];
-    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv);
+    float mm[VEC], vv[VEC], pp[VEC], lr[VEC], gg[VEC];
+    // everything the row needs is requested at once (one round trip to HBM, not two): the rows handed
+    // to this kernel are the ones a batch touches, and nearly all of them have work to do
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
+    if (pending) vload<VEC>(g + o, gg);
     if (!pending) {  // all-zero state (rows that never had a gradient): every replayed step is the identity
       // (m, v stay 0 and p -= lr * 0 / (0 + eps)), so neither the loop nor the stores are needed
       bool any_state = false;
@@ -232,7 +235,6 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
       for (int c = 0; c < VEC; ++c) any_state |= (mm[c] != 0.f) | (vv[c] != 0.f);
       if (!any_state) continue;
     }
-    vload<VEC>(p + o, pp); vload<VEC>(col_lr + k, lr);
     // zero-gradient steps from+1 .. to: the first max_replay are replayed exactly; by then the first moment
     // has decayed by beta1^max_replay (1e-12 at 0.9^256, far less with the batch-scaled betas), the remaining
     // parameter increments are below float resolution and only the moments' decay is applied
@@ -264,8 +266,6 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
     };
     if (pending) {
       replay(a, gs - 1);
-      float gg[VEC];
-      vload<VEC>(g + o, gg);
       float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
       if (bias_correction) {
         inv_bc1 = 1.f / (1.f - powf(beta1, (float)gs));
