@@ -36,7 +36,8 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace clmgs
 
-extern "C" int clmgs_version(void) { return 100; }
+extern "C" int clmgs_version(void) { return 200; }
+extern "C" int clmgs_host_usable_cpus(void);
 extern "C" const char* clmgs_last_error(void) { return clmgs::g_err; }
 
 // Number of NUMA nodes with memory (directories /sys/devices/system/node/nodeK).
@@ -189,7 +190,9 @@ extern "C" int clmgs_host_adam_rows(float* p, float* g, float* m, float* v, cons
       }
     }
   };
-  int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  // default: the CPUs the process may use (cgroup quota aware; see usable_cpus below), not the hardware
+  // thread count -- 256 threads on a 16-CPU quota are throttled into a 3x slowdown
+  int nt = n_threads > 0 ? n_threads : clmgs_host_usable_cpus();
   nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, n_rows / 1024));
   if (nt == 1) { work(0, n_rows); return 0; }
   std::vector<std::thread> th;
