@@ -80,6 +80,9 @@ def parse():
                     help="shuffle: batches are seeded random draws from the survey, as the reference's DataLoader "
                          "(shuffle=True, train.py:156-167); path: consecutive cameras of the lawn-mower path (neighbours "
                          "overlap ~80 %%: far fewer distinct rows per batch than a shuffled loader sees)")
+    ap.add_argument("--row-order", default="morton", choices=["morton", "random"],
+                    help="morton: the scene's rows are stored along a Z-order curve of (x, y) (utils.morton_order, applied "
+                         "once when the model is built, as a loader would); random: the generator's order")
     ap.add_argument("--no-host-leg", action="store_true",
                     help="skip the second leg (the same workload with the SH rows + Adam state in pinned host memory)")
     ap.add_argument("--host-steps", type=int, default=5)
@@ -205,6 +208,11 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     utils.set_args(args)
     utils.set_img_size(H, W)
     scene = synth_gaussians(N, seed=0, device="cuda")
+    if a.row_order == "morton":
+        order = utils.morton_order(scene["xyz"])
+        for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            scene[k] = scene[k][order].contiguous()
+        del order
     g = GaussianModelCLMOffload(3)
     g.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"],
                           spatial_lr_scale=lr_extent)
@@ -310,6 +318,11 @@ def main():
     torch.manual_seed(0)
 
     scene = synth_gaussians(N, seed=0, device="cuda")
+    if a.row_order == "morton":
+        order = utils.morton_order(scene["xyz"])
+        for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            scene[k] = scene[k][order].contiguous()
+        del order
     n_batches = a.warmup + a.steps
     # weak scaling: every rank owns its own cameras (seeded by rank)
     all_cams = nadir_cameras(n_batches * bsz * world, N, W, H, vis_frac, seed=0, device="cuda")
@@ -573,7 +586,7 @@ def main():
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
-                   "camera_order": a.camera_order,
+                   "camera_order": a.camera_order, "row_order": a.row_order,
                    "untimed_priming_s": a.prime_seconds},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
         "peak_gpu_bytes": int(peak),

@@ -94,6 +94,16 @@ class GaussianModelNoOffload(BaseGaussianModel):
         self.denom = self.denom[keep]
         self.max_radii2D = self.max_radii2D[keep]
 
+    def permute_rows(self, order):
+        order = order.to(self._xyz.device)
+        assert order.numel() == self._xyz.shape[0]
+        for name in self._GROUPS:
+            cur = getattr(self, self._attr(name)).detach()
+            self._replace(name, cur[order].contiguous(), lambda s: s[order].contiguous())
+        self.xyz_gradient_accum = self.xyz_gradient_accum[order]
+        self.denom = self.denom[order]
+        self.max_radii2D = self.max_radii2D[order]
+
     def _shs48_rows(self, mask):
         f = self.get_features.detach()
         f = f if mask is None else f[mask]

@@ -119,6 +119,9 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
                 gaussians.get_xyz, gaussians.get_opacity, gaussians.get_scaling, gaussians.get_rotation,
                 gaussians.get_features, gaussians.active_sh_degree, cam, background, mode="test")
             return img
+    spatial = bool(getattr(args, "spatial_row_order", True)) and hasattr(gaussians, "spatial_sort") and not naive
+    if spatial:
+        gaussians.spatial_sort()  # rows along a Z-order curve: a camera's rows become contiguous runs
     # a full cyclic GC pass over torch's ~10^6 long-lived objects stalls the enqueueing thread for
     # ~100 ms: freeze what exists now, later collections only see what the loop allocates
     gc.collect()
@@ -163,6 +166,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             timer.start()
         n_before = gaussians.get_xyz.shape[0]
         gsplat_densification(iteration, scene, gaussians, None)
+        if spatial and gaussians.get_xyz.shape[0] != n_before:
+            gaussians.spatial_sort()  # clones / splits were appended at the end of the tables
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
                 iteration, gbsz, args.densification_interval, 0):
             log_file.write(memory_line(iteration, gbsz, gaussians))

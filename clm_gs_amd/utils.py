@@ -52,6 +52,7 @@ def default_args(**over):
         pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
+        spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         dp_owner_computes=False,  # camera-DP: rows are owned by index range; all-gather of parameter rows before
                                   # rendering, reduce-scatter of gradient rows after it, only the owner steps a row
         lazy_dense_adam=True,   # HBM rows: replay zero-gradient Adam steps on demand (exact)   # two cameras of a batch in flight on two HIP streams
@@ -185,3 +186,26 @@ def RGB2SH(rgb):
 
 def SH2RGB(sh):
     return sh * SH_C0 + 0.5
+
+
+def morton_order(xyz, bits=16):
+    """Permutation that sorts points along a Z-order (Morton) curve of their (x, y) coordinates
+    (`bits` bits per axis; z is ignored: the scenes this engine trains are aerial / terrestrial slabs and
+    a camera's footprint is an area of the ground plane).  Rows stored in this order make the rows a
+    camera sees -- and the rows a batch touches -- contiguous runs of the row tables instead of isolated
+    192 B rows scattered over gigabytes: coalesced gathers, TLB reach, streaming host walks.
+    Row order is not part of the model: any permutation of the Gaussians renders the same image (up to
+    the tie order of equal depths)."""
+    with torch.no_grad():
+        p = xyz.detach()[:, :2].double()
+        lo, hi = p.min(dim=0).values, p.max(dim=0).values
+        q = ((p - lo) / (hi - lo).clamp_min(1e-30) * (2 ** bits - 1)).round().to(torch.int64)
+
+        def spread(v):  # 16 bits -> every second bit of 32
+            v = (v | (v << 8)) & 0x00FF00FF
+            v = (v | (v << 4)) & 0x0F0F0F0F
+            v = (v | (v << 2)) & 0x33333333
+            v = (v | (v << 1)) & 0x55555555
+            return v
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1)
+        return torch.sort(code, stable=True).indices

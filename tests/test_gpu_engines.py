@@ -459,3 +459,54 @@ def test_naive_offload_densify_and_prune(dev):
     losses, _ = naive_offload_train_one_batch(m, _Scene, cams, None)
     assert all(torch.isfinite(l) for l in losses)
     assert naive_offload_eval_one_cam(m, _Scene, cams[0], None).shape == (3, H, W)
+
+
+@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("clm_offload", "host"), ("no_offload", "hbm")])
+def test_spatial_sort_mid_training_is_a_pure_relabelling(dev, strategy, residency):
+    """permute_rows / spatial_sort (rows along a Z-order curve of x, y) between two batches: parameters,
+    both Adam moments and the densification statistics afterwards are the un-sorted run's, row for row
+    under the permutation (same arithmetic per row; only the tie order of equal depths can differ)."""
+    from clm_gs_amd import utils
+
+    def run(sort_after_first):
+        args, sc, cams = _setup(strategy, residency)
+        m = _make(strategy, sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        perm = None
+        for b in range(2):
+            utils.set_cur_iter(1 + b * BSZ)
+            m.update_learning_rate(1 + b * BSZ)
+            if strategy == "no_offload":
+                from clm_gs_amd.strategies.no_offload import baseline_accumGrads_impl
+                baseline_accumGrads_impl(m, _Scene, cams, None)
+                for p in m.all_parameters():
+                    p.grad /= BSZ
+                m.optimizer.step()
+                m.optimizer.zero_grad(set_to_none=True)
+            else:
+                from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+                clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None, comm, gen)
+            if b == 0 and sort_after_first:
+                perm = utils.morton_order(m._xyz.detach())
+                m.permute_rows(perm)
+        torch.cuda.synchronize()
+        if hasattr(m, "flush_lazy_rows"):
+            m.flush_lazy_rows()
+        out = {"xyz": m._xyz.detach().cpu(), "rot": m._rotation.detach().cpu(), "accum": m.xyz_gradient_accum.cpu(),
+               "denom": m.denom.cpu(), "radii": m.max_radii2D.cpu()}
+        if strategy == "no_offload":
+            out["sh"] = m.get_features.detach().reshape(-1, 48).cpu()
+            out["m_xyz"] = m.optimizer.state[m._xyz]["exp_avg"].cpu()
+        else:
+            out["sh"] = m._parameters.detach().cpu()
+            out["m_sh"] = m.optimizer.cpu_adam.state[m._parameters]["exp_avg"].cpu()
+            out["m_xyz"] = m.optimizer.gpu_adam.state[m._xyz]["exp_avg"].cpu()
+        return out, perm
+
+    ref, _ = run(False)
+    got, perm = run(True)
+    perm = perm.cpu()
+    assert not torch.equal(perm, torch.arange(perm.numel()))
+    assert torch.equal(got["denom"], ref["denom"][perm]) and torch.equal(got["radii"], ref["radii"][perm])
+    for k in ref:
+        assert rel_l2(got[k], ref[k][perm]) < 1e-5, k
