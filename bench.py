@@ -211,7 +211,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     if a.row_order == "morton":
         order = utils.morton_order(scene["xyz"])
         for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
-            scene[k] = scene[k][order].contiguous()
+            scene[k] = utils.gather_rows(scene[k], order)
         del order
     g = GaussianModelCLMOffload(3)
     g.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"],
@@ -321,7 +321,7 @@ def main():
     if a.row_order == "morton":
         order = utils.morton_order(scene["xyz"])
         for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
-            scene[k] = scene[k][order].contiguous()
+            scene[k] = utils.gather_rows(scene[k], order)
         del order
     n_batches = a.warmup + a.steps
     # weak scaling: every rank owns its own cameras (seeded by rank)

@@ -179,9 +179,9 @@ class BaseGaussianModel(ABC):
         sel = torch.norm(grads, dim=-1) >= grad_threshold
         sel &= torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent
         utils.get_log_file().write(f"Number of cloned gaussians: {int(sel.sum())}\n")
-        self.densification_postfix(self._xyz.detach()[sel], self._shs48_rows(sel),
-                                   self._opacity.detach()[sel], self._scaling.detach()[sel],
-                                   self._rotation.detach()[sel])
+        self.densification_postfix(utils.select_rows(self._xyz.detach(), sel), self._shs48_rows(sel),
+                                   utils.select_rows(self._opacity.detach(), sel), utils.select_rows(self._scaling.detach(), sel),
+                                   utils.select_rows(self._rotation.detach(), sel))
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
         n_init = self.get_xyz.shape[0]
@@ -189,15 +189,15 @@ class BaseGaussianModel(ABC):
         padded[: grads.shape[0]] = grads.squeeze()
         sel = padded >= grad_threshold
         sel &= torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent
-        stds = self.get_scaling.detach()[sel].repeat(N, 1)
+        stds = utils.select_rows(self.get_scaling.detach(), sel).repeat(N, 1)
         samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=self.split_generator)
         utils.get_log_file().write(f"Number of split gaussians: {int(sel.sum())}\n")
-        rots = build_rotation(self._rotation.detach()[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz.detach()[sel].repeat(N, 1)
-        new_scaling = self.scaling_inverse_activation(self.get_scaling.detach()[sel].repeat(N, 1) / (0.8 * N))
+        rots = build_rotation(utils.select_rows(self._rotation.detach(), sel)).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + utils.select_rows(self._xyz.detach(), sel).repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(utils.select_rows(self.get_scaling.detach(), sel).repeat(N, 1) / (0.8 * N))
         self.densification_postfix(new_xyz, self._shs48_rows(sel).repeat(N, 1),
-                                   self._opacity.detach()[sel].repeat(N, 1), new_scaling,
-                                   self._rotation.detach()[sel].repeat(N, 1))
+                                   utils.select_rows(self._opacity.detach(), sel).repeat(N, 1), new_scaling,
+                                   utils.select_rows(self._rotation.detach(), sel).repeat(N, 1))
         prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device="cuda", dtype=torch.bool)))
         self.prune_points(prune)
 

@@ -356,14 +356,14 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         keep_rows = keep.cpu() if self.sh_on_host else keep
         for attr in _ROW_BUFFERS:
             buf = getattr(self, attr)
-            buf[:m].copy_(buf[:n][keep_rows])  # in-place compaction (clm/gaussian_model.py:566-570)
+            buf[:m].copy_(utils.select_rows(buf[:n], keep_rows))  # in-place compaction (clm/gaussian_model.py:566-570)
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
-            self._replace_gpu(name, attr, cur[keep].contiguous(), lambda s: s[keep].contiguous())
+            self._replace_gpu(name, attr, utils.select_rows(cur, keep).contiguous(), lambda s: utils.select_rows(s, keep).contiguous())
         self._rebind_row_state(m)
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
+        self.xyz_gradient_accum = utils.select_rows(self.xyz_gradient_accum, keep)
+        self.denom = utils.select_rows(self.denom, keep)
+        self.max_radii2D = utils.select_rows(self.max_radii2D, keep)
 
     def permute_rows(self, order):
         n = self._parameters.shape[0]
@@ -375,20 +375,20 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             buf = getattr(self, attr, None)
             if buf is None or buf.numel() == 0:
                 continue
-            buf[:n].copy_(buf[:n][order_rows])  # out of place, one table at a time (5.4 GB transient at 28 M)
+            buf[:n].copy_(utils.gather_rows(buf[:n], order_rows))  # out of place, one table at a time
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
             if self.optimizer is not None:
-                self._replace_gpu(name, attr, cur[order].contiguous(), lambda s: s[order].contiguous())
+                self._replace_gpu(name, attr, utils.gather_rows(cur, order), lambda s: utils.gather_rows(s, order))
             else:
-                setattr(self, attr, nn.Parameter(cur[order].contiguous().requires_grad_(True)))
+                setattr(self, attr, nn.Parameter(utils.gather_rows(cur, order).requires_grad_(True)))
         if self.optimizer is not None:
             self._rebind_row_state(n)
-            self.xyz_gradient_accum = self.xyz_gradient_accum[order]
-            self.denom = self.denom[order]
+            self.xyz_gradient_accum = utils.gather_rows(self.xyz_gradient_accum, order)
+            self.denom = utils.gather_rows(self.denom, order)
         else:
             self._bind_rows(n)
-        self.max_radii2D = self.max_radii2D[order]
+        self.max_radii2D = utils.gather_rows(self.max_radii2D, order)
         self.invalidate_small_packed()
 
     def _shs48_rows(self, mask):
@@ -398,7 +398,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             return p.clone() if p.is_cuda else p.cuda()
         if self.sh_on_host:
             return p[mask.cpu()].cuda()
-        return p[mask]
+        return utils.select_rows(p, mask)
 
     def reset_opacity(self):
         new = utils.inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))

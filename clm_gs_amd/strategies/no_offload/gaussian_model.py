@@ -89,24 +89,24 @@ class GaussianModelNoOffload(BaseGaussianModel):
         keep = ~mask
         for name in self._GROUPS:
             cur = getattr(self, self._attr(name)).detach()
-            self._replace(name, cur[keep].contiguous(), lambda s: s[keep].contiguous())
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
+            self._replace(name, utils.select_rows(cur, keep).contiguous(), lambda s: utils.select_rows(s, keep).contiguous())
+        self.xyz_gradient_accum = utils.select_rows(self.xyz_gradient_accum, keep)
+        self.denom = utils.select_rows(self.denom, keep)
+        self.max_radii2D = utils.select_rows(self.max_radii2D, keep)
 
     def permute_rows(self, order):
         order = order.to(self._xyz.device)
         assert order.numel() == self._xyz.shape[0]
         for name in self._GROUPS:
             cur = getattr(self, self._attr(name)).detach()
-            self._replace(name, cur[order].contiguous(), lambda s: s[order].contiguous())
-        self.xyz_gradient_accum = self.xyz_gradient_accum[order]
-        self.denom = self.denom[order]
-        self.max_radii2D = self.max_radii2D[order]
+            self._replace(name, utils.gather_rows(cur, order), lambda s: utils.gather_rows(s, order))
+        self.xyz_gradient_accum = utils.gather_rows(self.xyz_gradient_accum, order)
+        self.denom = utils.gather_rows(self.denom, order)
+        self.max_radii2D = utils.gather_rows(self.max_radii2D, order)
 
     def _shs48_rows(self, mask):
         f = self.get_features.detach()
-        f = f if mask is None else f[mask]
+        f = f if mask is None else utils.select_rows(f, mask)
         return f.reshape(f.shape[0], 48)
 
     def reset_opacity(self):

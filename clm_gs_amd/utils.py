@@ -209,3 +209,22 @@ def morton_order(xyz, bits=16):
             return v
         code = spread(q[:, 0]) | (spread(q[:, 1]) << 1)
         return torch.sort(code, stable=True).indices
+
+
+def select_rows(t, mask, chunk=1 << 25):
+    """t[mask] (bool row mask) for row tables of any size: tables of more than 2^25 rows are selected in
+    chunks of source rows (see gather_rows: advanced indexing of [N,4] tables misbehaved beyond ~35 M rows)."""
+    n = t.shape[0]
+    if n <= chunk:
+        return t[mask]
+    return torch.cat([t[a:a + chunk][mask[a:a + chunk]] for a in range(0, n, chunk)], dim=0)
+
+
+def gather_rows(t, order, chunk=1 << 23):
+    """t[order] for row tables of any size, gathered in chunks of rows (a single advanced-indexing call
+    over a 102 M-row table returned rows of zeros for part of the output on ROCm 7 / torch 2.10)."""
+    out = torch.empty_like(t)
+    n = order.numel()
+    for a in range(0, n, chunk):
+        out[a:a + chunk] = t[order[a:a + chunk]]
+    return out
