@@ -31,6 +31,17 @@ constexpr int TILE = 16;
 constexpr int PPL = 4;        // pixels per lane (one per 8x8 quadrant)
 constexpr float ALPHA_MIN = 1.f / 255.f;
 constexpr float T_EPS = 1e-4f;
+// The staging lane stores the conic pre-multiplied by log2(e) (and the 1/2 of the quadratic form), so
+// the blend loops evaluate  s = log2(e) * sigma  with three FMA-class operations and feed v_exp_f32
+// (a base-2 exponential) directly: two VALU fewer per (entry, quadrant) in both tile kernels.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float CONIC_DIAG = 0.5f * LOG2E, CONIC_DIAG_INV = 2.f / LOG2E, CONIC_OFF_INV = 1.f / LOG2E;
+
+// s = log2(e) * (0.5 (a dx^2 + c dy^2) + b dx dy) from the pre-scaled conic; identical code in the
+// forward and the backward kernel, so both see the same alpha for every (entry, pixel)
+__device__ __forceinline__ float scaled_sigma(float as, float bs, float cs, float dx, float dy) {
+  return fmaf(cs * dy, dy, fmaf(as * dx, dx, (bs * dx) * dy));
+}
 
 // Per-Gaussian raster record, one 64 B line: {x, y, opacity, conic.a | conic.b, conic.c, r, g |
 // b, -, -, - | -}.  The tile kernels gather ONE line per (Gaussian, tile) instead of touching
@@ -176,7 +187,9 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const int bn = __popcll(bal);
     __syncthreads();
     if (mask) {
-      sm.a[pos] = A; sm.b[pos] = B; sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
+      sm.a[pos] = make_float4(A.x, A.y, A.z, A.w * CONIC_DIAG);
+      sm.b[pos] = make_float4(B.x * LOG2E, B.y * CONIC_DIAG, B.z, B.w);
+      sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
     }
     __syncthreads();
     for (int t = 0; t < bn; ++t) {
@@ -190,8 +203,8 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       for (int k = 0; k < PPL; ++k) {
         if (meta & (1 << k)) {  // wave-uniform: this quadrant can be touched
           const float dx = RA.x - px[k], dy = RA.y - py[k];
-          const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
-          const float alpha = fminf(0.999f, RA.z * __expf(-sigma));
+          const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
+          const float alpha = fminf(0.999f, RA.z * __builtin_amdgcn_exp2f(-sigma));
           const bool valid = alive[k] && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           const float next_T = T[k] * (1.f - alpha);
           const bool term = valid && (next_T <= T_EPS);
@@ -355,7 +368,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const int bn = __popcll(bal);
     __syncthreads();
     if (mask) {
-      sm.a[pos] = A; sm.b[pos] = B; sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
+      sm.a[pos] = make_float4(A.x, A.y, A.z, A.w * CONIC_DIAG);
+      sm.b[pos] = make_float4(B.x * LOG2E, B.y * CONIC_DIAG, B.z, B.w);
+      sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
       sm.id[pos] = PART ? pid : gid;
     }
     __syncthreads();
@@ -378,8 +393,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
         if (meta & (1 << k)) {  // wave-uniform
           const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
           const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
-          const float sigma = 0.5f * (RA.w * dx * dx + RB.y * dy * dy) + RB.x * dx * dy;
-          const float gex = __expf(-sigma);
+          const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
+          const float gex = __builtin_amdgcn_exp2f(-sigma);
           const float oa = RA.z * gex;
           const float alpha = fminf(0.999f, oa);
           const bool valid = (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
@@ -390,14 +405,14 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
             const float fac = alpha * T[k];
             g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
             const float cv = RB.z * vr[k] + RB.w * vg[k] + rblue * vb[k];
-            const float v_alpha = T[k] * cv - ra * Bk[k];
-            if (oa <= 0.999f) {
-              const float w = -oa * v_alpha;  // v_sigma
-              const float wdx = w * dx, wdy = w * dy;
-              Sx += wdx; Sy += wdy;
-              Sxx += wdx * dx; Sxy += wdx * dy; Syy += wdy * dy;
-              g_o += gex * v_alpha;
-            }
+            // a saturated alpha (o * G > 0.999, clamped) passes no gradient to sigma / opacity: a select,
+            // not a branch (the divergent form cost an exec save/restore and six register clears per pass)
+            const float v_alpha = (oa <= 0.999f) ? T[k] * cv - ra * Bk[k] : 0.f;
+            const float w = -oa * v_alpha;  // v_sigma
+            const float wdx = w * dx, wdy = w * dy;
+            Sx += wdx; Sy += wdy;
+            Sxx += wdx * dx; Sxy += wdx * dy; Syy += wdy * dy;
+            g_o += gex * v_alpha;
             Bk[k] += fac * cv;
           }
         }
@@ -432,7 +447,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
         float4 r0 = z4, r1 = z4, r2 = z4;
         if (hit) {  // moments -> gradients here (the conic is at hand): x y ca cb | cc r g b | o
           const float4 m0 = a[0], m1 = a[1];
-          const float ca = sm.a[lane].w, cb = sm.b[lane].x, cc = sm.b[lane].y;
+          const float ca = sm.a[lane].w * CONIC_DIAG_INV, cb = sm.b[lane].x * CONIC_OFF_INV,
+                      cc = sm.b[lane].y * CONIC_DIAG_INV;  // back from the pre-scaled form
           r0 = make_float4(ca * m0.x + cb * m0.y, cb * m0.x + cc * m0.y, 0.5f * m0.z, m0.w);
           r1 = make_float4(0.5f * m1.x, m1.y, m1.z, m1.w);
           r2 = make_float4(a[2].x, 0.f, 0.f, 0.f);
@@ -444,7 +460,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       // all nine atomics of a Gaussian land in its one 64 B gradient line
       float* dst = packed_grad + 4 * REC_F4 * (size_t)sm.id[lane];
       const float* a = sm.acc[lane];
-      const float ca = sm.a[lane].w, cb = sm.b[lane].x, cc = sm.b[lane].y;
+      const float ca = sm.a[lane].w * CONIC_DIAG_INV, cb = sm.b[lane].x * CONIC_OFF_INV,
+                      cc = sm.b[lane].y * CONIC_DIAG_INV;  // back from the pre-scaled form
       atomicAdd(dst + 0, ca * a[0] + cb * a[1]);  // x
       atomicAdd(dst + 1, cb * a[0] + cc * a[1]);  // y
       atomicAdd(dst + 2, 0.5f * a[2]);            // conic a

@@ -113,7 +113,7 @@ class UnifiedAdam(torch.optim.Optimizer):
         assert not isinstance(self.gpu_adam, SelectiveAdam)
         groups = {g["name"]: g for g in self.gpu_adam.param_groups}
         order = [groups[n] for n in ("xyz", "opacity", "scaling", "rotation")]
-        ps, ms, vs, lrs = [], [], [], []
+        ps, ms, vs, lrs, steps = [], [], [], [], []
         step = None
         cache = self.__dict__.setdefault("_gpu_steps", {})
         for group in order:
@@ -127,12 +127,13 @@ class UnifiedAdam(torch.optim.Optimizer):
                 cache.clear() if len(cache) > 64 else None
                 cache[id(st["step"])] = int(st["step"].item())
             cache[id(st["step"])] += 1
-            st["step"] += 1
+            steps.append(st["step"])
             step = cache[id(st["step"])] if step is None else step
             assert cache[id(st["step"])] == step, "the four groups step together"
             assert p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()
             ps.append(p.data_ptr()); ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
             lrs.append(float(group["lr"]))
+        torch._foreach_add_(steps, 1)  # the four torch-Adam step counters: one launch instead of four
         g0 = order[0]
         arr = lambda xs: (ctypes.c_void_p * 4)(*xs)
         L = _lib.lib()

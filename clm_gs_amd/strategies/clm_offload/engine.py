@@ -249,6 +249,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
     lazy_mode = gaussians.lazy_rows and not args.stop_update_param
+    fused = getattr(args, "fused_front_end", True)
+    mode = getattr(args, "overlap_cameras", True)
+    mode = {True: "pipeline", False: "off"}.get(mode, mode)
+    pipelined = fused and mode == "pipeline"
+    # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
+    use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
+                  and not args.stop_update_param)
     need_mask = touched_rows is None or args.sparse_adam or dp.active() or not lazy_mode
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
@@ -272,6 +279,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     st = row_adam.state[params]
     default_stream = torch.cuda.current_stream()
     side_event = None
+    split_catch_up = False
     col_lr = row_adam._col_lr(params.device)
 
     def row_update(rows, zero_grad_rows=False):
@@ -299,7 +307,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
-        gaussians.catch_up_rows(touched_rows, to_step=step - 1)
+        # Camera pipeline: only camera 0's rows are brought up to date before the pipeline starts; camera
+        # k's rows follow on the front stream right before camera k's projection, i.e. while camera k-1
+        # is being blended (rows an earlier camera already brought up to date are skipped by their stamp,
+        # so every row is stepped once and never after a backward has accumulated into it).
+        split_catch_up = (pipelined and bsz > 1 and getattr(args, "split_catch_up", True)
+                          and not getattr(args, "front_ahead", False))
+        gaussians.catch_up_rows(filters[0] if split_catch_up else touched_rows, to_step=step - 1)
     elif not args.stop_update_param and not args.sparse_adam:
         # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
         untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
@@ -310,10 +324,6 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             side_event.record(comm_stream)
         untouched_rows.record_stream(comm_stream)
 
-    fused = getattr(args, "fused_front_end", True)
-    # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
-    use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
-                  and not args.stop_update_param)
     small_pk = small_gk = stats_d = None
     if use_packed:
         small_pk, small_gk = gaussians.small_packed(), gaussians.small_grad()
@@ -329,8 +339,6 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # events so the read-modify-write gradient sums stay ordered.
         from ...fused import (camera_backward, camera_forward_finish, camera_front, camera_loss,
                               train_one_camera)
-        mode = getattr(args, "overlap_cameras", True)
-        mode = {True: "pipeline", False: "off"}.get(mode, mode)
         n_lanes = max(1, int(getattr(args, "overlap_lanes", 2)))
         sts = getattr(gaussians, "_clmgs_streams", None)
         if sts is None or len(sts["mem"]) < max(2, n_lanes):
@@ -386,6 +394,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             fronts = (s_front, sts["front2"]) if ahead else (s_front, s_front)
 
             def _front(k):
+                if k >= 1 and split_catch_up:
+                    with torch.cuda.stream(s_front):
+                        gaussians.catch_up_rows(filters[k], to_step=step - 1)
                 with _lib.host_region("camera_front"):
                     return camera_front(
                         gaussians, batched_cameras[k], filters[k], params.data, 1, background,

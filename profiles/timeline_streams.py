@@ -1,5 +1,5 @@
 """Per-queue timeline of the last training step of a rocprofv3 rocpd database:
-python profiles/timeline_streams.py results.db [window_ms]
+python profiles/timeline_streams.py results.db [window_ms | stepK]
 Every kernel of the window with its HSA queue, start offset and duration, then for each queue the
 busy time and, for the queue that runs the tile kernels, its idle gaps and what the other queues ran
 meanwhile (how well the kernel-type streams overlap)."""
@@ -7,12 +7,18 @@ import sqlite3
 import sys
 
 db = sys.argv[1]
-win_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 31.0
+arg = sys.argv[2] if len(sys.argv) > 2 else "31"
 c = sqlite3.connect(db)
 rows = list(c.execute("select name, start, end, queue_id, grid_x, workgroup_x, lds_size from kernels order by start"))
-t_end = max(r[2] for r in rows)
-t0 = t_end - win_ms * 1e6
-rows = [r for r in rows if r[1] >= t0]
+if arg.startswith("step"):  # stepK: the K-th batch from the end, between two visibility_bits launches
+    marks = [r[1] for r in rows if "visibility_bits" in r[0]]
+    k = int(arg[4:] or 2)
+    t0, t_end = marks[-k - 1], marks[-k]
+    rows = [r for r in rows if t0 <= r[1] < t_end]
+else:
+    t_end = max(r[2] for r in rows)
+    t0 = t_end - float(arg) * 1e6
+    rows = [r for r in rows if r[1] >= t0]
 KEYS = ("rasterize_bwd", "rasterize_fwd", "partials_sum", "preprocess_bwd", "preprocess_fwd", "loss_bwd",
         "loss_fwd", "adam_rows", "adam_small", "catch_up", "radix_scan_rows", "radix_scatter",
         "radix_onesweep", "radix_hist_all", "radix_hist", "radix_scan_digits", "isect2_keys", "isect2_count",
