@@ -367,7 +367,9 @@ adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < rows * 3; i += SA_ROWS) {
       packed_p[row0 * 3 + i] = reinterpret_cast<const float4*>(sp)[i];
-      packed_g[row0 * 3 + i] = z;
+      const float4 gq = reinterpret_cast<const float4*>(sg)[i];  // rows the batch did not touch are
+      if (gq.x != 0.f || gq.y != 0.f || gq.z != 0.f || gq.w != 0.f)  // zero already: nothing to clear
+        packed_g[row0 * 3 + i] = z;
     }
   }
 }

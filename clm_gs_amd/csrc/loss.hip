@@ -189,6 +189,8 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
   const float vv = v[0];
+  float res[3][4];  // the three channels of a pixel leave together (below): one full 12 B per pixel
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
     for (int i = tid; i < LH * LH; i += 256) {
@@ -236,14 +238,30 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         const int y = y0 + r4 + o, x = x0 + col;
+        res[c][o] = 0.f;
         if (y < H && x < W) {
           const int64_t oi = c * img.sc + y * img.sy + x * img.sx;
           const float xv = img.p[oi];
           const float yv = gt_val(gt, c * plane + (size_t)y * W + x);
           const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
           const float dss = g[0][o] + 2.f * xv * g[1][o] + yv * g[2][o];
-          v_img[oi] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
+          res[c][o] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
         }
+      }
+    }
+  }
+  // Channel-interleaved ([H,W,3]) cotangent images: a store per channel pass touched every 64 B line
+  // three times, a third of it each (WRITE_SIZE was 3x the image); back to back the three partial
+  // stores of a line merge before they leave the L2.
+  {
+    const int col = tid & 31, r4 = (tid >> 5) * 4;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int y = y0 + r4 + o, x = x0 + col;
+      if (y < H && x < W) {
+        const int64_t ob = y * img.sy + x * img.sx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v_img[ob + c * img.sc] = res[c][o];
       }
     }
   }

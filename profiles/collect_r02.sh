@@ -13,11 +13,19 @@ timeout 200 python bench.py --config bicycle6m --steps 10 --warmup 3 --no-cpu-ba
 timeout 300 python bench.py --config bigcity102m --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_bigcity102m_1gpu.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_s /tmp/pmcF /tmp/pmcW /tmp/pmcS /tmp/prof_h
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --no-cpu-baseline --no-host-leg > $O/prof_s.log 2>&1
+# kernel trace of the timed steps only (--no-kernel-timing: no instrumented pass, no single-stream batch
+# after them); the timelines take ONE pipelined batch, delimited by two visibility_bits launches
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-host-leg --no-kernel-timing > $O/prof_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py "$DB" 170 > $O/kernel_stats.csv
-python $R/profiles/timeline.py $DB 30 > $O/timeline_step.txt 2>&1
-python $R/profiles/timeline_streams.py $DB 30 > $O/timeline_streams.txt 2>&1
+python $R/profiles/timeline.py $DB step3 > $O/timeline_step.txt 2>&1
+python $R/profiles/timeline_streams.py $DB step3 > $O/timeline_streams.txt 2>&1
+# the same step on ONE stream (solo kernel durations, launch gaps)
+rm -rf /tmp/prof_1
+timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_1 -o st -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-host-leg --no-kernel-timing --opt overlap_cameras=false > $O/prof_1.log 2>&1
+DB1=$(find /tmp/prof_1 -name "*.db" | head -1)
+python $R/profiles/timeline.py $DB1 step2 > $O/timeline_step_single_stream.txt 2>&1
+python $R/profiles/timeline_streams.py $DB1 step2 > $O/timeline_streams_single_stream.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-host-leg > $O/pmcF.log 2>&1
 python $R/profiles/pmc_summary.py $(find /tmp/pmcF -name "*counter_collection.csv" | head -1) > $O/pmc_fetch_size.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-host-leg > $O/pmcW.log 2>&1
