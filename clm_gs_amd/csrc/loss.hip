@@ -62,7 +62,16 @@ loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
   __shared__ float la[LS_RING][LS_PITCH], lb[LS_RING][LS_PITCH];
   const int lane = threadIdx.x;
-  const int x0 = blockIdx.x * LS_W, y0 = blockIdx.y * LS_ROWS, c = blockIdx.z;
+  // 1-D grid, block id -> (strip, channel) so that the three channel passes of one strip are ids i,
+  // i+8, i+16: workgroups go to the 8 XCDs round-robin by id, so the three land on the SAME XCD close
+  // in time and the channel-interleaved image lines (each pass uses a third of every line) are
+  // fetched from HBM once instead of three times.
+  const int n_sx = (W + LS_W - 1) / LS_W, n_sy = (H + LS_ROWS - 1) / LS_ROWS;
+  const int grp = blockIdx.x / 24, rem = blockIdx.x - grp * 24;
+  const int c = rem >> 3, strip = grp * 8 + (rem & 7);
+  if (strip >= n_sx * n_sy) return;
+  const int by = strip / n_sx, bx = strip - by * n_sx;
+  const int x0 = bx * LS_W, y0 = by * LS_ROWS;
   const size_t plane = (size_t)H * W;
   const int xo = x0 + lane;                              // output column
   const int n_rows = min(LS_ROWS, H - y0) + 2 * LR;      // input rows to walk
@@ -168,7 +177,7 @@ loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float
   }
   const float tl1 = wave_sum(l1), tss = wave_sum(ss);
   if (lane == 0) {
-    const int slot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (LOSS_SLOTS - 1);
+    const int slot = ((c * n_sy + by) * n_sx + bx) & (LOSS_SLOTS - 1);
     atomicAdd(partials + 2 * slot, tl1);
     atomicAdd(partials + 2 * slot + 1, tss);
   }
@@ -185,7 +194,12 @@ loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const
                 const float* __restrict__ m2, const float* __restrict__ m3, float* __restrict__ v_img) {
   __shared__ float sm[3][LH][LH + 1];
   __shared__ float hz[3][LH][LT + 1];
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  // XCD-aware tile order: each XCD's L2 sees a contiguous run of tiles, so the 5-pixel halos shared
+  // with the neighbouring tiles are fetched from HBM once
+  const int n_tx = (W + LT - 1) / LT, n_ty = (H + LT - 1) / LT;
+  const int tile = (int)xcd_remap(blockIdx.x, (unsigned)(n_tx * n_ty));
+  const int tyi = tile / n_tx, txi = tile - tyi * n_tx;
+  const int x0 = txi * LT, y0 = tyi * LT;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
   const float vv = v[0];
@@ -279,7 +293,8 @@ extern "C" int clmgs_l1_ssim_loss_fwd(void* stream, int H, int W, const float* i
   CLMGS_CHECK_ARG(H >= 1 && W >= 1 && img && gt_u8 && partials);
   CLMGS_CHECK_ARG((m1 && m2 && m3) || (!m1 && !m2 && !m3));
   ImgView v{img, stride_c, stride_y, stride_x};
-  dim3 grid(ceil_div(W, LS_W), ceil_div(H, LS_ROWS), 3);
+  const int64_t strips = (int64_t)ceil_div(W, LS_W) * ceil_div(H, LS_ROWS);
+  dim3 grid((unsigned)(24 * ceil_div(strips, 8)));
   hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, H, W, v, gt_u8,
                      partials, m1, m2, m3);
   CLMGS_LAUNCH_CHECK();
@@ -293,7 +308,7 @@ extern "C" int clmgs_l1_ssim_loss_bwd(void* stream, int H, int W, const float* i
   CLMGS_CHECK_ARG(H >= 1 && W >= 1 && img && gt_u8 && v_loss && m1 && m2 && m3 && v_img);
   ImgView v{img, stride_c, stride_y, stride_x};
   const double numel = 3.0 * (double)H * (double)W;
-  dim3 grid(ceil_div(W, LT), ceil_div(H, LT));
+  dim3 grid((unsigned)(ceil_div(W, LT) * ceil_div(H, LT)));
   hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, v, gt_u8, v_loss,
                      (float)((1.0 - lambda_dssim) / numel), (float)(lambda_dssim / numel), m1, m2, m3,
                      v_img);
