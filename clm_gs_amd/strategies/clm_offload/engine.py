@@ -279,7 +279,6 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     st = row_adam.state[params]
     default_stream = torch.cuda.current_stream()
     side_event = None
-    split_catch_up = False
     col_lr = row_adam._col_lr(params.device)
 
     def row_update(rows, zero_grad_rows=False):
@@ -307,13 +306,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
-        # Camera pipeline: only camera 0's rows are brought up to date before the pipeline starts; camera
-        # k's rows follow on the front stream right before camera k's projection, i.e. while camera k-1
-        # is being blended (rows an earlier camera already brought up to date are skipped by their stamp,
-        # so every row is stepped once and never after a backward has accumulated into it).
-        split_catch_up = (pipelined and bsz > 1 and getattr(args, "split_catch_up", True)
-                          and not getattr(args, "front_ahead", False))
-        gaussians.catch_up_rows(filters[0] if split_catch_up else touched_rows, to_step=step - 1)
+        gaussians.catch_up_rows(touched_rows, to_step=step - 1)
     elif not args.stop_update_param and not args.sparse_adam:
         # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
         untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
@@ -365,12 +358,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # The tile kernels' one-wave workgroups refill every freed wave slot of the chip, so the
             # multi-wave workgroups of the front end wait for them.  When the front end is the long
             # pole (many visible rows per tile: 53 at 28 M / 4K, +2 %) some CUs are kept out of the
-            # tile stream's CU mask; with light front ends (19 rows per tile at 10 M: -2.5 %) the
+            # tile stream's CU mask (measured at 28 M, three interleaved rounds: 32 CUs 147.5, 48 149.8,
+            # 64 150.1, 96 146.8 img/s); with light front ends (19 rows per tile at 10 M: -2.5 %) the
             # tile kernels keep the whole chip.  raster_reserve_cus: -1 = this rule, >= 0 = fixed.
             reserve = int(getattr(args, "raster_reserve_cus", -1))
             if reserve < 0:
                 rows_per_tile = sum(int(f.shape[0]) for f in filters) / float(max(1, bsz) * max(1, n_tiles))
-                reserve = 32 if rows_per_tile >= 32.0 else 0
+                reserve = 64 if rows_per_tile >= 32.0 else 0
             if reserve > 0:
                 if reserve not in sts["raster_masked"]:
                     sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
@@ -394,9 +388,6 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             fronts = (s_front, sts["front2"]) if ahead else (s_front, s_front)
 
             def _front(k):
-                if k >= 1 and split_catch_up:
-                    with torch.cuda.stream(s_front):
-                        gaussians.catch_up_rows(filters[k], to_step=step - 1)
                 with _lib.host_region("camera_front"):
                     return camera_front(
                         gaussians, batched_cameras[k], filters[k], params.data, 1, background,
