@@ -57,10 +57,11 @@ ALGO_BYTES = {
     "clmgs_ssim_bwd": lambda n, V, I, P, T: (36 + 24 + 12) * P,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# Calibrated wave64 VALU issue rate of the whole chip (profiles/valu_calib.hip -> profiles/r02_valu_calib.jsonl:
-# independent v_fma_f32 chains, 4-8 waves / SIMD: 856-896 G wave-instructions/s; v_exp / v_rcp / v_permlane32_swap
-# issue at ~1/3 of that rate, DPP adds at ~2/3): the compute-side roofline of the alpha-blend tile kernels
-VALU_PEAK_G = 880.0
+# VALU issue rate of the chip (profiles/corun_probe.hip, "fma alone": 1 080 G wave64 v_fma_f32 per second =
+# 1024 SIMDs x 1 instruction / 2 cycles x the 2.1 GHz the chip holds under an all-VALU load; the 256-thread
+# harness of profiles/valu_calib.hip reached 870-896 and gives the RELATIVE costs: transcendentals and
+# permlane swaps 2.9 slots, DPP adds 1.5).  The compute-side roofline of the alpha-blend kernels.
+VALU_PEAK_G = 1075.0
 
 
 def parse():
@@ -546,9 +547,10 @@ def main():
                                  "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
                                  "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
                                  "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
-                                         "durations from this run; peak = calibrated plain-FMA issue rate -- the kernel's "
-                                         "exp / rcp / DPP / permlane instructions cost 1.5-3 slots each, so frac "
-                                         "UNDER-states how busy the VALU pipes are (DESIGN.md section 3)"}
+                                         "durations from this run; peak = measured plain-FMA issue rate "
+                                         "(profiles/r02_corun_probe.jsonl) -- the kernel's exp / rcp / DPP / permlane "
+                                         "instructions cost 1.5-3 issue slots each: weighted by those costs it needs "
+                                         "1.22x its instruction count in slots (DESIGN.md section 3)"}
                                 if valu else None),
                     "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
                     "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "
