@@ -52,3 +52,26 @@ def test_bucket_size_properties():
         assert b >= prev
         prev = b
     assert len({bucket_size(int(8.6e6 * (1 + 0.05 * (k - 10) / 10))) for k in range(21)}) <= 3
+
+
+def test_row_permutation_helpers():
+    """utils.gather_rows / select_rows (chunked replacements of t[order] / t[mask] for very long row
+    tables) equal plain indexing whatever the chunk size; utils.morton_order is a permutation that puts
+    points of the same ground-plane cell next to each other."""
+    from clm_gs_amd import utils
+    g = torch.Generator().manual_seed(5)
+    for shape in ((1000,), (1000, 4), (1000, 16, 3)):
+        t = torch.randn(*shape, generator=g)
+        order = torch.randperm(1000, generator=g)
+        mask = torch.rand(1000, generator=g) < 0.3
+        for chunk in (1, 7, 128, 1000, 4096):
+            assert torch.equal(utils.gather_rows(t, order, chunk=chunk), t[order])
+            assert torch.equal(utils.select_rows(t, mask, chunk=chunk), t[mask])
+    assert utils.select_rows(torch.zeros(0, 4), torch.zeros(0, dtype=torch.bool)).shape == (0, 4)
+    xyz = torch.rand(5000, 3, generator=g) * torch.tensor([100.0, 100.0, 3.0])
+    perm = utils.morton_order(xyz)
+    assert torch.equal(torch.sort(perm).values, torch.arange(5000))
+    p = xyz[perm][:, :2]
+    step_sorted = (p[1:] - p[:-1]).norm(dim=1).median()
+    step_random = (xyz[1:, :2] - xyz[:-1, :2]).norm(dim=1).median()
+    assert step_sorted < 0.1 * step_random  # consecutive rows are spatial neighbours
