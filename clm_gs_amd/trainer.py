@@ -4,10 +4,13 @@ Keeps what the published numbers depend on: the image-strided iteration counter
 (train.py:202-204), xyz LR schedule per image index, SH-degree ramp every 1000 images
 (:253-254), the engine call (:316-432), gsplat_densification (:452), the no_offload optimizer
 epilogue (:533-578), the end-to-end timer that pauses during evaluation (:438-447, utils/timer.py:
-87-111), and the exact log strings release_scripts/log2csv.py:54-102 scrapes.  Dataset readers,
-checkpoint directories and CLI plumbing are out of scope: cameras are handed in as objects.
+87-111), and the exact log strings release_scripts/log2csv.py:54-102 scrapes.  `training` takes cameras
+as objects; `train_from_colmap` (and `python -m clm_gs_amd.trainer -s ... -m ...`) builds them from a COLMAP
+directory (colmap_scene.py).  MatrixCity / Blender readers, checkpoint directories and the rest of the
+reference's CLI are out of scope.
 """
 import gc
+import os
 import random
 import time
 
@@ -188,3 +191,67 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     log_file.write(memory_line(iteration, gbsz, gaussians, what="final"))
     log_file.write("Max Memory usage: {} GB.\n".format(torch.cuda.max_memory_allocated() / 2 ** 30))
     return timer
+
+
+def train_from_colmap(source_path, model_path, strategy="clm_offload", iterations=None, eval=False, resolution=1,
+                      images="images", test_iterations=(), save=True, **arg_overrides):
+    """A COLMAP directory -> trained model (row f1): `colmap_scene.load_colmap_scene` (cameras, held-out
+    split, scene radius, sparse points) -> `create_from_pcd` with `spatial_lr_scale = cameras_extent` ->
+    `training_setup` -> `training` (log lines of the reference in `<model_path>/python_ws=1_rk=0.log`) ->
+    `point_cloud/iteration_N/point_cloud.ply` (scene/__init__.py:41-143, train.py:60-131 for the order of
+    these steps).  `strategy`: clm_offload | no_offload | naive_offload; `arg_overrides`: any flag of
+    `utils.default_args`.  Returns (gaussians, scene, timer)."""
+    from .colmap_scene import load_colmap_scene
+    from .strategies.clm_offload import GaussianModelCLMOffload
+    from .strategies.naive_offload import GaussianModelNaiveOffload
+    from .strategies.no_offload import GaussianModelNoOffload
+    assert strategy in ("clm_offload", "no_offload", "naive_offload"), strategy
+    args = utils.default_args(**arg_overrides)
+    setattr(args, strategy, True)
+    args.source_path, args.model_path, args.eval = source_path, model_path, bool(eval)
+    if iterations is not None:
+        args.iterations = int(iterations)
+    utils.set_args(args)
+    scene = load_colmap_scene(source_path, images=images, eval=eval, resolution=resolution, device="cuda")
+    if scene.point_cloud is None:
+        raise ValueError(f"{source_path}/sparse/0 holds no points3D.bin / points3D.txt to initialise from")
+    sizes = {(c.image_height, c.image_width) for c in scene.train_cameras + scene.test_cameras}
+    assert len(sizes) == 1, f"all images must share one size (utils.get_img_width/height are global): {sizes}"
+    h, w = next(iter(sizes))
+    utils.set_img_size(h, w)
+    utils.set_cur_iter(1)
+    gaussians = {"clm_offload": GaussianModelCLMOffload, "no_offload": GaussianModelNoOffload,
+                 "naive_offload": GaussianModelNaiveOffload}[strategy](args.sh_degree)
+    gaussians.create_from_pcd(scene.point_cloud, scene.cameras_extent)
+    gaussians.training_setup(args)
+    os.makedirs(model_path, exist_ok=True)
+    with open(os.path.join(model_path, "python_ws=1_rk=0.log"), "w") as log_file:
+        timer = training(gaussians, scene, scene.train_cameras, scene.test_cameras, log_file,
+                         iterations=args.iterations, test_iterations=test_iterations)
+    if save:
+        if hasattr(gaussians, "flush_lazy_rows"):
+            gaussians.flush_lazy_rows()
+        gaussians.save_ply(os.path.join(model_path, "point_cloud", f"iteration_{args.iterations}", "point_cloud.ply"))
+    return gaussians, scene, timer
+
+
+if __name__ == "__main__":  # python -m clm_gs_amd.trainer -s <colmap dir> -m <output dir> [--clm_offload] ...
+    import argparse
+    ap = argparse.ArgumentParser(description="train a 3DGS model from a COLMAP directory (flag names of train.py)")
+    ap.add_argument("-s", "--source_path", required=True)
+    ap.add_argument("-m", "--model_path", required=True)
+    ap.add_argument("-i", "--images", default="images")
+    ap.add_argument("-r", "--resolution", type=float, default=1)
+    ap.add_argument("--eval", action="store_true")
+    ap.add_argument("--iterations", type=int, default=30000)
+    ap.add_argument("--bsz", type=int, default=4)
+    ap.add_argument("--test_iterations", type=int, nargs="*", default=[7000, 30000])
+    grp = ap.add_mutually_exclusive_group()
+    for s_ in ("clm_offload", "no_offload", "naive_offload"):
+        grp.add_argument("--" + s_, action="store_true")
+    ap.add_argument("--sh_residency", choices=["hbm", "host"], default="hbm")
+    a = ap.parse_args()
+    strat = "no_offload" if a.no_offload else ("naive_offload" if a.naive_offload else "clm_offload")
+    _, _, t = train_from_colmap(a.source_path, a.model_path, strategy=strat, iterations=a.iterations, eval=a.eval,
+                                resolution=a.resolution, images=a.images, test_iterations=tuple(a.test_iterations),
+                                bsz=a.bsz, sh_residency=a.sh_residency)
