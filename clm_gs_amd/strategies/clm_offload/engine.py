@@ -364,7 +364,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             reserve = int(getattr(args, "raster_reserve_cus", -1))
             if reserve < 0:
                 rows_per_tile = sum(int(f.shape[0]) for f in filters) / float(max(1, bsz) * max(1, n_tiles))
-                reserve = 64 if rows_per_tile >= 32.0 else 0
+                # small images (BigCity 1080p: 8 160 tiles = 1.6 rounds of the chip's wave slots) lose
+                # more to the shorter rounds than the front end gains: 0 CUs 231-239, 32 233-234, 64 223-232 img/s
+                reserve = 64 if rows_per_tile >= 32.0 and n_tiles >= 20000 else 0
             if reserve > 0:
                 if reserve not in sts["raster_masked"]:
                     sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
