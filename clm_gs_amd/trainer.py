@@ -225,9 +225,13 @@ def train_from_colmap(source_path, model_path, strategy="clm_offload", iteration
     gaussians.create_from_pcd(scene.point_cloud, scene.cameras_extent)
     gaussians.training_setup(args)
     os.makedirs(model_path, exist_ok=True)
-    with open(os.path.join(model_path, "python_ws=1_rk=0.log"), "w") as log_file:
-        timer = training(gaussians, scene, scene.train_cameras, scene.test_cameras, log_file,
-                         iterations=args.iterations, test_iterations=test_iterations)
+    prev_log = utils.get_log_file()
+    try:
+        with open(os.path.join(model_path, "python_ws=1_rk=0.log"), "w") as log_file:
+            timer = training(gaussians, scene, scene.train_cameras, scene.test_cameras, log_file,
+                             iterations=args.iterations, test_iterations=test_iterations)
+    finally:
+        utils.set_log_file(prev_log)  # never leave a closed file as the process-wide log
     if save:
         if hasattr(gaussians, "flush_lazy_rows"):
             gaussians.flush_lazy_rows()
