@@ -57,11 +57,13 @@ ALGO_BYTES = {
     "clmgs_ssim_bwd": lambda n, V, I, P, T: (36 + 24 + 12) * P,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue rate of the chip (profiles/corun_probe.hip, "fma alone": 1 080 G wave64 v_fma_f32 per second =
-# 1024 SIMDs x 1 instruction / 2 cycles x the 2.1 GHz the chip holds under an all-VALU load; the 256-thread
-# harness of profiles/valu_calib.hip reached 870-896 and gives the RELATIVE costs: transcendentals and
-# permlane swaps 2.9 slots, DPP adds 1.5).  The compute-side roofline of the alpha-blend kernels.
-VALU_PEAK_G = 1075.0
+# VALU issue rate of the chip (profiles/ilp_probe.hip -> r02_ilp_probe.jsonl: one-wave workgroups of v_fma_f32
+# chains): 1 140 G wave64 instructions/s with 8 waves/SIMD resident, but only 870-914 with the 5 waves/SIMD the
+# backward tile kernel's 96 VGPRs allow (825 at 4, 675 at 2): occupancy, not instruction-level parallelism,
+# sets the issue rate.  profiles/valu_calib.hip gives the RELATIVE costs (exp / rcp / permlane swap 2.9 slots,
+# DPP add 1.5).  The compute-side roofline of the alpha-blend kernels.
+VALU_PEAK_G = 1140.0
+VALU_CEILING_5_WAVES_G = 900.0
 
 
 def parse():
@@ -546,11 +548,15 @@ def main():
                                  "frac": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / VALU_PEAK_G, 4),
                                  "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
                                  "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
+                                 "ceiling_at_kernel_occupancy": VALU_CEILING_5_WAVES_G,
+                                 "frac_solo_of_ceiling": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_CEILING_5_WAVES_G, 4)
+                                 if dom in solo else None,
                                  "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
-                                         "durations from this run; peak = measured plain-FMA issue rate "
-                                         "(profiles/r02_corun_probe.jsonl) -- the kernel's exp / rcp / DPP / permlane "
-                                         "instructions cost 1.5-3 issue slots each: weighted by those costs it needs "
-                                         "1.22x its instruction count in slots (DESIGN.md section 3)"}
+                                         "durations from this run; peak = plain-FMA issue rate at 8 waves/SIMD, ceiling = "
+                                         "the same at the kernel's 5 waves/SIMD (profiles/r02_ilp_probe.jsonl) -- the "
+                                         "kernel's exp / rcp / DPP / permlane instructions cost 1.5-3 issue slots each: "
+                                         "weighted by those costs it needs 1.22x its instruction count in slots "
+                                         "(DESIGN.md section 3)"}
                                 if valu else None),
                     "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
                     "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "

@@ -121,7 +121,13 @@ __device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, flo
   return m;
 }
 
-__global__ void __launch_bounds__(64)
+// waves/SIMD the forward is compiled for: 6 (80 VGPRs, six spilled dwords) measured 0.940 vs 0.970 ms at 5
+// (87 VGPRs); 7 / 8 (more spills) 0.934 / 0.925 -- the issue rate of one-wave workgroups grows with the
+// resident waves (profiles/ilp_probe.hip), the spills eat most of it
+#ifndef CLMGS_FWD_WAVES
+#define CLMGS_FWD_WAVES 6
+#endif
+__global__ void __launch_bounds__(64, CLMGS_FWD_WAVES)
 rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ packed,
                      const float* __restrict__ backgrounds,
                      int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
