@@ -144,16 +144,18 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   const int qx = lane & 7, qy = lane >> 3;
   const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
-  float T[PPL], cr[PPL], cg[PPL], cb[PPL], px[PPL], py[PPL];
+  // Per-pixel state kept lean (the VGPR budget decides the waves per SIMD, and the issue rate of one-wave
+  // workgroups grows with them): pixel centres are recomputed from the lane, and "this pixel still
+  // accumulates" is the SIGN of T (T > 1e-4 while alive; a terminated or out-of-image pixel holds -T).
+  float T[PPL], cr[PPL], cg[PPL], cb[PPL];
   int last[PPL];
-  bool alive[PPL];
+  const float px0 = tile_x0 + (float)qx + 0.5f, py0 = tile_y0 + (float)qy + 0.5f;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int j = tx * TILE + 8 * (k & 1) + qx;
     const int i = ty * TILE + 8 * (k >> 1) + qy;
-    px[k] = (float)j + 0.5f; py[k] = (float)i + 0.5f;
-    T[k] = 1.f; cr[k] = cg[k] = cb[k] = 0.f; last[k] = 0;
-    alive[k] = (i < H) && (j < W);
+    cr[k] = cg[k] = cb[k] = 0.f; last[k] = 0;
+    T[k] = ((i < H) && (j < W)) ? 1.f : -1.f;
   }
 
   int rs, re;
@@ -172,10 +174,7 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
   }
   for (int bs = rs; bs < re; bs += 64) {
-    bool any_alive = false;
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) any_alive |= alive[k];
-    if (!__any(any_alive)) break;
+    if (!__any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) break;
     const float4 A = nA, B = nB;
     const float blue = nblue;
     const int mask = (cur_g >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
@@ -204,26 +203,27 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       const int meta = __builtin_amdgcn_readfirstlane(sm.meta[t]);
       const float rblue = sm.c[t];
       const int gi = bs + (meta >> 4);
-      bool still = false;
+      int gi_v;  // the wave-uniform index in a VGPR, once per entry (v_cndmask cannot take it as a scalar
+      asm("v_mov_b32 %0, %1" : "=v"(gi_v) : "s"(gi));  // next to its mask; the compiler re-moved it per pass)
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         if (meta & (1 << k)) {  // wave-uniform: this quadrant can be touched
-          const float dx = RA.x - px[k], dy = RA.y - py[k];
+          const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
+          const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
           const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
           const float alpha = fminf(0.999f, RA.z * __builtin_amdgcn_exp2f(-sigma));
-          const bool valid = alive[k] && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
+          const bool valid = (T[k] > 0.f) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           const float next_T = T[k] * (1.f - alpha);
-          const bool term = valid && (next_T <= T_EPS);
-          const bool acc = valid && !term;
+          const bool goes_on = next_T > T_EPS;  // valid => alpha, T finite: one compare serves both cases
+          const bool acc = valid && goes_on;
+          const bool term = valid && !goes_on;
           const float vis = acc ? alpha * T[k] : 0.f;
           cr[k] += RB.z * vis; cg[k] += RB.w * vis; cb[k] += rblue * vis;
-          T[k] = acc ? next_T : T[k];
-          last[k] = acc ? gi : last[k];
-          alive[k] = alive[k] && !term;
+          last[k] = acc ? gi_v : last[k];
+          T[k] = acc ? next_T : (term ? -T[k] : T[k]);
         }
-        still |= alive[k];
       }
-      if (!__any(still)) break;
+      if (!__any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) break;
     }
   }
 
@@ -235,10 +235,11 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const int i = ty * TILE + 8 * (k >> 1) + qy;
     if (i < H && j < W) {
       const size_t pix = ((size_t)cam * H + i) * W + j;
-      render_colors[3 * pix] = cr[k] + T[k] * bgr;
-      render_colors[3 * pix + 1] = cg[k] + T[k] * bgg;
-      render_colors[3 * pix + 2] = cb[k] + T[k] * bgb;
-      render_alphas[pix] = 1.f - T[k];
+      const float Tf = fabsf(T[k]);
+      render_colors[3 * pix] = cr[k] + Tf * bgr;
+      render_colors[3 * pix + 1] = cg[k] + Tf * bgg;
+      render_colors[3 * pix + 2] = cb[k] + Tf * bgb;
+      render_alphas[pix] = 1.f - Tf;
       last_ids[pix] = last[k];
     }
   }
