@@ -57,7 +57,10 @@ __device__ __forceinline__ float gt_val(const uint8_t* __restrict__ gt, size_t o
   return fmaf(fmaf(-q, 255.0f, v), r, q);
 }
 
-__global__ void __launch_bounds__(64)
+#ifndef CLMGS_LOSS_FWD_WAVES
+#define CLMGS_LOSS_FWD_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, CLMGS_LOSS_FWD_WAVES)
 loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float* __restrict__ partials,
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
   __shared__ float la[LS_RING][LS_PITCH], lb[LS_RING][LS_PITCH];
