@@ -234,7 +234,7 @@ def adam_rows(p, g, m, v, rows, col_lr, beta1, beta2, eps, step, bias_correction
 
 
 def adam_catch_up(p, m, v, last_step, rows, col_lr, beta1, beta2, eps, to_step, bias_correction=True,
-                  max_replay=256, g=None, g_step=None, grad_scale=1.0):
+                  max_replay=256, g=None, g_step=None, grad_scale=1.0, keep_grad=False):
     """Replay the deferred zero-gradient Adam steps of `rows` (None = all) up to `to_step` and
     stamp them; with g / g_step also apply the gradient step that is waiting for a row, at its own
     step (see clmgs_adam_catch_up)."""
@@ -244,7 +244,7 @@ def adam_catch_up(p, m, v, last_step, rows, col_lr, beta1, beta2, eps, to_step, 
                                 dptr(rows, None, True), _idx64(rows), int(n_rows), int(p.shape[-1]),
                                 dptr(col_lr, F32), float(beta1), float(beta2), float(eps), int(to_step),
                                 int(bool(bias_correction)), int(max_replay), dptr(g, F32, True),
-                                dptr(g_step, I32, True), float(grad_scale)))
+                                dptr(g_step, I32, True), float(grad_scale), int(bool(keep_grad))))
     if rows is None:
         last_step[: p.shape[0]].fill_(int(to_step))
     else:

@@ -206,7 +206,8 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
                      int64_t n_rows, int cols, const float* __restrict__ col_lr, float beta1,
                      float beta2, float eps, int to_step, int bias_correction, int max_replay,
                      float* __restrict__ g, const int32_t* __restrict__ g_step, float grad_scale,
-                     float ob1, float ob2) {  // 1 - beta, rounded from double like the eager kernel's
+                     float ob1, float ob2,  // 1 - beta, rounded from double like the eager kernel's
+                     int keep_grad) {  // 1: the consumed gradient row is left as it is (first-touch producers)
   const int cv = cols / VEC;
   const int64_t total = n_rows * cv;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -279,7 +280,7 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
         pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
         gg[c] = 0.f;
       }
-      vstore<VEC>(g + o, gg);  // consumed
+      if (!keep_grad) vstore<VEC>(g + o, gg);  // consumed: cleared for producers that accumulate
       a = gs;
     }
     replay(a, to_step);
@@ -508,7 +509,8 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
                                    const int32_t* last_step, const void* rows, int idx_is_64,
                                    int64_t n_rows, int cols, const float* col_lr, double beta1,
                                    double beta2, double eps, int to_step, int bias_correction,
-                                   int max_replay, float* g, const int32_t* g_step, float grad_scale) {
+                                   int max_replay, float* g, const int32_t* g_step, float grad_scale,
+                                   int keep_grad) {
   CLMGS_CHECK_ARG(n_rows >= 0 && cols > 0 && to_step >= 0 && max_replay >= 1);
   if (n_rows == 0) return 0;
   CLMGS_CHECK_ARG(p && m && v && last_step && col_lr && ((g != nullptr) == (g_step != nullptr)));
@@ -519,7 +521,7 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
   hipLaunchKernelGGL((adam_catch_up_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
                      p, m, v, last_step, rows, n_rows, cols, col_lr, (float)beta1, (float)beta2,   \
                      (float)eps, to_step, bias_correction, max_replay, g, g_step, grad_scale,     \
-                     (float)(1.0 - beta1), (float)(1.0 - beta2))
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), keep_grad)
   if (idx_is_64) { if (v4) CLMGS_CATCH_UP(int64_t, 4); else CLMGS_CATCH_UP(int64_t, 1); }
   else { if (v4) CLMGS_CATCH_UP(int32_t, 4); else CLMGS_CATCH_UP(int32_t, 1); }
 #undef CLMGS_CATCH_UP

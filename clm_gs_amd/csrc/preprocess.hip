@@ -243,6 +243,12 @@ struct PreGrads {
   // (this kernel then takes the place of the row-sum pass: no [V,16] gradient table round trip)
   const float4* partials;
   const int64_t* row_cum;
+  // != NULL (with sh_by_filter): FIRST-TOUCH stores into the [N,48] gradient table.  sh_stamp[row] is the
+  // optimizer step whose gradient the row holds; a row whose stamp is not cur_step is STORED (its old
+  // content was consumed by the deferred row optimizer, which then need not clear it) and stamped,
+  // later cameras of the batch accumulate.  Saves the consumer's clearing write and the first read.
+  int32_t* sh_stamp;
+  int cur_step;
 };
 
 template <int DEG, bool PK>
@@ -279,6 +285,9 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     // dead lanes redirect every gather to the chunk's first live row: no branches, cache hits
     const int64_t g = mine ? my_row : 0;
     const int sh_id = mine ? my_sh : 0;
+    // first-touch mode: is this row's gradient line still the one of an earlier (consumed) step?
+    const bool fresh = o.sh_stamp && vis && (o.sh_stamp[sh_id] != o.cur_step);
+    const unsigned long long fresh_rows = __ballot(fresh);
     const int64_t gl = vis ? g : (int64_t)__shfl((int)g, first);
     const int i = mine ? base + t : base;
     // ---- everything this lane needs from HBM, requested at once
@@ -488,7 +497,9 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t dst_row = a.sh_by_filter ? (int64_t)__shfl(g_l, r) : (int64_t)(base + r);         \
     if ((live >> r) & 1ull) {                                                                       \
       const float4 v = *reinterpret_cast<const float4*>(lds + r * PP_PITCH + 4 * k);                \
-      float4 c = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);            \
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+      if (!((fresh_rows >> r) & 1ull))                                                              \
+        c = *reinterpret_cast<const float4*>(o.g_sh_rows + dst_row * 48 + 4 * k);                   \
       c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;                                               \
       *reinterpret_cast<float4*>(o.g_sh_rows + dst_row * 48 + 4 * k) = c;                           \
     }                                                                                               \
@@ -497,6 +508,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     CLMGS_FOR12(CLMGS_X)
     }
 #undef CLMGS_X
+    if (fresh) o.sh_stamp[sh_id] = o.cur_step;  // every row belongs to one lane of one wave of this launch
   }
 }
 
@@ -577,8 +589,9 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
                                     float* max_radii2D, float* grad_accum, float* denom,
                                     float* v_means2d_out, int stats_only_visible,
                                     const void* partials, const int64_t* row_cum,
-                                    const int32_t* sh_index) {
+                                    const int32_t* sh_index, int32_t* sh_stamp, int cur_step) {
   CLMGS_CHECK_ARG(V >= 0 && degree >= 0 && degree <= 3 && width > 0 && height > 0);  // row ids are int32 in flight
+  CLMGS_CHECK_ARG(!sh_stamp || (sh_by_filter && cur_step >= 1));
   if (V == 0) return 0;
   CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && g_xyz && g_sh_rows);
   // exactly one source of the per-row raster gradient: the [V,16] table, or the partial lines + ranges
@@ -599,7 +612,8 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   CLMGS_CHECK_ARG(!sh_index || sh_by_filter);
   a.sh_index = sh_index;
   PreGrads o{g_xyz, g_opacity, g_scaling, g_rotation, g_sh_rows, max_radii2D, grad_accum, denom,
-             pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible, (const float4*)partials, row_cum};
+             pg ? 1 : 0, ps ? 1 : 0, v_means2d_out, stats_only_visible, (const float4*)partials, row_cum,
+             sh_stamp, cur_step};
   const size_t lds = 0;
   const int grid = min(ceil_div(V, PP_ROWS), 256 * 12);
 #define CLMGS_PRE_BWD(D)                                                                          \

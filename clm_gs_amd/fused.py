@@ -185,9 +185,12 @@ def camera_loss(p):
 
 
 def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True, stats_delta=None,
-                    stats_only_visible=False, visibility_out=None, accumulate_after=None):
+                    stats_only_visible=False, visibility_out=None, accumulate_after=None, sh_stamp=None,
+                    cur_step=0):
     """Alpha-blend backward (stream `raster`) + projection / SH backward (stream `mem`) of the
-    camera whose forward left `p`.  Gradients are ACCUMULATED (see train_one_camera)."""
+    camera whose forward left `p`.  Gradients are ACCUMULATED (see train_one_camera); with `sh_stamp`
+    (int32 [N], the deferred optimizer's per-row gradient-step table) + `cur_step` the SH gradient rows
+    are STORED on their first touch of the step and stamped (clmgs_preprocess_bwd)."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -236,7 +239,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
             int(p.sh_by_filter), _np(vm), _np(K), _np(campos), W, H, p.deg, 0.3, dptr(p.radii),
             None, *small_out, dptr(g_sh_rows, F32, allow_host=True),
             *stat_ptrs, None, int(bool(stats_only_visible)), dptr(partials), dptr(p.row_cum),
-            dptr(p.sh_index, I32, True)))
+            dptr(p.sh_index, I32, True), dptr(sh_stamp, I32, True), int(cur_step)))
     # partials (64 B per intersection, 576 MB at 4K) and the loss cotangent image are dead once the two
     # kernels above have run: hand them back now instead of at the next batch.  Each was used on a second
     # stream (partials: written on s_raster, read on s_mem; v_out: written on s_mem, read on s_raster), so
@@ -252,7 +255,8 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
 def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh_rows, background,
                      gt_u8, lambda_dssim=0.2, update_stats=True, keep=None, accumulate_after=None,
                      return_event=False, stats_only_visible=False, visibility_out=None,
-                     raster_stream=None, small_packed=None, small_grad=None, stats_delta=None, sh_index=None):
+                     raster_stream=None, small_packed=None, small_grad=None, stats_delta=None, sh_index=None,
+                     sh_stamp=None, cur_step=0):
     """Forward, loss, backward for one camera over the rows of `this_filter`.
 
     Gradients are ACCUMULATED into gaussians._xyz/_opacity/_scaling/_rotation .grad (full size, must
@@ -272,7 +276,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
                        lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur),
                        sh_index)
     camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
-                    stats_only_visible, visibility_out, accumulate_after)
+                    stats_only_visible, visibility_out, accumulate_after, sh_stamp, cur_step)
     loss = camera_loss(p)  # on `cur`, which the loss kernels ran on
     if keep is not None:
         keep.append(p)

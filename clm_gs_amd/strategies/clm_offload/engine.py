@@ -294,6 +294,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     touched_rows = touched_rows.to(torch.int32)
     _lib.STATS.setdefault("touched_rows", []).append(int(touched_rows.shape[0]))  # shape known on the host
     lazy = gaussians.lazy_rows and not args.stop_update_param
+    # first-touch gradient stores (gaussian_model.first_touch_grads): the projection/SH backward stamps
+    # `_row_g_step` itself and stores instead of accumulating on a row's first touch of this step
+    ft_stamp = gaussians._row_g_step if (lazy and fused and gaussians.first_touch_grads) else None
     owner = None  # owner-computes camera-DP (dp.py): rows owned by index range
     if lazy and dp.active() and getattr(args, "dp_owner_computes", False):
         owner = dp.owner_plan(touched_rows.long(), N)
@@ -407,10 +410,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 if micro_idx >= depth:
                     with _lib.host_region("camera_backward"):
                         camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
-                                        stats_delta=stats_d)
+                                        stats_delta=stats_d, sh_stamp=ft_stamp, cur_step=step)
             for k in range(max(0, bsz - depth), bsz):
                 with _lib.host_region("camera_backward"):
-                    camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d)
+                    camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d,
+                                    sh_stamp=ft_stamp, cur_step=step)
             default_stream.wait_stream(fronts[1])
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
@@ -438,7 +442,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                         background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
                         return_event=True,
                         raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
-                        small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d)
+                        small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d,
+                        sh_stamp=ft_stamp, cur_step=step)
                 losses.append(loss)
             for ln in lanes:
                 if ln is not default_stream:
@@ -496,7 +501,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # (index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host scalar
         # to the device and block the host until the whole batch has drained)
         stamp = touched_rows[owner.lo:owner.hi] if owner is not None else touched_rows
-        if stamp.numel():
+        if stamp.numel() and ft_stamp is None:  # first-touch mode: the backward kernels stamped their rows
             gaussians._row_g_step.index_fill_(0, stamp.long(), step)
     elif not args.stop_update_param:
         row_update(touched_rows)

@@ -182,6 +182,17 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def lazy_rows(self):
         return getattr(self, "_row_last_step", None) is not None
 
+    @property
+    def first_touch_grads(self):
+        """The fused HBM engine STORES a row's SH gradient on its first touch of a step (stamping
+        `_row_g_step`) instead of accumulating into a row its consumer cleared; the deferred row optimizer
+        then leaves consumed rows as they are.  One policy per model: every producer of the gradient
+        table must follow it, so it is a function of the (constant) engine options only."""
+        from ... import dp
+        a = self.args
+        return bool(self.lazy_rows and getattr(a, "fused_front_end", True) and getattr(a, "first_touch_grads", True)
+                    and not dp.active() and not self.deferred_host_rows)
+
     def catch_up_rows(self, rows=None, to_step=None):
         """Bring `rows` (None = all) up to date with the zero-gradient Adam steps they skipped."""
         if not self.lazy_rows:
@@ -199,7 +210,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         adam_catch_up(p.data, st["exp_avg"], st["exp_avg_sq"], self._row_last_step, rows, col_lr,
                       g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"],
                       g=self.parameters_grad_buffer[:p.shape[0]], g_step=self._row_g_step,
-                      grad_scale=1.0 / (self.args.bsz * dp.world_size()))
+                      grad_scale=1.0 / (self.args.bsz * dp.world_size()), keep_grad=self.first_touch_grads)
 
     def flush_lazy_rows(self):
         if self.deferred_host_rows:

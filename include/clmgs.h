@@ -182,7 +182,13 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
  * [N,4] table  max radius | grad accum | count | pad  (one row instead of three scattered floats).
  * sh_index[V] (i32, optional, with sh_by_filter = 1): position i reads SH row sh_rows[sh_index[i]] and
  * accumulates into g_sh_rows[sh_index[i]] -- sh_rows is then a staging table holding only the rows a
- * batch touches (host-resident mode: clm_offload/engine.py:494-508 moves rows host -> GPU per batch). */
+ * batch touches (host-resident mode: clm_offload/engine.py:494-508 moves rows host -> GPU per batch).
+ * sh_stamp[N] (i32, optional, bwd with sh_by_filter = 1) + cur_step: FIRST-TOUCH stores.  sh_stamp[row]
+ * is the optimizer step whose gradient g_sh_rows[row] holds; a row whose stamp differs from cur_step is
+ * STORED (its previous content was consumed -- clmgs_adam_catch_up(keep_grad = 1) does not clear it) and
+ * stamped cur_step, later cameras of the same step accumulate.  sh_stamp doubles as the deferred
+ * optimizer's g_step table.  The reference clears the whole gradient buffer every batch
+ * (clm_offload/engine.py:870-882) and accumulates (send_shs2cpu_grad_buffer_stream, accum = True). */
 int clmgs_preprocess_fwd(void* stream, int V, const int64_t* filter, const float* xyz,
                          const float* opacity_raw, const float* scaling_raw,
                          const float* rotation_raw, const float* sh_rows, int sh_by_filter,
@@ -199,7 +205,8 @@ int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, const float
                          const void* packed_grad, float* g_xyz, float* g_opacity, float* g_scaling,
                          float* g_rotation, float* g_sh_rows, float* max_radii2D, float* grad_accum,
                          float* denom, float* v_means2d_out, int stats_only_visible,
-                         const void* partials, const int64_t* row_cum, const int32_t* sh_index);
+                         const void* partials, const int64_t* row_cum, const int32_t* sh_index,
+                         int32_t* sh_stamp, int cur_step);
 
 /* ---- clm_kernels.fused_ssim  (base_engine.py:5,93; definition utils/loss_utils.py:26-85)
  * img1,img2 [B,CH,H,W].  fwd adds per-block SSIM-map sums into ssim_sum[1024] (caller zeroes
@@ -277,7 +284,8 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
  * gradient waits in g[row, cols]; if it lies in (last_step, to_step] it is applied here at its own step
  * with grad_scale, between the replays before and after it, and the gradient row is zeroed: the same
  * operations in the same order as the eager update at the end of that batch (optimizer.py:130-144 /
- * clm_offload/engine.py:316-328), in one pass over the row instead of two. */
+ * clm_offload/engine.py:316-328), in one pass over the row instead of two.  keep_grad = 1: the consumed
+ * row is not cleared (producers that STORE on first touch: clmgs_preprocess_bwd with sh_stamp). */
 /* The packed [N,12] mirror of the four GPU-resident parameter tensors, and their dense Adam when the
  * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
  * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a
@@ -293,7 +301,7 @@ int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v, const int32_
                         const void* rows, int idx_is_64, int64_t n_rows, int cols,
                         const float* col_lr, double beta1, double beta2, double eps, int to_step,
                         int bias_correction, int max_replay, float* g, const int32_t* g_step,
-                        float grad_scale);
+                        float grad_scale, int keep_grad);
 /* Host (OpenMP) variant on pinned/pageable host memory: cpu_adam.FusedCPUAdam row group
  * update (clm_offload/engine.py:316-328).  If signal != NULL, busy-waits until
  * *signal != 0 before touching the rows. */

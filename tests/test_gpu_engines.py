@@ -103,7 +103,10 @@ def _one_step(strategy, residency, sparse=False):
         assert len(sparsity) == BSZ and all(0 < s <= 1 for s in sparsity) and sorted(order) == list(range(BSZ))
         m.flush_lazy_rows()  # deferred row optimizers (HBM lazy rows / host rows): apply what is pending
         shs = m._parameters.detach().cuda() if not m._parameters.is_cuda else m._parameters.detach()
-        if m._parameters.is_cuda:
+        if m._parameters.is_cuda and m.first_touch_grads:
+            # first-touch policy: a consumed gradient row is marked by its stamps, not cleared
+            assert bool((m._row_g_step[:N] <= m._row_last_step[:N]).all()) and int(m._row_last_step[:N].min()) == 1
+        elif m._parameters.is_cuda:
             assert float(m.parameters_grad_buffer[:N].abs().max()) == 0.0, "consumed grad rows must be zeroed"
         else:  # host rows: a consumed gradient row is marked by its stamp, not overwritten
             assert int(m._host_g_step[:N].max()) == 0 and int(m._host_last_step[:N].min()) == 1
@@ -195,6 +198,40 @@ def test_camera_schedules_are_bit_identical(dev):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_first_touch_gradient_stores_equal_clear_and_accumulate(dev):
+    """The fused HBM engine stores a row's SH gradient on its first touch of a step and never clears the
+    table (first_touch_grads, default) == the clear-by-the-consumer + read-modify-write policy: three
+    batches with moving cameras (rows seen in batch 0 and 2 but not 1 carry a consumed, uncleared gradient
+    through batch 1) end bit-identical, and stale rows really are left in the table."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    from clm_gs_amd.synthetic import nadir_cameras
+    outs = []
+    for ft in (True, False):
+        args, sc, _ = _setup("clm_offload", "hbm")
+        args.first_touch_grads = ft
+        m = _make("clm_offload", sc, args)
+        assert m.first_touch_grads == ft
+        allc = nadir_cameras(3 * BSZ, N, W, H, 0.3, seed=4, device="cuda")
+        g = torch.Generator().manual_seed(8)
+        for c in allc:
+            c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+        comm = torch.cuda.Stream()
+        for b in (0, 1, 0):  # the cameras of batch 0 come back after one batch elsewhere
+            utils.set_cur_iter(1 + len(outs) * 0 + b * BSZ)
+            clm_offload_train_one_batch(m, _Scene, allc[b * BSZ:(b + 1) * BSZ], m.parameters_grad_buffer, None,
+                                        None, comm, torch.Generator(device="cuda"))
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        outs.append([m._parameters.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                     m._xyz.detach().clone(), m._opacity.detach().clone()])
+        stale = float(m.parameters_grad_buffer[:N].abs().max())
+        assert (stale > 0) == ft  # consumed rows: left in place / cleared
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_lazy_dense_adam_equals_eager(dev):
