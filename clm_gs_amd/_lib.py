@@ -56,7 +56,7 @@ SIGNATURES = {
     "clmgs_set_signal": (_i, [_vp, _vp, _i, ctypes.c_int32]),
     "clmgs_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i]),
     "clmgs_pack_small": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "clmgs_adam_small_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f]),
+    "clmgs_adam_small_packed": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f, _vp, _i]),
     "clmgs_adam_catch_up": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _d, _d, _d, _i, _i, _i, _vp, _vp, _f, _i]),
     "clmgs_host_adam_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _f, _i, _vp, _i]),
     "clmgs_host_pool_start": (_i, [_i]),

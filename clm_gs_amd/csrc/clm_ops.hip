@@ -311,10 +311,14 @@ __device__ __forceinline__ float adam_elem(float& m, float& v, float p, float g,
   return p - lr_bc * adam_ratio(m, v, inv_sqrt_bc2, eps);
 }
 
+// g_stamp != NULL (first-touch producers, clmgs_preprocess_bwd with sh_stamp): row r carries a gradient of
+// THIS step only if g_stamp[r] == cur_step; other rows hold consumed leftovers, are not read (their
+// gradient is zero) and nothing is cleared.
 __global__ void __launch_bounds__(SA_ROWS)
 adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
                          float4* __restrict__ packed_g, float beta1, float beta2, float ob1,
-                         float ob2, float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
+                         float ob2, float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale,
+                         const int32_t* __restrict__ g_stamp, int cur_step) {
   __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
   __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
   const int tid = threadIdx.x;
@@ -323,8 +327,16 @@ adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
     const int64_t row0 = blk * SA_ROWS;
     const int rows = (int)min((int64_t)SA_ROWS, n - row0);
     __syncthreads();
-    for (int i = tid; i < rows * 3; i += SA_ROWS)
-      reinterpret_cast<float4*>(sg)[i] = packed_g[row0 * 3 + i];
+    if (g_stamp) {
+      __shared__ uint8_t has_g[SA_ROWS];
+      if (tid < rows) has_g[tid] = (uint8_t)(g_stamp[row0 + tid] == cur_step);
+      __syncthreads();
+      for (int i = tid; i < rows * 3; i += SA_ROWS)
+        reinterpret_cast<float4*>(sg)[i] = has_g[i / 3] ? packed_g[row0 * 3 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int i = tid; i < rows * 3; i += SA_ROWS)
+        reinterpret_cast<float4*>(sg)[i] = packed_g[row0 * 3 + i];
+    }
     if (tid < rows) sp[tid * 12 + 11] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -369,7 +381,7 @@ adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
     for (int i = tid; i < rows * 3; i += SA_ROWS) {
       packed_p[row0 * 3 + i] = reinterpret_cast<const float4*>(sp)[i];
       const float4 gq = reinterpret_cast<const float4*>(sg)[i];  // rows the batch did not touch are
-      if (gq.x != 0.f || gq.y != 0.f || gq.z != 0.f || gq.w != 0.f)  // zero already: nothing to clear
+      if (!g_stamp && (gq.x != 0.f || gq.y != 0.f || gq.z != 0.f || gq.w != 0.f))  // zero already
         packed_g[row0 * 3 + i] = z;
     }
   }
@@ -544,7 +556,8 @@ extern "C" int clmgs_adam_small_packed(void* stream, int64_t n, float* const* pa
                                        float* const* exp_avg, float* const* exp_avg_sq,
                                        const double* lr4, void* packed_p, void* packed_g,
                                        double beta1, double beta2, double eps, int step,
-                                       int bias_correction, float grad_scale) {
+                                       int bias_correction, float grad_scale, const int32_t* g_stamp,
+                                       int cur_step) {
   CLMGS_CHECK_ARG(n >= 0 && step >= 1);
   if (n == 0) return 0;
   CLMGS_CHECK_ARG(params && exp_avg && exp_avg_sq && lr4 && packed_p && packed_g &&
@@ -562,7 +575,7 @@ extern "C" int clmgs_adam_small_packed(void* stream, int64_t n, float* const* pa
   const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
   hipLaunchKernelGGL(adam_small_packed_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
                      (hipStream_t)stream, n, t, (float4*)packed_p, (float4*)packed_g, (float)beta1,
-                     (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale);
+                     (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, g_stamp, cur_step);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -262,7 +262,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
   const int n_chunks = (V + PP_ROWS - 1) / PP_ROWS;
   const int t = threadIdx.x;
   int chunk = blockIdx.x;
-  int my_row = -1, my_radius = 0, my_sh = 0;
+  int my_row = -1, my_radius = 0, my_sh = 0, my_stamp = 0;
   int64_t my_s0 = 0;
   int my_cnt = 0;
   if (chunk < n_chunks && chunk * PP_ROWS + t < V) {
@@ -270,6 +270,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     my_row = a.filter ? (int)a.filter[i] : i;
     my_sh = a.sh_index ? a.sh_index[i] : my_row;
     my_radius = radii[i];
+    if (o.sh_stamp) my_stamp = o.sh_stamp[my_sh];
     if (o.partials) { my_s0 = i ? o.row_cum[i - 1] : 0; my_cnt = (int)(o.row_cum[i] - my_s0); }
   }
   for (; chunk < n_chunks; chunk += gridDim.x) {
@@ -286,7 +287,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const int64_t g = mine ? my_row : 0;
     const int sh_id = mine ? my_sh : 0;
     // first-touch mode: is this row's gradient line still the one of an earlier (consumed) step?
-    const bool fresh = o.sh_stamp && vis && (o.sh_stamp[sh_id] != o.cur_step);
+    const bool fresh = o.sh_stamp && vis && (my_stamp != o.cur_step);
     const unsigned long long fresh_rows = __ballot(fresh);
     const int64_t gl = vis ? g : (int64_t)__shfl((int)g, first);
     const int i = mine ? base + t : base;
@@ -316,9 +317,10 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     const float oraw = sr.oraw;
     float c_xyz[3], c_sc[3], c_op;
     float4 c_rot;
-    if (PK) {  // the row's 11 accumulated gradients: one 48 B row
+    if (PK) {  // the row's 11 accumulated gradients: one 48 B row (first touch of the step: zeros, no read)
       const float4* grow = reinterpret_cast<const float4*>(o.g_xyz) + 3 * gl;
-      const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2];
+      float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+      if (!fresh) { g0 = grow[0]; g1 = grow[1]; g2 = grow[2]; }
       c_xyz[0] = g0.x; c_xyz[1] = g0.y; c_xyz[2] = g0.z; c_op = g0.w;
       c_sc[0] = g1.x; c_sc[1] = g1.y; c_sc[2] = g1.z;
       c_rot = make_float4(g1.w, g2.x, g2.y, g2.z);
@@ -351,6 +353,7 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
       if (ni < V) {
         my_row = a.filter ? (int)a.filter[ni] : ni; my_radius = radii[ni];
         my_sh = a.sh_index ? a.sh_index[ni] : my_row;
+        if (o.sh_stamp) my_stamp = o.sh_stamp[my_sh];  // next chunk's stamps travel with its row ids
         if (o.partials) { my_s0 = ni ? o.row_cum[ni - 1] : 0; my_cnt = (int)(o.row_cum[ni] - my_s0); }
       }
     }

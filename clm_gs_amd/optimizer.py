@@ -104,10 +104,12 @@ class UnifiedAdam(torch.optim.Optimizer):
         self.state = self.gpu_adam.state | self.cpu_adam.state
 
     @torch.no_grad()
-    def gpu_step_packed(self, packed_p, packed_g, grad_scale=1.0):
+    def gpu_step_packed(self, packed_p, packed_g, grad_scale=1.0, g_stamp=None, cur_step=0):
         """Dense Adam of the four GPU-resident tensors from the packed [N,12] gradient table
         (clmgs_adam_small_packed): updates p / exp_avg / exp_avg_sq of every group in place,
-        refreshes the packed parameter mirror and zeroes the gradient table, all in one pass."""
+        refreshes the packed parameter mirror and zeroes the gradient table, all in one pass.
+        g_stamp / cur_step: first-touch gradient table (only rows stamped cur_step carry a gradient;
+        nothing is zeroed)."""
         import ctypes
         from . import _lib
         assert not isinstance(self.gpu_adam, SelectiveAdam)
@@ -140,7 +142,8 @@ class UnifiedAdam(torch.optim.Optimizer):
         _lib.check(L.clmgs_adam_small_packed(
             _lib.stream(), int(packed_p.shape[0]), arr(ps), arr(ms), arr(vs), (ctypes.c_double * 4)(*lrs),
             _lib.dptr(packed_p), _lib.dptr(packed_g), float(g0["betas"][0]), float(g0["betas"][1]),
-            float(g0["eps"]), int(step), 1, float(grad_scale)))
+            float(g0["eps"]), int(step), 1, float(grad_scale),
+            None if g_stamp is None else _lib.dptr(g_stamp, torch.int32), int(cur_step)))
         self.state = self.gpu_adam.state | self.cpu_adam.state
 
     def get_all_states(self):

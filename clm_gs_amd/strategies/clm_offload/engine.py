@@ -488,7 +488,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             default_stream.wait_event(side_event)
         return losses, ordered_cams, sparsity
     if use_packed:
-        gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()))
+        gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()),
+                                            g_stamp=ft_stamp, cur_step=step)
     else:
         _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
                        grad_div=bsz * dp.world_size())

@@ -290,13 +290,16 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
  * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
  * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a
  * host array of their 4 learning rates.  One pass: grad * grad_scale -> Adam (torch.optim.Adam's
- * bias-corrected formula) -> p / m / v written back, mirror row refreshed, gradient row zeroed. */
+ * bias-corrected formula) -> p / m / v written back, mirror row refreshed, gradient row zeroed.
+ * g_stamp (i32 [n], optional) + cur_step: the first-touch form -- only rows with g_stamp[row] == cur_step
+ * carry a gradient of this step (clmgs_preprocess_bwd stamped them); the others are not read, and nothing
+ * is zeroed. */
 int clmgs_pack_small(void* stream, int64_t n, const float* xyz, const float* opacity,
                      const float* scaling, const float* rotation, void* packed_p);
 int clmgs_adam_small_packed(void* stream, int64_t n, float* const* params, float* const* exp_avg,
                             float* const* exp_avg_sq, const double* lr4, void* packed_p,
                             void* packed_g, double beta1, double beta2, double eps, int step,
-                            int bias_correction, float grad_scale);
+                            int bias_correction, float grad_scale, const int32_t* g_stamp, int cur_step);
 int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v, const int32_t* last_step,
                         const void* rows, int idx_is_64, int64_t n_rows, int cols,
                         const float* col_lr, double beta1, double beta2, double eps, int to_step,
