@@ -186,7 +186,7 @@ def camera_loss(p):
 
 def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True, stats_delta=None,
                     stats_only_visible=False, visibility_out=None, accumulate_after=None, sh_stamp=None,
-                    cur_step=0):
+                    cur_step=0, release=False):
     """Alpha-blend backward (stream `raster`) + projection / SH backward (stream `mem`) of the
     camera whose forward left `p`.  Gradients are ACCUMULATED (see train_one_camera); with `sh_stamp`
     (int32 [N], the deferred optimizer's per-row gradient-step table) + `cur_step` the SH gradient rows
@@ -249,6 +249,22 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         p.v_out.record_stream(s_raster)
     del partials
     p.v_out = None
+    if release:
+        # Nothing reads this camera's forward outputs after the two kernels above.  They were allocated on the
+        # front stream and used on the tile and memory streams: tell the allocator, then drop them, so the next
+        # cameras reuse the blocks in stream order instead of the whole batch's outputs staying alive until the
+        # next batch (4 x 0.7 GB at 4K).  Only what camera_loss() needs is kept.
+        for name in ("radii", "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids"):
+            t = getattr(p, name)
+            if t is not None:
+                for st in {s_mem, s_raster} - {s_front}:
+                    t.record_stream(st)
+                setattr(p, name, None)
+        for t in p.aux:
+            if isinstance(t, torch.Tensor) and t.is_cuda and t is not p.loss_partials:
+                for st in {s_mem, s_raster} - {s_front}:
+                    t.record_stream(st)
+        p.aux = (p.loss_partials,)
     return p
 
 

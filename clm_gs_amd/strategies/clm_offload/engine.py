@@ -410,11 +410,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 if micro_idx >= depth:
                     with _lib.host_region("camera_backward"):
                         camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
-                                        stats_delta=stats_d, sh_stamp=ft_stamp, cur_step=step)
+                                        stats_delta=stats_d, sh_stamp=ft_stamp, cur_step=step, release=True)
             for k in range(max(0, bsz - depth), bsz):
                 with _lib.host_region("camera_backward"):
                     camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d,
-                                    sh_stamp=ft_stamp, cur_step=step)
+                                    sh_stamp=ft_stamp, cur_step=step, release=True)
             default_stream.wait_stream(fronts[1])
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
