@@ -25,9 +25,8 @@ import time
 import torch
 
 from ... import _lib, clm_kernels, dp, fast_tsp, utils
-from ...clm_kernels import (send_shs2cpu_grad_buffer_stream,
-                            send_shs2cpu_grad_buffer_stream_retention, send_shs2gpu_stream,
-                            send_shs2gpu_stream_retention, spherical_harmonics_bwd_inplace)
+from ...clm_kernels import (send_shs2cpu_grad_buffer_stream, send_shs2gpu_stream,
+                            spherical_harmonics_bwd_inplace)
 from ...densification import update_densification_stats_offload_accum_grads
 from ...gsplat import (fully_fused_projection, isect_offset_encode, isect_tiles,
                        rasterize_to_pixels, spherical_harmonics)
