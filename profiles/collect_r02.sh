@@ -40,7 +40,7 @@ done
 # host-resident mode: kernels + SDMA copies on one timeline
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/prof_h -o h -- python $R/bench.py --residency host --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --camera-order path > $O/prof_h.log 2>&1
 DBH=$(find /tmp/prof_h -name "*.db" | head -1)
-python $R/profiles/timeline_host.py $DBH 340 > $O/timeline_host_resident.txt 2>&1
+python $R/profiles/timeline_host.py $DBH batches2 > $O/timeline_host_resident.txt 2>&1
 # do VALU-bound and HBM-bound kernels overlap, or share a budget?  (also the plain-FMA issue peak)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/profiles/corun_probe.hip -o /tmp/corun_probe && /tmp/corun_probe > $O/corun_probe.jsonl 2>&1
 cd $R

@@ -1,5 +1,7 @@
 """Host-resident mode: how much of the host<->HBM traffic runs UNDER the rendering kernels.
-python profiles/timeline_host.py results.db [window_ms]
+python profiles/timeline_host.py results.db [window_ms | batchesK]
+(`batches2` = the last two complete batches of the trace, from the third-last to the last
+visibility_bits launch: the bench's final flush of the deferred row steps, host work only, stays out)
 Reads a rocprofv3 rocpd database taken with --kernel-trace --memory-copy-trace.  Copies = the SDMA
 transfers (hipMemcpyAsync: staging rows host->device, row lists device->host, GT images) PLUS the
 zero-copy gradient scatter kernel (rows_move_f4_kernel writing pinned host memory).  "Render kernels" =
@@ -8,7 +10,8 @@ import sqlite3
 import sys
 
 c = sqlite3.connect(sys.argv[1])
-win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else None
+arg = sys.argv[2] if len(sys.argv) > 2 else None
+win = float(arg) * 1e6 if arg and not arg.startswith("batches") else None
 names = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
 kern = list(c.execute("select name, start, end from kernels order by start"))
 mc_view = next((n for n in names if n.lower() in ("memory_copies", "memory_copy")), None) or \
@@ -24,8 +27,12 @@ if mc_view:
     copies = [(s, e, b, str(n)) for s, e, b, n in c.execute(q)]
 t_end = max([k[2] for k in kern] + [x[1] for x in copies])
 t0 = t_end - win if win else min(k[1] for k in kern)
-kern = [k for k in kern if k[1] >= t0]
-copies = [x for x in copies if x[0] >= t0]
+if arg and arg.startswith("batches"):
+    marks = [k[1] for k in kern if "visibility_bits" in k[0]]
+    nb = int(arg[7:] or 2)
+    t0, t_end = marks[-nb - 1], marks[-1]
+kern = [k for k in kern if t0 <= k[1] < t_end]
+copies = [x for x in copies if t0 <= x[0] < t_end]
 scatter = [(s, e) for n, s, e in kern if "rows_move_f4_kernel" in n]
 render = sorted((s, e) for n, s, e in kern if "rows_move_f4_kernel" not in n)
 
