@@ -77,8 +77,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline budget")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--prime-seconds", type=float, default=2.0,
-                    help="untimed evaluation renders before the warm-up steps (GPU clock / power ramp of a fresh box)")
+    ap.add_argument("--prime-seconds", type=float, default=15.0,
+                    help="untimed evaluation renders (model untouched) before the warm-up steps: the first minute "
+                         "of a fresh box runs the same build 3-5 %% slower (143-151 vs 149-158 img/s as first / "
+                         "later process; 30 s of priming: 150.9 vs 152.7)")
     ap.add_argument("--camera-order", default="shuffle", choices=["shuffle", "path"],
                     help="shuffle: batches are seeded random draws from the survey, as the reference's DataLoader "
                          "(shuffle=True, train.py:156-167); path: consecutive cameras of the lawn-mower path (neighbours "
