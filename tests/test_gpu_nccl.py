@@ -40,7 +40,7 @@ def test_dp_collectives_and_engine_exchange_on_rccl_world1(dev):
 def test_bench_under_torchrun_world1_uses_rccl(dev):
     env = dict(os.environ, CLMGS_DP_FORCE="1")
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                     "--config", "small", "--no-cpu-baseline"], env=env)
+                     "--config", "small", "--no-cpu-baseline", "--prime-seconds", "0"], env=env)
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     j = json.loads(lines[0])
