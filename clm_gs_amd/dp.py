@@ -7,11 +7,12 @@ rows.  Densification statistics accumulate locally and are reduced only right be
 densify_and_prune (sum / sum / max).  Everything is plain torch.distributed (backend "nccl" is
 RCCL over xGMI on ROCm; the CPU tests use gloo), device-agnostic tensors.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
-
-import os
+from . import utils
 
 
 def world_size():
@@ -74,11 +75,11 @@ def allreduce_rows(grad_rows, touched_global, average=True, rows=None):
             grad_rows /= ws
         return
     rows = rows.long()
-    buf = grad_rows[rows]
+    buf = utils.take_rows(grad_rows, rows)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     if average:
         buf /= ws
-    grad_rows[rows] = buf
+    utils.put_rows(grad_rows, rows, buf)
 
 
 def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85):
@@ -104,12 +105,12 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
         return
     rows = rows.long()
     widths = [t.shape[1] for t in tables]
-    buf = torch.cat([t[rows] for t in tables], dim=1)
+    buf = torch.cat([utils.take_rows(t, rows) for t in tables], dim=1)  # chunked: see utils.gather_rows
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     if average:
         buf /= ws
     for t, piece in zip(tables, torch.split(buf, widths, dim=1)):
-        t[rows] = piece
+        utils.put_rows(t, rows, piece)
 
 
 # ------------------------------------------------------------------ owner-computes exchange

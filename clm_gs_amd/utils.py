@@ -221,6 +221,24 @@ def select_rows(t, mask, chunk=1 << 25):
     return torch.cat([t[a:a + chunk][mask[a:a + chunk]] for a in range(0, n, chunk)], dim=0)
 
 
+def take_rows(t, idx, chunk=1 << 23):
+    """t[idx] (int64 row ids, any count) in chunks of `chunk` indices; see gather_rows."""
+    n = idx.numel()
+    if n <= chunk:
+        return t[idx]
+    out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    for a in range(0, n, chunk):
+        out[a:a + chunk] = t[idx[a:a + chunk]]
+    return out
+
+
+def put_rows(t, idx, src, chunk=1 << 23):
+    """t[idx] = src in chunks of `chunk` indices (unique row ids)."""
+    n = idx.numel()
+    for a in range(0, n, chunk):
+        t[idx[a:a + chunk]] = src[a:a + chunk]
+
+
 def gather_rows(t, order, chunk=1 << 23):
     """t[order] for row tables of any size, gathered in chunks of rows (a single advanced-indexing call
     over a 102 M-row table returned rows of zeros for part of the output on ROCm 7 / torch 2.10)."""
