@@ -117,10 +117,11 @@ def make_gt_images(cams, scene, args_ns, width, height):
 
 def cpu_baseline(gaussians, cam, width, height, budget_s):
     """C oracle (OpenMP port) on a bounded sample: one micro-batch (camera 0) of the same scene,
-    cropped to a centred window sized to ~budget_s of CPU work; forward + loss + backward."""
-    import numpy as np
-
-    from clm_gs_amd.strategies.base_engine import calculate_filters
+    cropped to a centred window sized to ~budget_s of CPU work; forward + loss + backward.  The SAME
+    window then goes through the product's fused HIP path and the two results are compared
+    (oracle/camera_parity.py): `parity` = image PSNR, |loss|, radii / intersection-count mismatches and the
+    rel-L2 error of every gradient tensor -- at the size the bench runs, on the model the timed steps
+    have just trained."""
     from clm_gs_amd import _lib
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # all host cores this process may run on (SURVEY 8d): the affinity mask AND the cgroup CPU quota -- the
@@ -129,48 +130,50 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     usable = max(1, min(affinity, _lib.lib().clmgs_host_usable_cpus()))
     os.environ.setdefault("OMP_NUM_THREADS", str(usable))
     from oracle import c_oracle as C
+    from oracle import camera_parity as CP
     C.set_num_threads(usable)
+    if hasattr(gaussians, "flush_lazy_rows"):
+        gaussians.flush_lazy_rows()  # the SH rows both sides read are current
 
-    with torch.no_grad():
-        filters, _, _ = calculate_filters([cam], gaussians.get_xyz, gaussians.get_opacity,
-                                          gaussians.get_scaling, gaussians.get_rotation)
-        f = filters[0]
-        means = gaussians._xyz.detach()[f].cpu().numpy()
-        quats = gaussians.get_rotation.detach()[f].cpu().numpy()
-        scales = gaussians.get_scaling.detach()[f].cpu().numpy()
-        opac = gaussians.get_opacity.detach()[f].cpu().numpy()
-        p = gaussians._parameters.detach()
-        shs = (p[f] if p.is_cuda else p[f.cpu()]).cpu().numpy()
-        viewmat = cam.world_view_transform.t().contiguous().cpu().numpy()
-        K = cam.K.cpu().numpy().copy()
-        gt = cam.original_image.cpu().numpy()
-
-    def run(cw, ch):
-        x0, y0 = (width - cw) // 2 // 16 * 16, (height - ch) // 2 // 16 * 16
-        Kc = K.copy()
-        Kc[0, 2] -= x0
-        Kc[1, 2] -= y0
-        gtc = np.ascontiguousarray(gt[:, y0:y0 + ch, x0:x0 + cw])
-        t0 = time.perf_counter()
-        fw = C.render_forward(means, quats, scales, opac, shs, 3, viewmat, Kc, cw, ch)
-        C.loss_and_backward(fw, gtc)
-        return time.perf_counter() - t0, fw["n_isects"], int((fw["radii"] > 0).sum())
+    def oracle_only(cw, ch):
+        from clm_gs_amd import utils
+        from clm_gs_amd.strategies.base_engine import calculate_filters
+        wcam, w, h = CP.window_camera(cam, width, height, cw, ch)
+        utils.set_img_size(h, w)
+        try:
+            with torch.no_grad():
+                filters, _, _ = calculate_filters([wcam], gaussians.get_xyz, gaussians.get_opacity,
+                                                  gaussians.get_scaling, gaussians.get_rotation)
+            inp = CP.oracle_inputs(gaussians, wcam, filters[0])
+        finally:
+            utils.set_img_size(height, width)
+        return CP.oracle_camera(inp, w, h, int(gaussians.active_sh_degree))[1]
 
     cw, ch = min(width, 512), min(height, 384)
-    t_cal, _, _ = run(cw, ch)  # calibration crop
+    t_cal = oracle_only(cw, ch)  # calibration crop
     frac = (cw * ch) / float(width * height)
     scale = max(1.0, min(1.0 / frac, budget_s / max(t_cal, 1e-3)))
     s = math.sqrt(scale)
     cw2, ch2 = min(width, int(cw * s) // 16 * 16), min(height, int(ch * s) // 16 * 16)
-    t, isects, vis = run(cw2, ch2)
+    if cw2 * ch2 >= 0.9 * width * height:  # the budget reaches (nearly) the whole image: take all of it
+        cw2, ch2 = width, height
+    rep, t = CP.camera_parity(gaussians, cam, width, height, rows="visible", cw=cw2, ch=ch2)
     frac2 = (cw2 * ch2) / float(width * height)
+    parity_ok = rep["violations"] == []
     return {
         "value": frac2 / t, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
         "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads = the CPUs this container may use: cgroup quota / "
                    f"affinity, of {os.cpu_count()} hardware threads): "
-                   f"1 micro-batch (camera 0, V={len(means)} rows in), centred {cw2}x{ch2} crop = "
-                   f"{frac2:.4f} of the {width}x{height} image, {vis} visible, {isects} intersections, "
-                   f"forward+loss+backward in {t:.2f}s; value = crop fraction / time"),
+                   f"1 micro-batch (camera 0, V={rep['rows']} rows in), centred {cw2}x{ch2} window = "
+                   f"{frac2:.4f} of the {width}x{height} image, {rep['n_visible']} visible, {rep['n_isects_oracle']} intersections, "
+                   f"forward+loss+backward in {t:.2f}s; value = window fraction / time"),
+        "parity": {"ok": bool(parity_ok),
+                   "what": "the same window through the fused HIP path (clm_gs_amd.fused.camera_forward/backward) vs the "
+                           "oracle (oracle/camera_parity.py: image >= 60 dB, |loss| <= 1e-5, radii / intersection total "
+                           "bit-exact up to counted fp32 ceil() ties, raw-parameter gradients rel-L2 <= 1e-3 per tensor on "
+                           "the same loss cotangent; `natural` = each side's own cotangent, bounded by the counted "
+                           "sign(image-gt) ties of the L1 term)",
+                   **{k: (round(v, 9) if isinstance(v, float) else v) for k, v in rep.items()}},
     }
 
 

@@ -596,13 +596,15 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
   CLMGS_CHECK_ARG(!v_means2d || (v_conics && v_colors && v_opacities));
-  const bool part = emit_slot != nullptr;
-  CLMGS_CHECK_ARG(!part || (C == 1 && partials && (((uintptr_t)partials & 63) == 0)));
-  // packed_grad == NULL (slot mode only): the caller sums the partial lines itself (clmgs_preprocess_bwd)
-  CLMGS_CHECK_ARG(packed_grad ? ((((uintptr_t)packed_grad & 63) == 0) && (!part || row_cum)) : (part && !v_means2d));
   hipStream_t s = (hipStream_t)stream;
   const int64_t CN = (int64_t)C * N;
-  if (CN == 0) return 0;
+  if (CN == 0) return 0;  // nothing to differentiate: no argument below is required to exist
+  // slot mode is selected by the partial-line table: a camera without a single intersection hands over
+  // an EMPTY emit_slot (NULL data pointer) and must still be accepted (its gradients are all zero)
+  const bool part = partials != nullptr;
+  CLMGS_CHECK_ARG(!part || (C == 1 && (emit_slot || n_isects == 0) && (((uintptr_t)partials & 63) == 0)));
+  // packed_grad == NULL (slot mode only): the caller sums the partial lines itself (clmgs_preprocess_bwd)
+  CLMGS_CHECK_ARG(packed_grad ? ((((uintptr_t)packed_grad & 63) == 0) && (!part || row_cum)) : (part && !v_means2d));
   if (packed_grad && (!part || n_isects == 0))
     CLMGS_HIP(hipMemsetAsync(packed_grad, 0, clmgs_rasterize_pack_bytes(C, N), s));
   if (n_isects > 0) {

@@ -158,10 +158,11 @@ def owner_gather_rows(table, pl):
     W = table.shape[1]
     send = torch.zeros((pl.chunk, W), dtype=table.dtype, device=table.device)
     if pl.hi > pl.lo:
-        send[: pl.hi - pl.lo] = table[pl.rows[pl.lo:pl.hi]]
+        send[: pl.hi - pl.lo] = utils.take_rows(table, pl.rows[pl.lo:pl.hi])
     recv = torch.empty((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
     dist.all_gather_into_tensor(recv, send)
-    table[pl.rows] = recv[pl.pos]
+    _count("all_gather", send.numel() * send.element_size() * (pl.n_ranks - 1))
+    utils.put_rows(table, pl.rows, utils.take_rows(recv, pl.pos))
 
 
 def owner_reduce_rows(table, pl):
@@ -171,12 +172,13 @@ def owner_reduce_rows(table, pl):
         return
     W = table.shape[1]
     buf = torch.zeros((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
-    buf[pl.pos] = table[pl.rows]
+    utils.put_rows(buf, pl.pos, utils.take_rows(table, pl.rows))
     mine = torch.empty((pl.chunk, W), dtype=table.dtype, device=table.device)
     dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
-    table[pl.rows] = 0
+    _count("reduce_scatter", mine.numel() * mine.element_size() * (pl.n_ranks - 1))
+    utils.fill_rows(table, pl.rows, 0.0)
     if pl.hi > pl.lo:
-        table[pl.rows[pl.lo:pl.hi]] = mine[: pl.hi - pl.lo]
+        utils.put_rows(table, pl.rows[pl.lo:pl.hi], mine[: pl.hi - pl.lo])
 
 
 def owner_gather_dense(tables, n_total):

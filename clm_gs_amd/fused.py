@@ -47,7 +47,7 @@ class _CameraPass:
     __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
                  "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids",
                  "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux", "loss_partials",
-                 "lambda_dssim", "gt_u8", "background", "isect", "sh_index")
+                 "lambda_dssim", "gt_u8", "background", "isect", "sh_index", "means2d")
 
 
 def _sptr(torch_stream):
@@ -112,6 +112,7 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
         p.isect = isect2_begin(means2d, radii, depths, TILE, tw, th, want_slots=True,
                                packed=packed if getattr(args, "exact_tile_cull", True) else None)
         p.aux = p.aux + (means2d, depths)
+        p.means2d = means2d  # [1,V,2] pixel centres (parity checks read them; kept alive through p.aux)
     return p
 
 
@@ -265,6 +266,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
                 for st in {s_mem, s_raster} - {s_front}:
                     t.record_stream(st)
         p.aux = (p.loss_partials,)
+        p.means2d = None
     return p
 
 

@@ -239,6 +239,14 @@ def put_rows(t, idx, src, chunk=1 << 23):
         t[idx[a:a + chunk]] = src[a:a + chunk]
 
 
+def fill_rows(t, idx, value, chunk=1 << 23):
+    """t[idx] = value (a scalar) in chunks of `chunk` indices; index_fill_ takes the scalar as a kernel
+    argument (no host -> device copy of a 0-dim tensor, which would block the enqueueing thread)."""
+    n = idx.numel()
+    for a in range(0, n, chunk):
+        t.index_fill_(0, idx[a:a + chunk], value)
+
+
 def gather_rows(t, order, chunk=1 << 23):
     """t[order] for row tables of any size, gathered in chunks of rows (a single advanced-indexing call
     over a 102 M-row table returned rows of zeros for part of the output on ROCm 7 / torch 2.10)."""

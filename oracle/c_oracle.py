@@ -84,15 +84,29 @@ def render_forward(means, quats, scales, opac, shs48, sh_degree, viewmat, K, wid
                             viewmat=viewmat, K=K, sh_degree=sh_degree, width=width, height=height))
 
 
-def loss_and_backward(fw, gt_u8):
-    """Loss (0.8 L1 + 0.2 (1-SSIM)) and gradients w.r.t. the ACTIVATED inputs of render_forward."""
+def loss_and_cotangent(fw, gt_u8):
+    """-> (loss, d loss / d image as [3,H,W])."""
     L = lib()
     i = fw["inputs"]
-    n, width, height = fw["n"], i["width"], i["height"]
     img_chw = np.ascontiguousarray(fw["image_hwc"].transpose(2, 0, 1))
     v_img = np.zeros_like(img_chw)
     gt = np.ascontiguousarray(gt_u8, dtype=np.uint8)
-    loss = L.orc_loss(height, width, _p(img_chw), _p(gt), _p(v_img))
+    loss = L.orc_loss(i["height"], i["width"], _p(img_chw), _p(gt), _p(v_img))
+    return float(loss), v_img
+
+
+def loss_and_backward(fw, gt_u8, v_image=None, loss=None):
+    """Loss (0.8 L1 + 0.2 (1-SSIM)) and gradients w.r.t. the ACTIVATED inputs of render_forward.
+    v_image ([3,H,W]): use this loss cotangent instead of the oracle's own (the backward of everything
+    below the loss on a given cotangent); `loss` then labels the result."""
+    L = lib()
+    i = fw["inputs"]
+    n, width, height = fw["n"], i["width"], i["height"]
+    if v_image is None:
+        loss, v_img = loss_and_cotangent(fw, gt_u8)
+    else:
+        v_img = np.ascontiguousarray(v_image, dtype=np.float32)
+        loss = float("nan") if loss is None else loss
     v_out = np.ascontiguousarray(v_img.transpose(1, 2, 0))
     v_m2, v_con = np.zeros((n, 2), np.float32), np.zeros((n, 3), np.float32)
     v_col, v_op = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)

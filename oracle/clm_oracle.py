@@ -161,6 +161,47 @@ class FusedCPUAdam(torch.optim.Optimizer):
                 p.grad.zero_()
 
 
+# ---- cpu_adam.CPUAdam (strategies/naive_offload/gaussian_model.py:146; naive_offload/engine.py:328-334)
+class CPUAdam(torch.optim.Optimizer):
+    """The plain multi-group host Adam of the naive_offload strategy (DeepSpeed cpu_adam, weight decay 0):
+    every group has ONE learning rate; step() walks every row, sparse_step(sparse_indices) only the listed
+    rows; one step counter per optimizer call, bias correction as in FusedCPUAdam (step_size = lr / bc1,
+    denom = sqrt(v) / sqrt(bc2) + eps).  The engine has already divided the gradients by bsz
+    (naive_offload/engine.py:322-324)."""
+
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-8, weight_decay=0,
+                 amsgrad=False, adamw_mode=True, fp32_optimizer_states=True):
+        super().__init__(params, dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps,
+                                      weight_decay=weight_decay, amsgrad=amsgrad))
+        self.global_step = 0
+
+    def _update(self, rows):
+        self.global_step += 1
+        with torch.no_grad():
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p.data)
+                        st["exp_avg_sq"] = torch.zeros_like(p.data)
+                    st["step"] = self.global_step
+                    n = p.shape[0]
+                    P, G = p.data.view(n, -1), p.grad.view(n, -1)
+                    M, V = st["exp_avg"].view(n, -1), st["exp_avg_sq"].view(n, -1)
+                    col_lr = torch.full((P.shape[1],), float(g["lr"]))
+                    O.adam_rows(P, G, M, V, rows, col_lr, g["betas"][0], g["betas"][1], g["eps"],
+                                self.global_step, 1.0, g["bias_correction"], False)
+
+    def step(self, closure=None):
+        self._update(None)
+
+    def sparse_step(self, sparse_indices=None, closure=None):
+        self._update(sparse_indices)
+
+
 # ---- fast_tsp.find_tour (strategies/clm_offload/engine.py:179): any tour is valid (the upstream solver
 # is time-budgeted and not reproducible); here the optimal OPEN tour by brute force for small n,
 # greedy nearest neighbour otherwise.

@@ -17,6 +17,9 @@ oracle/gs_oracle.py plugged in as `gsplat` / `clm_kernels`, and commits what it 
                           on the statistics of the batch above: masks, the normal draws of the split,
                           every tensor and both Adam moments after the surgery, and the schedule
                           (which iterations densify / reset opacity).
+  engine_naive_offload.npz strategies/naive_offload/engine.py:48-357 naive_offload_train_one_batch, 3 batches
+                          dense and 3 with sparse_adam (cpu_adam.CPUAdam stood in by oracle/clm_oracle.py):
+                          losses, parameters + both moments of the six groups, statistics, eval image.
   arguments_defaults.json arguments/__init__.py: parser.parse_args([]) of the six ParamGroups.
 
 The GPU tests compare the HIP engines with these files; the CPU tests re-derive them from the oracle
@@ -154,6 +157,45 @@ def clm_stage(sc, cams, Scene, rutils, mode):
     print("clm_offload fixture written; losses", out["losses_b0"], "order", out["ordered_cams_b0"])
 
 
+def naive_stage(sc, cams, Scene, rutils):
+    """strategies/naive_offload/engine.py:48-357 naive_offload_train_one_batch (all parameters in host
+    memory, whole-model upload per batch, cpu_adam.CPUAdam over six groups), 3 batches dense + the same 3
+    batches with sparse_adam=True (sparse_step over the visible rows) -> engine_naive_offload.npz."""
+    from strategies.naive_offload.engine import naive_offload_eval_one_cam, naive_offload_train_one_batch
+    from strategies.naive_offload.gaussian_model import GaussianModelNaiveOffload
+    out = {}
+    for tag, sparse in (("dense", False), ("sparse", True)):
+        args, _ = RH.reference_default_args(naive_offload=True, bsz=BSZ, sparse_adam=sparse)
+        rutils.set_args(args)
+        m = make_ref_model(sc, args, GaussianModelNaiveOffload)
+        m.sum_visible_count_in_one_batch = torch.zeros((N,))
+        if tag == "dense":
+            out["groups_json"] = json.dumps({g["name"]: dict(lr=float(g["lr"]), eps=float(g["eps"]),
+                                                              betas=[float(b) for b in g["betas"]])
+                                             for g in m.optimizer.param_groups})
+        iteration = 1
+        for b in range(N_BATCHES):
+            rutils.set_cur_iter(iteration)
+            m.update_learning_rate(iteration)
+            losses, vis = naive_offload_train_one_batch(m, Scene, cams[b * BSZ:(b + 1) * BSZ], None, sparse_adam=sparse)
+            out[f"{tag}_losses_b{b}"] = np.array([float(l) for l in losses])
+            if sparse:
+                out[f"{tag}_visibility_b{b}"] = np_(vis)
+            assert all(p.grad is None for p in m.all_parameters())  # zero_grad(set_to_none=True), engine.py:336
+            iteration += BSZ
+        for g in m.optimizer.param_groups:
+            p = g["params"][0]
+            st = m.optimizer.state[p]
+            out[f"{tag}_p_{g['name']}"], out[f"{tag}_m_{g['name']}"], out[f"{tag}_v_{g['name']}"] = \
+                np_(p), np_(st["exp_avg"]), np_(st["exp_avg_sq"])
+        out[f"{tag}_xyz_gradient_accum"], out[f"{tag}_denom"] = np_(m.xyz_gradient_accum), np_(m.denom)
+        out[f"{tag}_max_radii2D"] = np_(m.max_radii2D)
+        if tag == "dense":
+            out["eval_image_cam0"] = np_(naive_offload_eval_one_cam(m, Scene, cams[0], None))
+    np.savez_compressed(os.path.join(HERE, "engine_naive_offload.npz"), **out)
+    print("naive_offload fixture written; losses", out["dense_losses_b0"], out["sparse_losses_b2"])
+
+
 def main():
     RH.install_stubs()
     import utils.general_utils as rutils
@@ -181,6 +223,11 @@ def main():
     with RH.CudaToCpu() as mode:
         if "densify" in sys.argv[1:]:
             return densify_stage(sc, Scene, rutils)
+        if "naive" in sys.argv[1:] or len(sys.argv) == 1:
+            naive_stage(sc, cams, Scene, rutils)
+            if "naive" in sys.argv[1:]:
+                return
+            rutils.set_args(args)
         if "clm" in sys.argv[1:] or len(sys.argv) == 1:
             clm_stage(sc, cams, Scene, rutils, mode)
             if "clm" in sys.argv[1:]:

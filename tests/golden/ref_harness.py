@@ -122,6 +122,7 @@ def install_stubs(oracle_gsplat=True):
 
     ca = types.ModuleType("cpu_adam")
     ca.FusedCPUAdam = CO.FusedCPUAdam
+    ca.CPUAdam = CO.CPUAdam
     sys.modules["cpu_adam"] = ca
     ft = types.ModuleType("fast_tsp")
     ft.find_tour = CO.find_tour
@@ -136,7 +137,6 @@ def install_stubs(oracle_gsplat=True):
     sys.modules["numba"].cuda = sys.modules["numba.cuda"]
     sys.modules["numba.cuda"].pinned_array = lambda shape, dtype=None: __import__("numpy").zeros(shape, dtype)
     sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
-    sys.modules["cpu_adam"].CPUAdam = object
 
     torch._dynamo.config.disable = True
     nv = torch.cuda.nvtx

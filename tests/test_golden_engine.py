@@ -159,3 +159,24 @@ def test_trainer_log_lines_are_what_the_reference_scraper_parses():
     assert p["num_3dgs"] == 1215377 and p["iterations"] == 30001
     assert abs(p["total_time_s"] - 351.06) < 1e-9 and abs(p["throughput"] - 85.46) < 1e-9
     assert p["max_gpu_memory_gb"] == 1.75 and p["pinned_cpu_memory_gb"] is not None
+
+
+def test_reference_naive_offload_run_agrees_with_reference_no_offload_run():
+    """engine_naive_offload.npz (the reference's naive_offload_train_one_batch, 3 batches, host CPUAdam stood in
+    by oracle/clm_oracle.CPUAdam) vs engine_no_offload.npz (the reference's baseline engine + torch Adam):
+    two engines of the reference, two optimizers, one trajectory -- the stand-in did not bend the run.  The
+    sparse run differs from the dense one exactly on rows some batch did not see."""
+    a, b = _load("engine_naive_offload.npz"), _load("engine_no_offload.npz")
+    for bi in range(3):
+        assert np.allclose(a[f"dense_losses_b{bi}"], b[f"losses_b{bi}"], atol=1e-6)
+    for n in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+        for k in "pmv":
+            x, y = a[f"dense_{k}_{n}"], b[f"{k}_{n}"]
+            assert np.linalg.norm(x - y) <= 1e-6 * np.linalg.norm(y) + 1e-12, (n, k)
+    assert np.array_equal(a["dense_denom"], b["stats3_denom"])
+    assert np.array_equal(a["dense_max_radii2D"], b["stats3_max_radii2D"])
+    seen_all = a["sparse_visibility_b0"] & a["sparse_visibility_b1"] & a["sparse_visibility_b2"]
+    assert 0 < seen_all.sum() < seen_all.size
+    never = ~(a["sparse_visibility_b0"] | a["sparse_visibility_b1"] | a["sparse_visibility_b2"])
+    assert never.any() and np.array_equal(a["sparse_p_xyz"][never], b["xyz"][never])  # never visible: never stepped
+    assert not np.allclose(a["sparse_m_xyz"][~seen_all], a["dense_m_xyz"][~seen_all])

@@ -547,3 +547,32 @@ def test_spatial_sort_mid_training_is_a_pure_relabelling(dev, strategy, residenc
     assert torch.equal(got["denom"], ref["denom"][perm]) and torch.equal(got["radii"], ref["radii"][perm])
     for k in ref:
         assert rel_l2(got[k], ref[k][perm]) < 1e-5, k
+
+
+def test_camera_without_intersections_trains_with_zero_gradients(dev):
+    """A training camera that sees nothing (clmgs_rasterize_bwd rejected the empty emit_slot of a
+    camera with zero tile intersections).  Two forms: a non-empty row set whose radii are all 0 (every
+    Gaussian behind the camera) and an empty filter.  Both must run the whole forward + loss + backward,
+    render the background-free black image and leave every gradient exactly zero."""
+    from clm_gs_amd import fused
+    args, sc, cams = _setup("clm_offload")
+    m = _make("clm_offload", sc, args)
+    cam = cams[0]
+    with torch.no_grad():  # move the whole scene behind the camera (nadir camera looks down -z)
+        m._xyz[:, 2] += 1.0e4
+    m.invalidate_small_packed()
+    for rows in (None, torch.empty(0, dtype=torch.int64, device="cuda")):
+        for p in (m._xyz, m._opacity, m._scaling, m._rotation):
+            p.grad = torch.zeros_like(p)
+        V = N if rows is None else 0
+        sh = m._parameters.data if rows is None else torch.empty((0, 48), device="cuda")
+        g_sh = torch.zeros((max(V, 1), 48), device="cuda")[:V]
+        p = fused.camera_forward(m, cam, rows, sh, 0, None, cam.original_image)
+        assert p.fids.numel() == 0
+        fused.camera_backward(m, p, g_sh, update_stats=False)
+        loss = fused.camera_loss(p)
+        torch.cuda.synchronize()
+        assert float(p.out.abs().max()) == 0.0 and 0.0 < loss.item() < 1.0
+        assert float(g_sh.abs().sum()) == 0.0
+        for q in (m._xyz, m._opacity, m._scaling, m._rotation):
+            assert float(q.grad.abs().max()) == 0.0

@@ -46,7 +46,8 @@ def _rec(key, val):
 
 @pytest.fixture(scope="module")
 def fx():
-    return {k: np.load(os.path.join(G, f"engine_{k}.npz")) for k in ("no_offload", "clm_offload", "filters", "densify")}
+    return {k: np.load(os.path.join(G, f"engine_{k}.npz")) for k in ("no_offload", "clm_offload", "filters", "densify",
+                                                                      "naive_offload")}
 
 
 def _t(a):
@@ -289,6 +290,66 @@ def test_eval_and_forward_paths_match_reference_image(dev, fx):
     m.invalidate_small_packed()
     img = clm_offload_eval_one_cam(cams[0], m, None, Scene)
     assert _rec("eval.same_params.psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 100.0
+
+
+# ------------------------------------------------------------------ f4: naive_offload
+@pytest.mark.parametrize("sparse", [False, True])
+def test_naive_offload_three_batches_match_reference_engine(dev, fx, sparse):
+    """The reference's OWN naive_offload_train_one_batch (strategies/naive_offload/engine.py:48-357: whole
+    model uploaded per batch, torch.gather of the visible rows, scatter_add of their gradients, grad /= bsz,
+    cpu_adam.CPUAdam.step / sparse_step over six host groups) ran 3 batches in the build container
+    (tests/golden/make_engine_golden.py naive_stage); this build's naive_offload engine (two pinned tables,
+    fused per-camera kernels, clmgs_host_adam_rows) must end in the same state: losses, parameters and
+    both moments of every group, statistics, eval image; sparse_adam: visibility masks too."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.cameras import Camera
+    from clm_gs_amd.strategies.naive_offload import (GaussianModelNaiveOffload, naive_offload_eval_one_cam,
+                                                     naive_offload_train_one_batch)
+    d, d0 = fx["naive_offload"], fx["no_offload"]
+    W, H, bsz = int(d0["W"]), int(d0["H"]), int(d0["bsz"])
+    args = utils.default_args(bsz=bsz, sparse_adam=sparse)
+    args.naive_offload = True
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    cams = [Camera(i, _t(d0["w2c"][i]), float(d0["fovx"]), float(d0["fovy"]), W, H, _t(d0["gt"][i]))
+            for i in range(d0["w2c"].shape[0])]
+    m = GaussianModelNaiveOffload(3)
+    m.create_from_tensors(_t(d0["xyz"]).clone(), _t(d0["shs48"]).clone(), _t(d0["scaling"]).clone(),
+                          _t(d0["rotation"]).clone(), _t(d0["opacity"]).clone(), spatial_lr_scale=1.0)
+    m.active_sh_degree = 3
+    m.training_setup(args)
+
+    class Scene:
+        cameras_extent = float(d0["extent"])
+    tag = "sparse" if sparse else "dense"
+    it = 1
+    for b in range(int(d0["n_batches"])):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        losses, vis = naive_offload_train_one_batch(m, Scene, cams[b * bsz:(b + 1) * bsz], None, sparse_adam=sparse)
+        for a, r in zip(losses, d[f"{tag}_losses_b{b}"]):
+            assert abs(a.item() - r) < 5e-5, (b, a.item(), r)
+        if sparse:
+            assert np.array_equal(vis.cpu().numpy(), d[f"sparse_visibility_b{b}"])
+        it += bsz
+    torch.cuda.synchronize()
+    sm, rw = m._small.detach(), m._parameters.detach()
+    st_s, st_r = m.small_adam.state[m._small], m.row_adam.state[m._parameters]
+    cols = {"xyz": (sm, st_s, 0, 3), "opacity": (sm, st_s, 3, 4), "scaling": (sm, st_s, 4, 7), "rotation": (sm, st_s, 7, 11),
+            "f_dc": (rw, st_r, 0, 3), "f_rest": (rw, st_r, 3, 48)}
+    init = {"xyz": _t(d0["xyz"]), "opacity": _t(d0["opacity"]), "scaling": _t(d0["scaling"]), "rotation": _t(d0["rotation"]),
+            "f_dc": _t(d0["shs48"])[:, :3], "f_rest": _t(d0["shs48"])[:, 3:]}
+    dd = {k[len(tag) + 1:]: d[k] for k in d.files if k.startswith(tag + "_")}
+    for name, (p, st, a, b) in cols.items():
+        _adam_close(f"naive3.{tag}", name, p[:, a:b].contiguous(), st["exp_avg"][:, a:b].contiguous(),
+                    st["exp_avg_sq"][:, a:b].contiguous(), dd, init[name])
+    assert torch.equal(m.denom.cpu(), _t(dd["denom"]))
+    assert torch.equal(m.max_radii2D.cpu(), _t(dd["max_radii2D"]))
+    assert _rec(f"naive3.{tag}.xyz_gradient_accum.rel_l2", rel_l2(m.xyz_gradient_accum.cpu(), _t(dd["xyz_gradient_accum"]))) < 5e-5
+    if not sparse:
+        img = naive_offload_eval_one_cam(m, Scene, cams[0], None)
+        assert _rec("naive3.eval_psnr", psnr(img.cpu(), _t(d["eval_image_cam0"]))) > 100.0
 
 
 # ------------------------------------------------------------------ a13: densification
