@@ -6,6 +6,17 @@ OR of the touched-row mask, and sum of the SH gradient rows restricted to the un
 rows.  Densification statistics accumulate locally and are reduced only right before
 densify_and_prune (sum / sum / max).  Everything is plain torch.distributed (backend "nccl" is
 RCCL over xGMI on ROCm; the CPU tests use gloo), device-agnostic tensors.
+
+Three exchanges (engine option in brackets), same result after flush_lazy_rows():
+  all-reduce      [default]            every rank steps every row: 240 B x globally touched rows, all-reduced
+  owner-computes  [dp_owner_computes]  rows owned by index range; all-gather params / reduce-scatter grads
+  locality        [dp_locality]        owner-computes + point-to-point: a rank fetches ONLY the rows its own
+                                       cameras touch outside its range from their owners (all_to_all), sends
+                                       their gradients back, and the owners publish the summed small-attribute
+                                       gradients of their touched rows (all-gather).  With Z-ordered rows a
+                                       rank's range is a spatial region; assign_cameras() deals every camera to
+                                       the rank owning most of its rows, so most touched rows never travel.
+WIRE counts the bytes this rank SENDS per exchange (ring model for all-reduce), see wire_bytes().
 """
 import os
 
@@ -13,6 +24,31 @@ import torch
 import torch.distributed as dist
 
 from . import utils
+
+
+WIRE = {}  # exchange kind -> bytes this rank has sent since reset_wire()
+
+
+def _count(kind, nbytes):
+    WIRE[kind] = WIRE.get(kind, 0) + int(nbytes)
+
+
+def reset_wire():
+    WIRE.clear()
+
+
+def wire_bytes():
+    """-> {kind: bytes sent by this rank, ..., "total": sum}.  Model: an all-reduce of B bytes over G ranks
+    sends 2 (G-1)/G B per rank (reduce-scatter + all-gather, ring or full mesh alike); an all-gather /
+    reduce-scatter with a per-rank block of c bytes sends (G-1) c; an all_to_all sends what leaves the rank."""
+    d = dict(WIRE)
+    d["total"] = sum(WIRE.values())
+    return d
+
+
+def _allreduce_bytes(nbytes):
+    g = max(1, world_size())
+    return 2.0 * (g - 1) / g * nbytes
 
 
 def world_size():
@@ -43,6 +79,7 @@ def allreduce_small_grads(grads, average=True):
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
     for w in works:
         w.wait()
+    _count("all_reduce", sum(_allreduce_bytes(g.numel() * g.element_size()) for g in grads))
     if average:
         for g in grads:
             g /= ws
@@ -54,6 +91,7 @@ def allreduce_touched(touched):
         return touched
     t = touched.to(torch.uint8)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _count("all_reduce_mask", _allreduce_bytes(t.numel()))
     return t.to(torch.bool)
 
 
@@ -71,12 +109,14 @@ def allreduce_rows(grad_rows, touched_global, average=True, rows=None):
     if 2 * n_touched >= grad_rows.shape[0]:
         # most rows are in play: reduce the whole buffer in place, no pack / unpack copies
         dist.all_reduce(grad_rows, op=dist.ReduceOp.SUM)
+        _count("all_reduce", _allreduce_bytes(grad_rows.numel() * grad_rows.element_size()))
         if average:
             grad_rows /= ws
         return
     rows = rows.long()
     buf = utils.take_rows(grad_rows, rows)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    _count("all_reduce", _allreduce_bytes(buf.numel() * buf.element_size()))
     if average:
         buf /= ws
     utils.put_rows(grad_rows, rows, buf)
@@ -99,6 +139,7 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
         works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in tables]
         for w in works:
             w.wait()
+        _count("all_reduce", sum(_allreduce_bytes(t.numel() * t.element_size()) for t in tables))
         if average:
             for t in tables:
                 t /= ws
@@ -107,6 +148,7 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
     widths = [t.shape[1] for t in tables]
     buf = torch.cat([utils.take_rows(t, rows) for t in tables], dim=1)  # chunked: see utils.gather_rows
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    _count("all_reduce", _allreduce_bytes(buf.numel() * buf.element_size()))
     if average:
         buf /= ws
     for t, piece in zip(tables, torch.split(buf, widths, dim=1)):
@@ -194,10 +236,213 @@ def owner_gather_dense(tables, n_total):
         send[: hi - lo] = t2[lo:hi]
         recv = torch.empty((G * chunk, t2.shape[1]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(recv, send)
+        _count("flush_all_gather", send.numel() * send.element_size() * (G - 1))
         for q in range(G):
             a, b = owner_range(n_total, q, G)
             if q != rank():
                 t2[a:b] = recv[q * chunk: q * chunk + (b - a)]
+
+
+# ------------------------------------------------------------------ locality exchange (dp_locality)
+# Owner-computes with point-to-point traffic only.  Rank r's cameras touch the ascending row list T_r.
+#   A  border_plan        : T_r splits into `mine` (own range) and `border` (grouped by owner, ascending);
+#                           one all_to_all of counts + one of row ids tells every owner which rows to serve
+#   B  border_params_out  : owners send the CURRENT parameter rows of the requested ids (after their deferred
+#                           optimizer caught them up); the requester writes them into its replica at the row ids
+#   -- render: gradients accumulate by row id as on one GPU (first-touch stores, stamp = this step) --
+#   D  border_grads_home  : the requester returns the gradient rows (SH row | packed small row, 240 B) of its
+#                           border rows; the owner adds them, requester by requester in rank order (deterministic),
+#                           storing instead of adding -- and stamping -- where the row had no gradient this step yet
+#   F  publish_small      : every owner all-gathers (row id, summed packed small gradient) of ITS rows touched
+#                           this step, so that the replicated small-attribute Adam (the next visibility pass
+#                           needs every row's position on every rank) sees the same global sum everywhere
+# Nothing else travels: a row deep inside a rank's region costs 52 B per peer (step F) instead of 240 B x 2 (G-1)/G.
+class BorderPlan:
+    __slots__ = ("n_ranks", "rank", "lo", "hi", "n_total", "mine", "border", "need", "serve", "serve_rows")
+
+
+def border_plan(touched_rows, n_total):
+    """touched_rows: ascending int64 ids this rank's cameras touch.  Two small collectives, ONE host read."""
+    G, r = world_size(), rank()
+    dev = touched_rows.device
+    cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
+    b = torch.searchsorted(touched_rows, cuts)
+    need = b[1:] - b[:-1]
+    need[r] = 0
+    serve = torch.empty_like(need)
+    dist.all_to_all_single(serve, need)
+    host = torch.cat((b, need, serve)).tolist()
+    bl, need_l, serve_l = host[:G + 1], host[G + 1:2 * G + 1], host[2 * G + 1:]
+    bl[0], bl[-1] = 0, int(touched_rows.numel())
+    pl = BorderPlan()
+    pl.n_ranks, pl.rank, pl.n_total = G, r, n_total
+    pl.lo, pl.hi = owner_range(n_total, r, G)
+    pl.mine = touched_rows[bl[r]:bl[r + 1]]
+    pl.border = torch.cat((touched_rows[:bl[r]], touched_rows[bl[r + 1]:]))
+    pl.need, pl.serve = need_l, serve_l
+    pl.serve_rows = torch.empty((sum(serve_l),), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(pl.serve_rows, pl.border, output_split_sizes=serve_l, input_split_sizes=need_l)
+    _count("all_to_all_ids", 8 * (G + pl.border.numel()))
+    return pl
+
+
+def border_own_rows(pl):
+    """Rows of this rank's range that anybody touches this batch (own cameras or served), ascending."""
+    dev = pl.mine.device
+    mark = torch.zeros((max(1, pl.hi - pl.lo),), dtype=torch.bool, device=dev)
+    if pl.mine.numel():
+        mark.index_fill_(0, pl.mine - pl.lo, True)
+    if pl.serve_rows.numel():
+        mark.index_fill_(0, pl.serve_rows - pl.lo, True)
+    return torch.nonzero(mark).flatten() + pl.lo
+
+
+def border_params_out(table, pl):
+    """B: table[border] <- the owners' rows."""
+    W = table.shape[1]
+    send = utils.take_rows(table, pl.serve_rows) if pl.serve_rows.numel() else table.new_empty((0, W))
+    recv = table.new_empty((pl.border.numel(), W))
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=pl.need, input_split_sizes=pl.serve)
+    _count("all_to_all_params", send.numel() * send.element_size())
+    if pl.border.numel():
+        utils.put_rows(table, pl.border, recv)
+
+
+def border_grads_home(tables, stamp, step, pl):
+    """D: the gradient rows of this rank's border rows go to their owners, which accumulate them.
+    tables: gradient tables [N, w_i] sharing `stamp` (int32 [N]: the step a row's gradient lines belong to)."""
+    widths = [t.shape[1] for t in tables]
+    Wt = sum(widths)
+    t0 = tables[0]
+    if pl.border.numel():
+        send = torch.cat([utils.take_rows(t, pl.border) for t in tables], dim=1)
+    else:
+        send = t0.new_empty((0, Wt))
+    recv = t0.new_empty((pl.serve_rows.numel(), Wt))
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=pl.serve, input_split_sizes=pl.need)
+    _count("all_to_all_grads", send.numel() * send.element_size())
+    off = 0
+    for q in range(pl.n_ranks):  # requester by requester: ids are unique within a segment -> no atomics,
+        k = pl.serve[q]          # and a fixed summation order
+        if not k:
+            continue
+        ids, seg = pl.serve_rows[off:off + k], recv[off:off + k]
+        fresh = (utils.take_rows(stamp, ids) != step)[:, None]  # no gradient at the owner yet this step: store
+        c = 0
+        for t, w in zip(tables, widths):
+            utils.put_rows(t, ids, torch.where(fresh, seg[:, c:c + w], utils.take_rows(t, ids) + seg[:, c:c + w]))
+            c += w
+        utils.fill_rows(stamp, ids, step)
+        off += k
+
+
+def publish_small(small_g, stamp, step, n_total):
+    """F: all-gather of (row id, summed packed small-gradient row) of every owner's rows touched this step; the
+    receivers store the rows and stamp them, so the replicated small-attribute Adam consumes identical sums."""
+    G, r = world_size(), rank()
+    lo, hi = owner_range(n_total, r, G)
+    own = torch.nonzero(stamp[lo:hi] == step).flatten()  # relative ids, ascending
+    k = torch.tensor([own.numel()], dtype=torch.int64, device=small_g.device)
+    counts = torch.empty((G,), dtype=torch.int64, device=small_g.device)
+    dist.all_gather_into_tensor(counts, k)
+    counts = counts.tolist()  # host read
+    chunk = max(1, max(counts))
+    W = small_g.shape[1]
+    send = small_g.new_zeros((chunk, W + 1))
+    if own.numel():
+        send[:own.numel(), :W] = utils.take_rows(small_g, own + lo)
+        send[:own.numel(), W] = own.to(torch.int32).view(torch.float32)  # the id rides along as raw bits
+    recv = small_g.new_empty((G * chunk, W + 1))
+    dist.all_gather_into_tensor(recv, send)
+    _count("all_gather_small", (send.numel() * send.element_size() + 8) * (G - 1))
+    for q in range(G):
+        if q == r or not counts[q]:
+            continue
+        seg = recv[q * chunk:q * chunk + counts[q]]
+        ids = seg[:, W].contiguous().view(torch.int32).to(torch.int64) + owner_range(n_total, q, G)[0]
+        utils.put_rows(small_g, ids, seg[:, :W])
+        utils.fill_rows(stamp, ids, step)
+    return counts
+
+
+def camera_shares(filters, n_total, n_ranks):
+    """[len(filters), n_ranks] int64 (host): how many of each camera's rows lie in each rank's range."""
+    dev = filters[0].device
+    cuts = torch.tensor([(q * n_total) // n_ranks for q in range(n_ranks + 1)], dtype=torch.int64).to(dev)
+    b = torch.stack([torch.searchsorted(f, cuts) for f in filters])
+    return (b[:, 1:] - b[:, :-1]).cpu()
+
+
+def assign_cameras(shares, per_rank=None):
+    """Deal cameras to ranks by locality: camera c prefers the rank owning most of its rows (shares[c, q]);
+    every rank gets the same number of cameras (`per_rank`, default len / ranks): cameras are taken in order
+    of how much they lose by not getting their first choice, each goes to its best rank with room left.
+    -> list of rank per camera (deterministic: every rank computes the same deal)."""
+    shares = torch.as_tensor(shares).to(torch.float64)
+    n, G = shares.shape
+    cap = per_rank if per_rank is not None else (n + G - 1) // G
+    top2 = torch.topk(shares, k=min(2, G), dim=1).values
+    regret = (top2[:, 0] - (top2[:, 1] if G > 1 else 0)).tolist()
+    order = sorted(range(n), key=lambda c: (-regret[c], c))
+    room = [cap] * G
+    out = [0] * n
+    pref = torch.argsort(shares, dim=1, descending=True, stable=True).tolist()
+    for c in order:
+        for q in pref[c]:
+            if room[q] > 0:
+                out[c] = q
+                room[q] -= 1
+                break
+    return out
+
+
+def deal_cameras(cameras, gaussians, n_ranks=None, chunk=8, per_rank=None):
+    """Locality deal of a camera list over the ranks for the CURRENT row order of `gaussians` (rows in Z-order:
+    utils.morton_order / model.spatial_sort): visibility of every camera (GPU selection, `chunk` cameras per pass)
+    -> camera_shares -> assign_cameras.  Deterministic; every rank computes the same deal.
+    -> (rank of every camera, shares [n_cameras, n_ranks] on the host)."""
+    from .strategies.base_engine import select_filters
+    n_ranks = world_size() if n_ranks is None else n_ranks
+    n = gaussians._xyz.shape[0]
+    rows = []
+    with torch.no_grad():
+        for a in range(0, len(cameras), chunk):
+            filters, _ = select_filters(cameras[a:a + chunk], gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                        gaussians._rotation.detach())
+            rows.append(camera_shares(filters, n, n_ranks))
+    shares = torch.cat(rows)
+    return assign_cameras(shares, per_rank), shares
+
+
+def exchange_bytes(touched_per_rank, n_total):
+    """Wire bytes per rank and batch of the three exchanges for given per-rank touched sets (ascending int64 id
+    tensors, one per rank) -- pure index arithmetic, no communication: used to account a partition of the bench
+    scenes into virtual ranks.  -> {"allreduce": [...], "owner": [...], "locality": [...], "union": U, ...}"""
+    G = len(touched_per_rank)
+    dev = touched_per_rank[0].device
+    cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
+    mark = torch.zeros((n_total,), dtype=torch.bool, device=dev)
+    for t in touched_per_rank:
+        mark.index_fill_(0, t, True)
+    U = int(mark.sum())
+    cs = torch.cumsum(mark.to(torch.int64), 0)
+    ends = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), cs[cuts[1:] - 1])).tolist()
+    own_touched = [ends[q + 1] - ends[q] for q in range(G)]           # |U in range q|
+    per = torch.stack([torch.searchsorted(t, cuts) for t in touched_per_rank])
+    per = (per[:, 1:] - per[:, :-1]).tolist()                          # per[p][q] = |T_p in range q|
+    f = 2.0 * (G - 1) / G
+    allreduce = [f * (240.0 * U + n_total)] * G                        # packed rows + the uint8 touched mask
+    chunk = max(own_touched)
+    owner = [(G - 1) * 192.0 * chunk * 2 + f * (48.0 * U + n_total)] * G
+    locality = []
+    for r in range(G):
+        border = sum(per[r][q] for q in range(G) if q != r)
+        serve = sum(per[p][r] for p in range(G) if p != r)
+        locality.append(8.0 * (G + border) + 192.0 * serve + 240.0 * border + (G - 1) * 52.0 * chunk + 8.0 * (G - 1))
+    return {"allreduce": allreduce, "owner": owner, "locality": locality, "union": U, "n_ranks": G,
+            "touched": [int(t.numel()) for t in touched_per_rank],
+            "border": [sum(per[r][q] for q in range(G) if q != r) for r in range(G)],
+            "own_touched": own_touched, "reference_240B_x_union": 240.0 * U}
 
 
 def allreduce_densify_stats(gaussians):

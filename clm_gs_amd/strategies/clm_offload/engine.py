@@ -255,7 +255,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
     use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
                   and not args.stop_update_param)
-    need_mask = touched_rows is None or args.sparse_adam or dp.active() or not lazy_mode
+    # camera-DP, locality exchange (dp.py): every rank works on ITS cameras' rows; no global touched mask
+    locality = bool(lazy_mode and dp.active() and getattr(args, "dp_locality", False))
+    if getattr(args, "dp_locality", False) and dp.active():
+        assert locality and use_packed and touched_rows is not None and gaussians.first_touch_grads, (
+            "dp_locality needs the dense deferred row optimizer, the packed small-attribute tables and "
+            "first-touch gradient stores (defaults of the fused HBM engine)")
+    need_mask = touched_rows is None or args.sparse_adam or (dp.active() and not locality) or not lazy_mode
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
         if touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
@@ -296,8 +302,18 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     # first-touch gradient stores (gaussian_model.first_touch_grads): the projection/SH backward stamps
     # `_row_g_step` itself and stores instead of accumulating on a row's first touch of this step
     ft_stamp = gaussians._row_g_step if (lazy and fused and gaussians.first_touch_grads) else None
-    owner = None  # owner-computes camera-DP (dp.py): rows owned by index range
-    if lazy and dp.active() and getattr(args, "dp_owner_computes", False):
+    owner = border = None  # owner-computes camera-DP (dp.py): rows owned by index range
+    if locality:
+        # A + B of the locality exchange: who needs which of my rows; bring every own row anybody renders from
+        # up to date (waiting gradient step + replays); parameter rows out to the ranks that asked for them
+        with _lib.host_region("dp_border_plan"):
+            border = dp.border_plan(touched_rows.long(), N)
+        gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
+        own_rows = dp.border_own_rows(border)
+        if own_rows.numel():
+            gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
+        dp.border_params_out(params.data, border)
+    elif lazy and dp.active() and getattr(args, "dp_owner_computes", False):
         owner = dp.owner_plan(touched_rows.long(), N)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
         own_rows = touched_rows[owner.lo:owner.hi]
@@ -461,7 +477,12 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
 
     if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
-        if owner is not None:
+        if border is not None:
+            # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
+            # their owners; the owners publish the summed small-attribute gradients of their touched rows
+            dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
+            dp.publish_small(small_gk, ft_stamp, step, N)
+        elif owner is not None:
             # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
             # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);
             # SH gradient rows: summed AT THEIR OWNER, which alone will step them
@@ -728,7 +749,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
                                           gaussians.get_scaling, gaussians.get_rotation)
         f = filters[0]
         if getattr(gaussians, "lazy_rows", False):
-            if dp.active() and getattr(utils.get_args(), "dp_owner_computes", False):
+            a_ = utils.get_args()
+            if dp.active() and (getattr(a_, "dp_owner_computes", False) or getattr(a_, "dp_locality", False)):
                 gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
             gaussians.catch_up_rows(f.to(torch.int32))
         if getattr(gaussians, "deferred_host_rows", False):  # host rows: apply what is waiting for them

@@ -190,8 +190,11 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         table must follow it, so it is a function of the (constant) engine options only."""
         from ... import dp
         a = self.args
+        # camera-DP: the all-reduce / owner-computes exchanges sum whole row sets over the ranks (a rank's untouched
+        # rows must be zeros), so they keep the clearing policy; the locality exchange moves stamped rows only
+        dp_ok = (not dp.active()) or bool(getattr(a, "dp_locality", False))
         return bool(self.lazy_rows and getattr(a, "fused_front_end", True) and getattr(a, "first_touch_grads", True)
-                    and not dp.active() and not self.deferred_host_rows)
+                    and dp_ok and not self.deferred_host_rows)
 
     def catch_up_rows(self, rows=None, to_step=None):
         """Bring `rows` (None = all) up to date with the zero-gradient Adam steps they skipped."""
@@ -217,7 +220,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             self.host_rows_prepare(None, None)
             return
         from ... import dp
-        if self.lazy_rows and dp.active() and getattr(self.args, "dp_owner_computes", False):
+        if self.lazy_rows and dp.active() and (getattr(self.args, "dp_owner_computes", False)
+                                               or getattr(self.args, "dp_locality", False)):
             # owner-computes camera-DP: every rank brings the rows it OWNS up to date, then all ranks
             # exchange parameters, moments and stamps, after which each replica is complete and current
             if not getattr(self, "_owner_dirty", True):

@@ -131,6 +131,20 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     gc.freeze()
     rng = random.Random(shuffle_seed)
     order = []
+    # camera-DP, locality exchange (dp.py): every rank draws its batches from the cameras that look mostly at
+    # the rows it owns (index ranges of the Z-ordered tables = spatial regions); the deal is recomputed when
+    # densification has grown the model by 10 % (rows are re-sorted after every densification)
+    locality = ws > 1 and bool(getattr(args, "dp_locality", False))
+    pool, dealt_at = None, 0
+
+    def deal():
+        nonlocal pool, dealt_at, order
+        ranks_of, _ = dp.deal_cameras(train_cameras, gaussians, ws)
+        pool = [i for i, q in enumerate(ranks_of) if q == rk]
+        dealt_at, order = gaussians.get_xyz.shape[0], []
+    if locality:
+        assert spatial, "dp_locality needs the Z-ordered row tables (spatial_row_order)"
+        deal()
     timer = End2endTimer()
     timer.start()
     for iteration in range(1, iterations + 1, gbsz):
@@ -138,10 +152,16 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         gaussians.update_learning_rate(iteration)
         if utils.check_update_at_this_iter(iteration, gbsz, 1000, 0):
             gaussians.oneupSHdegree()
-        if len(order) < gbsz:  # new epoch: shuffle, drop_last (train.py:156-167)
-            order = list(range(len(train_cameras)))
-            rng.shuffle(order)
-        batch = [train_cameras[order.pop()] for _ in range(gbsz)][rk::ws]
+        if locality:
+            if len(order) < bsz:  # new epoch of THIS rank's pool
+                order = list(pool)
+                rng.shuffle(order)
+            batch = [train_cameras[order.pop()] for _ in range(bsz)]
+        else:
+            if len(order) < gbsz:  # new epoch: shuffle, drop_last (train.py:156-167)
+                order = list(range(len(train_cameras)))
+                rng.shuffle(order)
+            batch = [train_cameras[order.pop()] for _ in range(gbsz)][rk::ws]
         if naive:
             losses, visibility = naive_offload_train_one_batch(gaussians, scene, batch, background,
                                                                sparse_adam=args.sparse_adam)
@@ -171,6 +191,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         gsplat_densification(iteration, scene, gaussians, None)
         if spatial and gaussians.get_xyz.shape[0] != n_before:
             gaussians.spatial_sort()  # clones / splits were appended at the end of the tables
+            if locality and abs(gaussians.get_xyz.shape[0] - dealt_at) > 0.1 * dealt_at:
+                deal()
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
                 iteration, gbsz, args.densification_interval, 0):
             log_file.write(memory_line(iteration, gbsz, gaussians))

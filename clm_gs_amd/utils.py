@@ -54,6 +54,8 @@ def default_args(**over):
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
+        dp_locality=False,  # camera-DP: owner-computes with point-to-point traffic only (dp.py "locality exchange"):
+        # a rank fetches just the rows its cameras touch outside its own index range and returns their gradients
         dp_owner_computes=False,  # camera-DP: rows are owned by index range; all-gather of parameter rows before
                                   # rendering, reduce-scatter of gradient rows after it, only the owner steps a row
         lazy_dense_adam=True,   # HBM rows: replay zero-gradient Adam steps on demand (exact)   # two cameras of a batch in flight on two HIP streams
@@ -248,8 +250,15 @@ def fill_rows(t, idx, value, chunk=1 << 23):
 
 
 def gather_rows(t, order, chunk=1 << 23):
-    """t[order] for row tables of any size, gathered in chunks of rows (a single advanced-indexing call
-    over a 102 M-row table returned rows of zeros for part of the output on ROCm 7 / torch 2.10)."""
+    """t[order] for row tables of any size, gathered in chunks of rows.
+
+    Why chunks (profiles/repro_index_defect.py, profiles/r03_index_defect.json): on torch 2.10 / ROCm 7,
+    `t[idx]` and `torch.index_select(t, 0, idx)` with MORE THAN 2^26 INDICES into a table whose rows are a
+    multiple of 16 bytes ([N,4] fp32; [N,3] is fine) write only the first (len(idx) mod 2^26) output rows --
+    102 231 360 indices: rows 35 122 496.. are garbage.  The fast path launches one 64-thread workgroup per
+    index, and HIP caps gridDim.x * blockDim.x at 2^32, i.e. 2^26 such workgroups.  Every row selection /
+    permutation / exchange of the package stays below that by construction (2^23 indices per call);
+    tests/test_gpu_row_indexing.py pins the helpers at the failing size."""
     out = torch.empty_like(t)
     n = order.numel()
     for a in range(0, n, chunk):

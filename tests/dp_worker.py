@@ -50,7 +50,7 @@ def _train(m, batches, args, world=1):
             m._rotation.detach().clone(), m._parameters.detach().clone()]
 
 
-def trainer_mode(rank, world, owner=False):
+def trainer_mode(rank, world, owner=False, locality=False):
     """Both ranks run trainer.training (engine exchange + reduced densification statistics + the
     shared split generator); after clone / split / prune the replicas must still be identical."""
     import io
@@ -58,7 +58,8 @@ def trainer_mode(rank, world, owner=False):
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
     n0, w, h = 6000, 128, 96
     args = utils.default_args(bsz=4, sh_residency="hbm", densify_from_iter=16, densification_interval=16,
-                              densify_until_iter=48, densify_grad_threshold=0.00002, dp_owner_computes=owner)
+                              densify_until_iter=48, densify_grad_threshold=0.00002, dp_owner_computes=owner,
+                              dp_locality=locality)
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(h, w)
@@ -99,7 +100,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     if len(sys.argv) > 1 and sys.argv[1].startswith("trainer"):
-        return trainer_mode(rank, world, owner=sys.argv[1] == "trainer_owner")
+        return trainer_mode(rank, world, owner=sys.argv[1] == "trainer_owner", locality=sys.argv[1] == "trainer_locality")
     from clm_gs_amd import dp, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 
@@ -117,7 +118,27 @@ def main():
 
     if len(sys.argv) > 1 and sys.argv[1] == "owner":
         args.dp_owner_computes = True  # rows owned by index range: all-gather params / reduce-scatter grads
-    mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
+    wire = None
+    if len(sys.argv) > 1 and sys.argv[1] == "locality":
+        # locality exchange: rows in Z-order (index ranges = regions), cameras dealt to the rank owning most of
+        # their rows; the global batch of a step is the union of the ranks' batches (the solo run trains on it)
+        args.dp_locality = True
+        order = utils.morton_order(sc["xyz"])
+        for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            sc[k] = utils.gather_rows(sc[k], order)
+        probe = _model(sc, args)
+        ranks_of, shares = dp.deal_cameras(cams, probe, world)
+        del probe
+        pools = [[c for c, q in zip(cams, ranks_of) if q == r] for r in range(world)]
+        assert all(len(p) == STEPS * BSZ for p in pools), [len(p) for p in pools]
+        per_rank = [[pools[r][s * BSZ:(s + 1) * BSZ] for s in range(STEPS)] for r in range(world)]
+        global_batches = [sum((per_rank[r][s] for r in range(world)), []) for s in range(STEPS)]
+        dp.reset_wire()
+        mine = _train(_model(sc, args), per_rank[rank], args, world)
+        wire = dp.wire_bytes()
+        local_share = float(sum(int(shares[c, q]) for c, q in enumerate(ranks_of)) / max(1, int(shares.sum())))
+    else:
+        mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
     # replicas identical bit for bit (same reduced gradients, same optimizer arithmetic)
     same = True
     for i, t in enumerate(mine):
@@ -142,7 +163,10 @@ def main():
     err = []
     for a, b in zip(mine, solo):
         err.append(float((a - b).norm() / b.norm().clamp_min(1e-12)))
-    print("DPRESULT " + json.dumps({"replicas_equal": all(flags), "rel_l2_vs_single": err}))
+    res = {"replicas_equal": all(flags), "rel_l2_vs_single": err}
+    if wire is not None:
+        res.update(wire=wire, local_share=local_share)
+    print("DPRESULT " + json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -112,3 +112,128 @@ def test_dp_is_noop_without_process_group():
     assert dp.world_size() == 1 and dp.rank() == 0
     t = torch.zeros(4, dtype=torch.bool)
     assert dp.allreduce_touched(t) is t
+
+
+def _locality_worker(rank, world, port, out):
+    """The four locality collectives against plain dense arithmetic: every rank 'renders' a touched set
+    concentrated in its own range plus a spill-over into the other ranks' ranges."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clm_gs_amd import dp
+    N, step = 3000, 7
+    dp.reset_wire()
+    lo, hi = dp.owner_range(N)
+    g = torch.Generator().manual_seed(50 + rank)
+    pick = torch.zeros(N, dtype=torch.bool)
+    pick[lo + torch.randperm(hi - lo, generator=g)[: (hi - lo) // 2]] = True          # half of my own range
+    pick[torch.randperm(N, generator=g)[:200]] = True                                    # spill-over anywhere
+    T = torch.nonzero(pick).flatten()
+    pl = dp.border_plan(T, N)
+    fails = []
+    if not (torch.equal(torch.sort(torch.cat((pl.mine, pl.border))).values, T)):
+        fails.append(1)
+    if not (bool(((pl.mine >= lo) & (pl.mine < hi)).all()) and bool(((pl.border < lo) | (pl.border >= hi)).all())):
+        fails.append(2)
+    if not (bool(((pl.serve_rows >= lo) & (pl.serve_rows < hi)).all())):
+        fails.append(3)
+    # B: parameters: every owner holds value (1000 * owner + row-dependent) in its range, garbage elsewhere
+    owner_of = torch.zeros(N, dtype=torch.long)
+    for q in range(world):
+        a, b = dp.owner_range(N, q, world)
+        owner_of[a:b] = q
+    truth = (owner_of * 1000 + torch.arange(N) % 97).float()[:, None].repeat(1, 48)
+    params = torch.full((N, 48), -1.0)
+    params[lo:hi] = truth[lo:hi]
+    dp.border_params_out(params, pl)
+    if not (torch.equal(params[T], truth[T])):  # everything I render from is current
+        fails.append(4)
+    untouched_foreign = torch.ones(N, dtype=torch.bool)
+    untouched_foreign[T] = False
+    untouched_foreign[lo:hi] = False
+    if not (bool((params[untouched_foreign] == -1.0).all())):  # nothing else travelled
+        fails.append(5)
+    # render: first-touch gradient tables (stale garbage + old stamps everywhere, fresh rows stamped `step`)
+    stamp = torch.full((N,), 3, dtype=torch.int32)
+    g_sh, g_small = torch.full((N, 48), 9.0), torch.full((N, 12), 9.0)      # 9.0 = stale content
+    my_sh, my_small = torch.randn(T.numel(), 48, generator=g), torch.randn(T.numel(), 12, generator=g)
+    g_sh[T], g_small[T], stamp[T] = my_sh, my_small, step
+    dense_sh, dense_small = torch.zeros(N, 48), torch.zeros(N, 12)           # what an all-reduce would sum
+    dense_sh[T], dense_small[T] = my_sh, my_small
+    dp.border_grads_home([g_sh, g_small], stamp, step, pl)
+    own_touched = dp.border_own_rows(pl)
+    dp.publish_small(g_small, stamp, step, N)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, dict(dense_sh=dense_sh, dense_small=dense_small, T=T))
+    want_sh = sum(x["dense_sh"] for x in gathered)
+    want_small = sum(x["dense_small"] for x in gathered)
+    U = torch.zeros(N, dtype=torch.bool)
+    for x in gathered:
+        U[x["T"]] = True
+    own_U = torch.nonzero(U[lo:hi]).flatten() + lo
+    if not (torch.equal(own_touched, own_U)):
+        fails.append(6)
+    if not (torch.allclose(g_sh[own_U], want_sh[own_U], atol=1e-6)):  # owners hold the summed SH gradient rows
+        fails.append(7)
+    if not (bool((stamp[own_U] == step).all())):
+        fails.append(8)
+    rows_U = torch.nonzero(U).flatten()
+    if not (torch.allclose(g_small[rows_U], want_small[rows_U], atol=1e-6)):  # everybody holds the summed small rows
+        fails.append(9)
+    if not (bool((stamp[rows_U] == step).all())):
+        fails.append(10)
+    if not (bool((stamp[~U] == 3).all()) and bool((g_small[~U] == 9.0).all())):  # untouched rows: untouched
+        fails.append(11)
+    # wire accounting: the model of exchange_bytes == what the collectives counted
+    acct = dp.exchange_bytes([x["T"] for x in gathered], N)
+    w = dp.wire_bytes()
+    if not (abs(w["total"] - acct["locality"][rank]) < 1e-6 * max(1.0, w["total"])):
+        fails.append(12)
+    if not (acct["union"] == int(U.sum()) and acct["border"][rank] == int(pl.border.numel())):
+        fails.append(13)
+    if not (acct["locality"][rank] < acct["allreduce"][rank]):
+        fails.append(14)
+    res = [None] * world
+    dist.all_gather_object(res, list(fails))
+    if rank == 0:
+        out.put(not any(res) or res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(target, world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True
+
+
+def test_dp_locality_exchange_world2_gloo():
+    _run_world(_locality_worker, 2)
+
+
+def test_dp_locality_exchange_world3_gloo():
+    _run_world(_locality_worker, 3)
+
+
+def test_assign_cameras_by_locality_is_balanced_and_local():
+    from clm_gs_amd import dp
+    # 12 cameras over 4 ranks; camera c sees mostly rank c % 4's range, a few see two ranges equally
+    shares = torch.zeros(12, 4, dtype=torch.int64)
+    for c in range(12):
+        shares[c, c % 4] = 1000
+        shares[c, (c + 1) % 4] = 100 + 10 * c
+    shares[3] = torch.tensor([500, 500, 0, 0])
+    deal = dp.assign_cameras(shares)
+    assert sorted(deal.count(q) for q in range(4)) == [3, 3, 3, 3]
+    kept = sum(int(shares[c, deal[c]]) for c in range(12))
+    assert kept >= 0.9 * int(shares.max(dim=1).values.sum())
+    # more first choices than room: the cameras that lose least are the ones moved
+    shares = torch.tensor([[100, 0], [90, 80], [95, 10], [5, 50]])
+    assert dp.assign_cameras(shares) == [0, 1, 0, 1]

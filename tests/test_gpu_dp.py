@@ -80,6 +80,32 @@ def test_trainer_owner_computes_densify_keeps_replicas_identical(dev):
     assert res["n_after"] != res["n_before"] and res["split"], res
 
 
+def test_locality_exchange_equals_single_rank_with_global_batch(dev):
+    """dp_locality (dp.py "locality exchange"): Z-ordered rows, cameras dealt to the rank owning most of their
+    rows, only border rows travel (all_to_all: parameters out, gradient rows back), owners publish the summed
+    small-attribute gradients.  After flush_lazy_rows() the replicas are identical and equal the single-rank run
+    on the global batches (union of the ranks' batches)."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "locality"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert max(res["rel_l2_vs_single"]) < 2e-4, res
+    assert res["local_share"] > 0.5, res                      # the deal keeps most touched rows at home
+    assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
+
+
+def test_trainer_locality_densify_keeps_replicas_identical(dev):
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "trainer_locality"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert res["n_after"] != res["n_before"] and res["split"], res
+
+
 def test_trainer_two_ranks_densify_keeps_replicas_identical(dev):
     """trainer.training under camera-DP: global-batch image stride, reduced densification
     statistics, shared split samples -> bit-identical replicas after clone / split / prune."""

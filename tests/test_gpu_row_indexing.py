@@ -1,8 +1,9 @@
 """-m gpu: regression test for the row-selection helpers at > 2^25 rows.
 
-torch 2.10 / ROCm 7 advanced indexing `t[idx]` of a [102 231 360, 4] float table returned wrong rows for the
-last 2^26 output rows (profiles/repro_index_defect.py is the stand-alone repro; its output on MI355X is
-committed as profiles/r03_index_defect.json).  Every row permutation / selection / exchange of the package goes
+torch 2.10 / ROCm 7: `t[idx]` / index_select with more than 2^26 indices into a table with 16-byte-multiple rows
+writes only the first (len(idx) mod 2^26) output rows -- [102 231 360, 4]: the last 2^26 rows are garbage (one
+64-thread workgroup per index against HIP's gridDim.x * blockDim.x <= 2^32; profiles/repro_index_defect.py is the
+stand-alone repro, its output on MI355X is committed as profiles/r03_index_defect.json).  Every row permutation / selection / exchange of the package goes
 through utils.take_rows / put_rows / gather_rows / select_rows (chunked); this test pins those helpers against
 ANALYTIC tables at the failing size, and records -- without asserting -- whether the raw form is still broken,
 so a fixed torch shows up as a message instead of a failure."""
