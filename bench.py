@@ -90,8 +90,15 @@ def parse():
                          "once when the model is built, as a loader would); random: the generator's order")
     ap.add_argument("--no-host-leg", action="store_true",
                     help="skip the second leg (the same workload with the SH rows + Adam state in pinned host memory)")
-    ap.add_argument("--host-steps", type=int, default=5)
+    ap.add_argument("--host-steps", type=int, default=20)
     ap.add_argument("--host-warmup", type=int, default=2)
+    ap.add_argument("--gt", default="host", choices=["host", "resident"],
+                    help="host: ground-truth images live in pinned host memory and every batch's images are uploaded on the "
+                         "side stream one batch ahead (the reference: train.py:310-312); resident: all images in HBM before "
+                         "the timed region.  The default run reports both (value = host, value_gt_resident)")
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
+                    help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality for the dense optimizer, "
+                         "allreduce for sparse_adam configurations")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -188,6 +195,31 @@ def gt_to_pinned_host(cams):
             c.image_host, c.original_image = h, None
 
 
+class GtFeeder:
+    """train.py:310-312 with one batch of look-ahead: while batch b renders, batch b+1's images travel from pinned
+    host memory to HBM on the side stream (SDMA, no compute unit involved)."""
+
+    def __init__(self, stream):
+        self.stream, self.pending = stream, {}
+
+    def start(self, key, batch):
+        if key in self.pending or not batch:
+            return
+        with torch.cuda.stream(self.stream):
+            imgs = [c.image_host.to("cuda", non_blocking=True) for c in batch]
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending[key] = (batch, imgs, ev)
+
+    def take(self, key, batch):
+        self.start(key, batch)
+        b, imgs, ev = self.pending.pop(key)
+        torch.cuda.current_stream().wait_event(ev)
+        for c, im in zip(b, imgs):
+            im.record_stream(torch.cuda.current_stream())
+            c.original_image = im
+
+
 def upload_gt(batch, stream):
     """train.py:310-312: the batch's GT images go to the GPU (here: asynchronously on the side stream)."""
     cur = torch.cuda.current_stream()
@@ -206,9 +238,12 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     from clm_gs_amd import _lib, utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
     from clm_gs_amd.synthetic import synth_gaussians
-    n_b = a.host_warmup + a.host_steps
+    host_steps = max(1, min(a.host_steps, len(cams) // bsz - a.host_warmup))
+    n_b = a.host_warmup + host_steps
     cams = cams[:n_b * bsz]
     gt_to_pinned_host(cams)
+    for c in cams:
+        c.original_image = None
     gc.collect()
     torch.cuda.empty_cache()
     args = utils.default_args(bsz=bsz, sh_residency="host")
@@ -268,13 +303,17 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     link_bytes = 2 * 192.0 * T + 4.0 * T + bsz * 3.0 * H * W  # rows down + gradient rows up + row list + GT images
     vals = [float(x) for x in losses_all]
     k2 = min(2 * bsz, max(bsz, len(vals) // 2))
-    out = {"value": round(a.host_steps * bsz / dt, 3), "unit": "img/s", "ms_per_step": round(dt / a.host_steps * 1e3, 2),
-           "steps": a.host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
+    out = {"value": round(host_steps * bsz / dt, 3), "unit": "img/s", "ms_per_step": round(dt / host_steps * 1e3, 2),
+           "steps": host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
            "pinned_host_bytes": int(4 * g.parameters_buffer.shape[0] * 192),
            "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
            "final_flush_ms": round((dt - t_batches) * 1e3, 1),
-           "host_ms_per_step": {k: round(v / a.host_steps * 1e3, 2) for k, v in regions.items()},
-           "link": {"bytes_per_batch": round(link_bytes, 1), "achieved_GBps": round(link_bytes * a.host_steps / dt / 1e9, 2),
+           "value_steady": round(host_steps * bsz / t_batches, 3),
+           "value_note": "value = timed batches + the flush of the deferred host row steps still waiting after the last batch "
+                         "(one-off, final_flush_ms); value_steady = the batches alone",
+           "host_rows_per_s_per_thread": round(T * host_steps / t_batches / max(1, n_threads), 1),
+           "host_ms_per_step": {k: round(v / host_steps * 1e3, 2) for k, v in regions.items()},
+           "link": {"bytes_per_batch": round(link_bytes, 1), "achieved_GBps": round(link_bytes * host_steps / dt / 1e9, 2),
                     "peak_GBps": 57.0, "note": "peak = hipMemcpyAsync pinned<->HBM measured on this node type, EITHER direction or "
                     "both together (profiles/r02_probe_host_link.json); every touched SH row crosses once per direction per batch"},
            "loss_first": round(sum(vals[:k2]) / k2, 6), "loss_last": round(sum(vals[-k2:]) / k2, 6),
@@ -321,6 +360,13 @@ def main():
             setattr(args, k, v.lower() in ("1", "true", "yes"))
         else:
             setattr(args, k, v if isinstance(cur, bool) else type(cur)(v))
+    dp_mode = a.dp_mode
+    if dp_mode == "auto":
+        dp_mode = "locality" if (world > 1 and a.strategy == "clm_offload" and a.residency == "hbm"
+                                 and not args.sparse_adam and a.row_order == "morton") else "allreduce"
+    if world > 1 or under_torchrun:
+        args.dp_locality = dp_mode == "locality"
+        args.dp_owner_computes = dp_mode == "owner"
     utils.set_args(args)
     utils.set_img_size(H, W)
     torch.manual_seed(0)
@@ -337,7 +383,19 @@ def main():
     if a.camera_order == "shuffle":
         perm = torch.randperm(len(all_cams), generator=torch.Generator().manual_seed(7)).tolist()
         all_cams = [all_cams[i] for i in perm]
-    cams = all_cams[rank::world]
+    deal_info = None
+    if world > 1 and dp_mode == "locality":
+        # locality deal (dp.deal_cameras): every camera goes to the rank owning most of its rows (index ranges of
+        # the Z-ordered tables = spatial regions); every rank computes the same deal and renders its own pool
+        from types import SimpleNamespace
+        from clm_gs_amd import dp as _dp
+        ranks_of, shares = _dp.deal_cameras(all_cams, SimpleNamespace(_xyz=scene["xyz"], _scaling=scene["scaling"],
+                                                                      _rotation=scene["rotation"]), world)
+        cams = [c for c, q in zip(all_cams, ranks_of) if q == rank]
+        deal_info = {"local_share": round(sum(int(shares[c, q]) for c, q in enumerate(ranks_of)) / float(shares.sum()), 4),
+                     "cameras_per_rank": len(cams)}
+    else:
+        cams = all_cams[rank::world]
     make_gt_images(cams, scene, args, W, H)
 
     if a.strategy == "clm_offload":
@@ -364,15 +422,17 @@ def main():
 
     state = {"iteration": 1}
 
-    host_main = a.strategy == "clm_offload" and a.residency == "host"
-    if host_main:
+    gt_mode = {"v": "host" if (a.gt == "host" or (a.strategy == "clm_offload" and a.residency == "host")) else "resident"}
+    if gt_mode["v"] == "host":
         gt_to_pinned_host(cams)
         torch.cuda.empty_cache()
+    feeder = GtFeeder(torch.cuda.Stream())
 
     def step(batch_idx):
         batch = cams[batch_idx * bsz:(batch_idx + 1) * bsz]
-        if host_main:
-            upload_gt(batch, comm_stream)
+        if gt_mode["v"] == "host":
+            feeder.take(batch_idx, batch)
+            feeder.start(batch_idx + 1, cams[(batch_idx + 1) * bsz:(batch_idx + 2) * bsz])
         utils.set_cur_iter(state["iteration"])
         gaussians.update_learning_rate(state["iteration"])
         if a.strategy == "clm_offload":
@@ -391,7 +451,7 @@ def main():
             gaussians.optimizer.zero_grad(set_to_none=True)
             sparsity = None
         state["iteration"] += bsz * world
-        if host_main:
+        if gt_mode["v"] == "host":
             for c in batch:
                 c.original_image = None
         return losses, sparsity
@@ -433,6 +493,8 @@ def main():
     ms0 = torch.cuda.memory_stats()
     if os.environ.get("CLMGS_HOST_REGIONS") == "1":
         _lib.HOST_REGIONS = {}
+    from clm_gs_amd import dp as _dpm
+    _dpm.reset_wire()
     # ---- the timed region: exactly K steps, NO per-kernel event instrumentation inside it
     t0 = time.perf_counter()
     step_marks = []
@@ -458,7 +520,30 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    peak = torch.cuda.max_memory_allocated()
+    peak_timed = torch.cuda.max_memory_allocated()
+    wire = _dpm.wire_bytes()
+    n_loss_timed = len(all_losses)
+    # ---- the same K steps once more with every ground-truth image already in HBM (what round 1 / 2 measured as
+    # the headline): reported beside `value` as value_gt_resident; the passes below (instrumented, solo) keep it
+    dt_res = peak_res = None
+    if gt_mode["v"] == "host" and not (a.strategy == "clm_offload" and a.residency == "host"):
+        for c in cams[a.warmup * bsz:(a.warmup + a.steps) * bsz]:
+            c.original_image = c.image_host.to("cuda")
+        gt_mode["v"] = "resident"
+        fence()
+        torch.cuda.reset_peak_memory_stats()
+        tr0 = time.perf_counter()
+        for b in range(a.warmup, a.warmup + a.steps):
+            all_losses += list(step(b)[0])
+        if hasattr(gaussians, "flush_lazy_rows"):
+            gaussians.flush_lazy_rows()
+        fence()
+        dt_res = time.perf_counter() - tr0
+        if grouped:
+            t = torch.tensor([dt_res], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_res = float(t.item())
+        peak_res = torch.cuda.max_memory_allocated()
     loss_vals = [float(l) for l in all_losses]
     # ---- the same K steps again (same cameras, the model has moved on) with an event pair around every
     # C-ABI call on the stream it is launched on: the per-kernel table and the roofline entry.  Its
@@ -472,7 +557,7 @@ def main():
             step(b)
         fence()
         dt_instr = time.perf_counter() - ti
-    peak = torch.cuda.max_memory_allocated()
+    peak = peak_timed
     timing = _lib.timing_summary()
     _lib.TIMING = None
     # One extra UNTIMED batch on a single stream: the same kernels without anything co-running, so
@@ -542,17 +627,24 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
+                    # the same figure on the list this build actually walks (after exact per-tile culling) --
+                    # `frac` charges the reference's unculled intersection count, the work the algorithm defines
+                    "algo_bytes_per_launch_processed": ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T),
+                    "frac_processed": round(ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T)
+                                            / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "algo_bytes_per_launch": ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T),
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "avg_launch_ms_solo": round(solo[dom], 4) if dom in solo else None,
                     "frac_solo": round(ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T) / (solo[dom] * 1e-3) / 1e9
                                        / HBM_PEAK_GBS, 5) if dom in solo else None,
                     "compute": ({"unit": "G wave-instr/s (VALU)", "peak": VALU_PEAK_G,
+                                 "peak_theoretical": 1229.0,  # 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
                                  "valu_insts_per_launch": valu,
                                  "achieved": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9, 1),
                                  "frac": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / VALU_PEAK_G, 4),
                                  "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
                                  "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
+                                 "frac_solo_of_theoretical": round(valu / (solo[dom] * 1e-3) / 1e9 / 1229.0, 4) if dom in solo else None,
                                  "ceiling_at_kernel_occupancy": VALU_CEILING_5_WAVES_G,
                                  "frac_solo_of_ceiling": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_CEILING_5_WAVES_G, 4)
                                  if dom in solo else None,
@@ -595,6 +687,12 @@ def main():
                              **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
                                 if host_regions else {})},
         "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
+        "dp": ({"mode": dp_mode, "deal": deal_info,
+                "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
+                "by_collective_per_step": {k: round(v / a.steps, 1) for k, v in wire.items() if k != "total"},
+                "note": "bytes rank 0 SENDS per batch (clm_gs_amd.dp.wire_bytes: ring model for all-reduce, exact sizes for "
+                        "all_to_all / all_gather); includes the final flush of the timed region"}
+               if (world > 1 or under_torchrun) else None),
         "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
@@ -602,10 +700,17 @@ def main():
                    "camera_order": a.camera_order, "row_order": a.row_order,
                    "untimed_priming_s": a.prime_seconds},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
+        "gt_images": ("pinned host memory, every batch uploaded on a side stream one batch ahead (train.py:310-312)"
+                      if (a.gt == "host" or a.residency == "host") else "all resident in HBM before the timed region"),
+        "value_gt_resident": round(n_images * world / dt_res, 4) if dt_res else None,
         "peak_gpu_bytes": int(peak),
-        "resident_input_bytes": {"gt_images_u8": int(len(cams) * 3 * H * W),
-                                 "note": "the bench keeps every camera's GT image in HBM (inputs resident before the timed "
-                                         "region); the reference streams them from host per batch (train.py:310-312)"},
+        "peak_gpu_bytes_gt_resident": int(peak_res) if peak_res else None,
+        "peak_gpu_bytes_note": ("sh_residency=hbm keeps the whole model + optimizer state in HBM by design (SURVEY 7: 288 GB): "
+                                f"{944 * N / 1e9:.1f} GB of the peak are the {N} x 944 B of parameters, moments and gradient rows, "
+                                f"{60 * N / 1e9:.1f} GB the packed small-attribute mirror / gradient / stamp tables; the rest is one "
+                                "to two cameras' working set (stream-ordered frees) and, in the gt_resident figure, "
+                                f"{a.steps * bsz} resident GT images ({a.steps * bsz * 3 * H * W / 1e9:.1f} GB).  The reference's 13.0 GB "
+                                "is its offloading configuration (SH rows + Adam state in host memory): compare host_resident.peak_gpu_bytes"),
         "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
                      "I_emitted_avg": round(I_emitted, 1), "touched_rows_per_batch": round(touched_avg, 1),
                      "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
@@ -622,6 +727,8 @@ def main():
     }
     if not a.no_cpu_baseline and world == 1:
         try:
+            if cams[0].original_image is None:  # GT images live in pinned host memory (--gt host)
+                cams[0].original_image = cams[0].image_host.to("cuda")
             out["cpu_baseline"] = cpu_baseline(gaussians, cams[0], W, H, a.cpu_seconds)
         except Exception as e:  # the baseline is reporting, never the product path
             out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",

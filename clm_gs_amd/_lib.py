@@ -147,22 +147,49 @@ def check(rc):
 
 
 HOST_REGIONS = None  # set to {} to accumulate host wall time per engine region (diagnostics)
+_ROCTX = None        # libroctx64 handle when CLMGS_ROCTX=1 (ranges show up in `rocprofv3 --marker-trace`)
+
+
+def roctx():
+    """roctx range markers around the engine's regions (the reference's torch.cuda.nvtx.range_push / pop,
+    train.py:238-250): off unless CLMGS_ROCTX=1, so the product path makes no extra calls."""
+    global _ROCTX
+    if _ROCTX is None:
+        _ROCTX = False
+        if os.environ.get("CLMGS_ROCTX") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    l = ctypes.CDLL(name)
+                    l.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    l.roctxRangePushA.restype = ctypes.c_int
+                    l.roctxRangePop.restype = ctypes.c_int
+                    _ROCTX = l
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _ROCTX
 
 
 class host_region:
-    """with host_region("name"): ...   -- adds the block's host wall time to HOST_REGIONS[name]."""
-    __slots__ = ("name", "t0")
+    """with host_region("name"): ...   -- adds the block's host wall time to HOST_REGIONS[name]; with
+    CLMGS_ROCTX=1 the block is also a roctx range."""
+    __slots__ = ("name", "t0", "rx")
 
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
+        self.rx = roctx()
+        if self.rx:
+            self.rx.roctxRangePushA(self.name.encode())
         if HOST_REGIONS is not None:
             self.t0 = time.perf_counter()
 
     def __exit__(self, *exc):
         if HOST_REGIONS is not None:
             HOST_REGIONS[self.name] = HOST_REGIONS.get(self.name, 0.0) + time.perf_counter() - self.t0
+        if self.rx:
+            self.rx.roctxRangePop()
         return False
 
 

@@ -83,6 +83,16 @@ static void* thp_alloc(size_t bytes, int nodes) {
     munmap(p, len);
     return nullptr;
   }
+  // kernels are handed the HOST pointer (zero-copy gradient scatter into the row tables): only valid when the
+  // device address of the registered range IS the host address (HMM / unified addressing).  Otherwise fall
+  // back to hipHostMalloc (the caller does), whose pointer is device-accessible by contract.
+  void* dptr = nullptr;
+  if (hipHostGetDevicePointer(&dptr, p, 0) != hipSuccess || dptr != p) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(p);
+    munmap(p, len);
+    return nullptr;
+  }
   std::lock_guard<std::mutex> l(g_registered_mu);
   g_registered[p] = len;
   return p;

@@ -6,16 +6,22 @@ render, loss, backward, SH backward in place, scatter the small gradients back -
 
 Two residency modes for the [N,48] SH rows and their optimizer state (see gaussian_model.py):
 
-* HBM-resident (MI355X default).  Rows are gathered / scatter-added inside HBM; the Adam for
-  rows NOT touched by this batch (pure momentum decay, needs no gradient) runs on the side
-  stream concurrently with rendering, the Adam for touched rows right after the last
-  micro-batch.  Camera re-ordering and the retention sets exist to save PCIe traffic and are
-  skipped here: they cannot change the batch gradient (exact arithmetic), only its float
-  summation order.
-* host-resident (the reference's design, for scenes beyond HBM).  Pinned host rows, zero-copy
-  gather / scatter-add kernels on the comm stream with the H / D / G retention sets
-  (engine.py:568-571), TSP camera order, row groups by last use, pinned signal flags and a
-  host Adam thread overlapped with rendering.
+* HBM-resident (MI355X default, `_train_one_batch_hbm`).  Rows are read / accumulated by row id inside HBM by
+  the fused front end; the SH-row optimizer is DEFERRED (a row's step of batch b is applied, with the
+  zero-gradient steps it skipped, the next time the row is rendered / evaluated / saved: clmgs_adam_catch_up);
+  the cameras of a batch run as a software pipeline over three streams by kernel type.
+* host-resident (`_train_one_batch_host`, the offloading configuration of the metric).  Pinned host rows; the
+  union of the batch's touched rows is staged once per direction: a feeder thread drives the host pool
+  (deferred host row optimizer + copy into pinned staging) and ships 48 MB chunks with hipMemcpyAsync on a side
+  stream, grouped by the camera that uses a row first; gradient rows go home as zero-copy stores after the
+  camera that uses a row last.  No retention sets, no signal flags, no host Adam thread: see the function's
+  docstring for what replaced them and why.
+
+Camera order: both modes process the cameras in the order given (the batch gradient does not depend on it and
+every touched row crosses the host link once per direction whatever the order).  `order_calculation` -- the
+reference's TSP order + last-use groups + retention-set sizes (engine.py:135-298) -- is kept as the
+reference-compatible ordering entry and is what `reference_camera_order=True` runs: the cameras are then
+processed, and `ordered_cams` / `sparsity` reported, in that order, as the reference does.
 """
 import ctypes
 import math
@@ -139,16 +145,6 @@ def order_calculation(filters, batched_cameras, n_gaussians, bsz, perm_generator
             cnt_g, visibility_mask, bitmap)
 
 
-def cpuadam_thread(bsz, n_gaussians, signal_tensor_pinned, finish_indices_filters, cpu_adam,
-                   parameters, parameters_grad, iteration, args):
-    """Host optimizer thread body (engine.py:301-335)."""
-    parameters.grad = parameters_grad
-    if not args.stop_update_param:
-        cpu_adam.batched_sparse_step(batch_size=bsz, batched_sparse_indices=finish_indices_filters,
-                                     signal_tensor_pinned=signal_tensor_pinned, version=3,
-                                     scale=1.0 / bsz, sparse_adam=args.sparse_adam)
-
-
 # ------------------------------------------------------------------ shared micro-batch
 def _gather_small(gaussians, this_filter):
     idx = this_filter
@@ -247,6 +243,9 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                                               gaussians.get_scaling, gaussians.get_rotation)
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
+    if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
+        _, batched_cameras, filters, sparsity, ordered_cams = order_calculation(
+            list(filters), list(batched_cameras), N, bsz, None, args)[:5]
     lazy_mode = gaussians.lazy_rows and not args.stop_update_param
     fused = getattr(args, "fused_front_end", True)
     mode = getattr(args, "overlap_cameras", True)
@@ -611,6 +610,9 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         _lib.STATS.setdefault("touched_rows", []).append(T)
         sparsity = [len(f) / float(N) for f in filters]
         ordered_cams = list(range(bsz))
+        if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
+            _, batched_cameras, filters, sparsity, ordered_cams = order_calculation(
+                list(filters), list(batched_cameras), N, bsz, perm_generator, args)[:5]
         hb = _host_buffers(gaussians, T, dev)
         rows_h, stage_h = hb["rows_h"][:T], hb["stage_h"][:T]
         sh_stage, g_stage, slot_of = hb["sh_stage"][:T], hb["g_stage"][:T], hb["slot_of"]
@@ -619,9 +621,10 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
             bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
             bm = (bitmap[touched_rows].to(torch.int32) & ((1 << bsz) - 1)) if bsz < 32 else None
             if bm is not None:
-                first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float32))).to(torch.int64)   # earliest camera
+                # float64 holds every bitmap word below 2^53 exactly: floor(log2) is the index of the top bit
+                first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float64))).to(torch.int64)   # earliest camera
                 low = bm & (-bm)
-                last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float32))).to(torch.int64)   # latest camera
+                last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float64))).to(torch.int64)   # latest camera
             else:  # bsz 32 / 64: per-camera membership instead of float log2 on wide words
                 first = torch.full((T,), bsz, dtype=torch.int64, device=dev)
                 last = torch.zeros((T,), dtype=torch.int64, device=dev)
@@ -734,6 +737,9 @@ def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_gr
     args = utils.get_args()
     bsz = len(batched_cameras)
     assert bsz > 1 and bsz in _BITMAP_DTYPE, "clm_offload supports bsz in (4, 8, 16, 32, 64)"
+    # the deferred SH-row step applies a batch's gradient later with the scale 1 / (args.bsz x ranks), the
+    # small-attribute Adam of the same batch uses len(batched_cameras): they must be the same number
+    assert bsz == args.bsz, f"batch of {bsz} cameras but args.bsz = {args.bsz} (optimizer hyper-parameters are scaled by args.bsz)"
     if gaussians._parameters.is_cuda:
         with _lib.host_region("batch_total"):
             return _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer,

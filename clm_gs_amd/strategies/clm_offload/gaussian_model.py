@@ -216,6 +216,10 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                       grad_scale=1.0 / (self.args.bsz * dp.world_size()), keep_grad=self.first_touch_grads)
 
     def flush_lazy_rows(self):
+        """Apply every deferred row step that is still waiting.  Under owner-computes / locality camera-DP this
+        is a COLLECTIVE while replicas are partial (a batch ran since the last flush): call it on ALL ranks
+        before any rank-0-only evaluation / save_ply / capture (trainer.py does); once nothing is dirty it is
+        a local no-op, so the implicit calls inside those entry points are safe afterwards."""
         if self.deferred_host_rows:
             self.host_rows_prepare(None, None)
             return

@@ -256,8 +256,9 @@ def train_from_colmap(source_path, model_path, strategy="clm_offload", iteration
         utils.set_log_file(prev_log)  # never leave a closed file as the process-wide log
     if save:
         if hasattr(gaussians, "flush_lazy_rows"):
-            gaussians.flush_lazy_rows()
-        gaussians.save_ply(os.path.join(model_path, "point_cloud", f"iteration_{args.iterations}", "point_cloud.ply"))
+            gaussians.flush_lazy_rows()  # ALL ranks (a collective under owner-computes / locality camera-DP) ...
+        if dp.rank() == 0:               # ... then rank-0-only I/O (no collective left inside save_ply: nothing is dirty)
+            gaussians.save_ply(os.path.join(model_path, "point_cloud", f"iteration_{args.iterations}", "point_cloud.ply"))
     return gaussians, scene, timer
 
 

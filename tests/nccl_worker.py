@@ -21,12 +21,12 @@ class _Scene:
     cameras_extent = 5.0
 
 
-def _train(force):
+def _train(force, locality=False):
     from clm_gs_amd import utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
     os.environ["CLMGS_DP_FORCE"] = "1" if force else "0"
-    args = utils.default_args(bsz=BSZ)
+    args = utils.default_args(bsz=BSZ, dp_locality=locality)
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -94,9 +94,23 @@ def main():
     dense = [t48.clone(), torch.arange(n, device="cuda", dtype=torch.float32)]
     dp.owner_gather_dense(dense, n)
     res["owner_exchange"] = bool(torch.equal(b48, t48) and torch.equal(dense[0], t48) and pl.lo == 0 and pl.hi == idx.numel())
+    # locality exchange on RCCL: all_to_all_single with split sizes, all_gather_into_tensor
+    bp = dp.border_plan(idx, n)
+    p48 = t48.clone()
+    dp.border_params_out(p48, bp)
+    stamp = torch.zeros(n, dtype=torch.int32, device="cuda")
+    stamp[idx] = 5
+    g48, g12 = t48.clone(), t12.clone()
+    dp.border_grads_home([g48, g12], stamp, 5, bp)
+    counts = dp.publish_small(g12, stamp, 5, n)
+    res["locality_exchange"] = bool(torch.equal(p48, t48) and torch.equal(g48, t48) and torch.equal(g12, t12)
+                                    and bp.border.numel() == 0 and counts == [idx.numel()]
+                                    and torch.equal(dp.border_own_rows(bp), idx))
     forced = _train(True)
     plain = _train(False)
     res["train_forced_equals_plain"] = all(torch.equal(a, b) for a, b in zip(forced, plain))
+    local = _train(True, locality=True)
+    res["train_locality_equals_plain"] = all(torch.equal(a, b) for a, b in zip(local, plain))
     dist.barrier()
     dist.destroy_process_group()
     print("NCCLRESULT " + json.dumps(res))

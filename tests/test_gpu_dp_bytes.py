@@ -38,14 +38,16 @@ def test_exchange_bytes_of_virtual_ranks(dev, name, N, W, H, bsz, vis):
                         _rotation=utils.gather_rows(sc["rotation"], order))
     del sc, order
     steps = 3
-    report = {"config": name, "n_gaussians": N, "bsz_per_rank": bsz, "steps_averaged": steps, "ranks": {}}
+    report = {"config": name, "n_gaussians": N, "bsz_per_rank": bsz, "steps_averaged": steps,
+              "camera_population_per_rank": 25 * bsz, "ranks": {}}
     for G in (2, 4, 8):
-        cams = nadir_cameras(steps * bsz * G, N, W, H, vis, seed=0, device="cuda")
+        pop = 25  # the camera population the deal chooses from: the bench's 25 batches per rank
+        cams = nadir_cameras(pop * bsz * G, N, W, H, vis, seed=0, device="cuda")
         perm = torch.randperm(len(cams), generator=torch.Generator().manual_seed(7)).tolist()
         cams = [cams[i] for i in perm]                       # the bench's shuffled order
         ranks_of, shares = dp.deal_cameras(cams, g, G)
         pools = [[c for c, q in zip(cams, ranks_of) if q == r] for r in range(G)]
-        assert all(len(p) == steps * bsz for p in pools)
+        assert all(len(p) == pop * bsz for p in pools)
         local_share = sum(int(shares[c, q]) for c, q in enumerate(ranks_of)) / float(shares.sum())
         acc = {}
         for deal_name in ("strided", "locality_deal"):

@@ -576,3 +576,36 @@ def test_camera_without_intersections_trains_with_zero_gradients(dev):
         assert float(g_sh.abs().sum()) == 0.0
         for q in (m._xyz, m._opacity, m._scaling, m._rotation):
             assert float(q.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("residency", ["hbm", "host"])
+def test_reference_camera_order_reorders_and_reports_like_the_reference(dev, residency):
+    """reference_camera_order=True: the batch's cameras are processed in order_calculation's TSP order (the
+    reference's engine.py:135-298) and `ordered_cams` / `sparsity` / `losses` are reported in that order; the
+    batch gradient does not depend on the order, so one optimizer step ends where the plain order ends."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.base_engine import select_filters
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    from clm_gs_amd.strategies.clm_offload.engine import order_calculation
+    res = {}
+    for ref_order in (False, True):
+        args, sc, cams = _setup("clm_offload", residency)
+        args.reference_camera_order = ref_order
+        m = _make("clm_offload", sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        with torch.no_grad():
+            filters, _ = select_filters(cams, m._xyz.detach(), m._scaling.detach(), m._rotation.detach())
+        want = order_calculation(list(filters), list(cams), N, BSZ, gen, args)[4]
+        losses, order, sparsity = clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None, comm, gen)
+        torch.cuda.synchronize()
+        m.flush_lazy_rows()
+        assert sorted(order) == list(range(BSZ))
+        assert order == (want if ref_order else list(range(BSZ)))
+        for k, s in zip(order, sparsity):
+            assert abs(s - filters[k].numel() / float(N)) < 1e-9
+        by_cam = {k: l.item() for k, l in zip(order, losses)}
+        res[ref_order] = (by_cam, [t.detach().clone().cuda() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters)])
+    for k in range(BSZ):
+        assert abs(res[True][0][k] - res[False][0][k]) < 1e-6
+    for a, b, init in zip(res[True][1], res[False][1], (sc["xyz"], sc["opacity"], sc["scaling"], sc["rotation"], sc["shs48"])):
+        assert _frac_differs(a, b.reshape(a.shape), init.cuda().reshape(a.shape), 0.02) < 0.01
