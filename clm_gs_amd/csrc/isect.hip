@@ -291,7 +291,7 @@ isect2_emit_kernel(int V, const int32_t* __restrict__ order,
                    const unsigned long long* __restrict__ boxes,
                    const int64_t* __restrict__ cum, int tile_w, uint32_t* __restrict__ tkeys,
                    int32_t* __restrict__ vals, int2* __restrict__ vals2,
-                   const int64_t* __restrict__ row_cum) {
+                   const int64_t* __restrict__ row_cum, int64_t cap) {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
     const unsigned long long b = boxes[2 * (size_t)j];
     if (b == 0ull) continue;
@@ -306,6 +306,7 @@ isect2_emit_kernel(int V, const int32_t* __restrict__ order,
     for (int ty = y0; ty < y1; ++ty)
       for (int tx = x0; tx < x1; ++tx, ++t) {
         if (masked && !((m >> t) & 1ull)) continue;
+        if (cur >= cap) return;  // device-count mode, capacity exceeded: dropped (the caller compares the totals)
         tkeys[cur] = (uint32_t)(ty * tile_w + tx);
         if (vals2) vals2[cur] = make_int2(i, slot++);
         else vals[cur] = i;
@@ -319,7 +320,9 @@ __global__ void __launch_bounds__(256)
 isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int n_tiles,
                       int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids,
                       int32_t* __restrict__ emit_slot, const int2* __restrict__ sorted2,
-                      const float* __restrict__ depths, int64_t* __restrict__ isect_ids) {
+                      const float* __restrict__ depths, int64_t* __restrict__ isect_ids,
+                      const int64_t* __restrict__ n_dev) {
+  if (n_dev) n_isects = min(n_isects, *n_dev);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_isects;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int cur = (int)tkeys[i];
@@ -400,18 +403,18 @@ extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
 // isect_ids[I] i64 optional (NULL to skip).  emit_slot[I] optional: the emit index of every sorted
 // intersection, consumed (with order / cum) by clmgs_rasterize_bwd's atomic-free accumulation.
-extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
-                                      const int32_t* order, const int64_t* cum,
-                                      const uint64_t* boxes, int tile_width, int tile_height,
-                                      int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
-                                      int32_t* emit_slot, void* temp, size_t temp_bytes,
-                                      const int64_t* row_cum) {
+static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const float* depths,
+                                 const int32_t* order, const int64_t* cum,
+                                 const uint64_t* boxes, int tile_width, int tile_height,
+                                 int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
+                                 int32_t* emit_slot, void* temp, size_t temp_bytes,
+                                 const int64_t* row_cum, const int64_t* n_dev) {
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
-  if (n_isects == 0) {
+  if (n_isects == 0 || n_dev) {  // device-count mode: a true count of 0 leaves no thread to write the offsets
     CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
-    return 0;
+    if (n_isects == 0) return 0;
   }
   CLMGS_CHECK_ARG(n_isects < ((int64_t)1 << 31));
   CLMGS_CHECK_ARG(depths && order && cum && boxes && flatten_ids && temp);
@@ -429,22 +432,48 @@ extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, con
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
                      order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
-                     slots ? (int2*)v_a : nullptr, row_cum);
+                     slots ? (int2*)v_a : nullptr, row_cum, n_isects);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc;
   if (slots)
     rc = radix_sort_pairs<uint32_t, int2>(s, n_isects, k_a, k_b, (int2*)v_a, (int2*)v_b, (int2*)v_f, 0,
-                                          tile_bits, table, &sorted);
+                                          tile_bits, table, &sorted, n_dev);
   else
     rc = radix_sort_pairs<uint32_t, int32_t>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b,
-                                             flatten_ids, 0, tile_bits, table, &sorted);
+                                             flatten_ids, 0, tile_bits, table, &sorted, n_dev);
   if (rc) return rc;
   hipLaunchKernelGGL(isect2_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0,
                      s, n_isects, sorted, n_tiles, offsets, flatten_ids, emit_slot,
-                     slots ? (const int2*)v_f : nullptr, depths, isect_ids);
+                     slots ? (const int2*)v_f : nullptr, depths, isect_ids, n_dev);
   CLMGS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int clmgs_isect2_emit_sort(void* stream, int V, int64_t n_isects, const float* depths,
+                                      const int32_t* order, const int64_t* cum,
+                                      const uint64_t* boxes, int tile_width, int tile_height,
+                                      int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
+                                      int32_t* emit_slot, void* temp, size_t temp_bytes,
+                                      const int64_t* row_cum) {
+  return isect2_emit_sort_impl(stream, V, n_isects, depths, order, cum, boxes, tile_width, tile_height,
+                               flatten_ids, offsets, isect_ids, emit_slot, temp, temp_bytes, row_cum, nullptr);
+}
+
+// Device-count form: `capacity` sizes every buffer and launch, the TRUE intersection count is read on the
+// device from n_isects_dev (totals[0] of clmgs_isect2_order_count), so the host need not wait for it before
+// enqueueing.  Intersections beyond the capacity are dropped: the caller MUST compare the count with the
+// capacity (after the fact, from its asynchronous readback) and redo the camera with the exact form if it
+// was exceeded.
+extern "C" int clmgs_isect2_emit_sort_dev(void* stream, int V, int64_t capacity, const int64_t* n_isects_dev,
+                                          const float* depths, const int32_t* order, const int64_t* cum,
+                                          const uint64_t* boxes, int tile_width, int tile_height,
+                                          int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
+                                          int32_t* emit_slot, void* temp, size_t temp_bytes,
+                                          const int64_t* row_cum) {
+  CLMGS_CHECK_ARG(n_isects_dev && capacity > 0);
+  return isect2_emit_sort_impl(stream, V, capacity, depths, order, cum, boxes, tile_width, tile_height,
+                               flatten_ids, offsets, isect_ids, emit_slot, temp, temp_bytes, row_cum, n_isects_dev);
 }
 
 namespace clmgs {

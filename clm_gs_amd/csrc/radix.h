@@ -28,8 +28,9 @@ constexpr int RS_MIN_CHUNK = RS_THREADS * RS_DEFAULT_ITEMS;
 template <typename KeyT, int RS_ITEMS>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int n_blocks,
-                  uint32_t* __restrict__ table /*[256][n_blocks]*/) {
+                  uint32_t* __restrict__ table /*[256][n_blocks]*/, const int64_t* __restrict__ n_dev) {
   constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
+  if (n_dev) n = min(n, *n_dev);  // device-side count: the launch was sized for the capacity `n`
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -83,8 +84,10 @@ __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, int shift,
                      int n_blocks, const uint32_t* __restrict__ table,
-                     const uint32_t* __restrict__ row_tot /*[256] keys per digit*/) {
+                     const uint32_t* __restrict__ row_tot /*[256] keys per digit*/,
+                     const int64_t* __restrict__ n_dev) {
   constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
+  if (n_dev) n = min(n, *n_dev);
   // cnt[round][wave][digit]: first the number of keys of that digit in that (round, wave), then
   // (after the per-digit prefix) the offset of that group inside the block's digit bucket.
   __shared__ uint16_t cnt[RS_ITEMS][4][256];
@@ -200,7 +203,7 @@ static inline size_t radix_table_bytes(int64_t n) {
 template <typename KeyT, typename ValT, int ITEMS>
 static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                                  ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
-                                 uint32_t* table, KeyT** keys_sorted) {
+                                 uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr) {
   constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -217,10 +220,10 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
     KeyT* kdst = (ksrc == keysA) ? keysB : keysA;
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
     hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
-                       n_blocks, table);
+                       n_blocks, table, n_dev);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
-                       kdst, vdst, shift, n_blocks, table, row_tot);
+                       kdst, vdst, shift, n_blocks, table, row_tot, n_dev);
     CLMGS_LAUNCH_CHECK();
     ksrc = kdst;
     vsrc = vdst;
@@ -232,9 +235,9 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
 template <typename KeyT, typename ValT = int32_t>
 static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                             ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
-                            uint32_t* table, KeyT** keys_sorted) {
+                            uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr) {
   return radix_sort_pairs_impl<KeyT, ValT, RS_DEFAULT_ITEMS>(s, n, keysA, keysB, valsA, valsB, vals_final,
-                                                      begin_bit, end_bit, table, keys_sorted);
+                                                      begin_bit, end_bit, table, keys_sorted, n_dev);
 }
 
 // ------------------------------------------------------------- inclusive scan of int64

@@ -132,8 +132,10 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
                      const float* __restrict__ backgrounds,
                      int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets,
                      const int32_t* __restrict__ flatten_ids, float* __restrict__ render_colors,
-                     float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+                     float* __restrict__ render_alphas, int32_t* __restrict__ last_ids,
+                     const int64_t* __restrict__ n_dev) {
   __shared__ TileLds sm;
+  if (n_dev) n_isects = min(n_isects, *n_dev);  // device-side count (the launch was prepared for a capacity)
   const int n_tiles = tile_w * tile_h;
   const int n_tiles_total = C * n_tiles;
   const int tile = (int)xcd_remap(blockIdx.x, (unsigned)n_tiles_total);
@@ -275,8 +277,10 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
                      const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
                      const float* __restrict__ v_render_colors,
                      const float* __restrict__ v_render_alphas, float* __restrict__ packed_grad,
-                     const int32_t* __restrict__ emit_slot, float4* __restrict__ partials) {
+                     const int32_t* __restrict__ emit_slot, float4* __restrict__ partials,
+                     const int64_t* __restrict__ n_dev) {
   __shared__ TileLdsBwd sm;
+  if (n_dev) n_isects = min(n_isects, *n_dev);
   const int n_tiles = tile_w * tile_h;
   const int n_tiles_total = C * n_tiles;
   const int tile = (int)xcd_remap(blockIdx.x, (unsigned)n_tiles_total);
@@ -550,12 +554,13 @@ extern "C" size_t clmgs_rasterize_pack_bytes(int C, int N) {
   return (size_t)C * (size_t)N * REC_F4 * sizeof(float4);
 }
 
-extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
-                                   const float* means2d, const float* conics, const float* colors,
-                                   const float* opacities, const float* backgrounds, int width,
-                                   int height, int tile_size, int tile_width, int tile_height,
-                                   const int32_t* offsets, const int32_t* flatten_ids, void* packed,
-                                   float* render_colors, float* render_alphas, int32_t* last_ids) {
+static int rasterize_fwd_impl(void* stream, int C, int N, int64_t n_isects,
+                              const float* means2d, const float* conics, const float* colors,
+                              const float* opacities, const float* backgrounds, int width,
+                              int height, int tile_size, int tile_width, int tile_height,
+                              const int32_t* offsets, const int32_t* flatten_ids, void* packed,
+                              float* render_colors, float* render_alphas, int32_t* last_ids,
+                              const int64_t* n_dev) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
@@ -578,20 +583,44 @@ extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
 #endif
   hipLaunchKernelGGL(rasterize_fwd_kernel, dim3(n_blocks), dim3(64), fwd_pad, s, C, N, n_isects,
                      (const float4*)packed, backgrounds, width, height, tile_width, tile_height,
-                     offsets, flatten_ids, render_colors, render_alphas, last_ids);
+                     offsets, flatten_ids, render_colors, render_alphas, last_ids, n_dev);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void* packed,
-                                   const float* backgrounds, int width, int height, int tile_size,
-                                   int tile_width, int tile_height, const int32_t* offsets,
-                                   const int32_t* flatten_ids, const float* render_alphas,
-                                   const int32_t* last_ids, const float* v_render_colors,
-                                   const float* v_render_alphas, void* packed_grad,
-                                   float* v_means2d, float* v_conics, float* v_colors,
-                                   float* v_opacities, const int32_t* emit_slot,
-                                   const int64_t* row_cum, void* partials) {
+extern "C" int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects,
+                                   const float* means2d, const float* conics, const float* colors,
+                                   const float* opacities, const float* backgrounds, int width,
+                                   int height, int tile_size, int tile_width, int tile_height,
+                                   const int32_t* offsets, const int32_t* flatten_ids, void* packed,
+                                   float* render_colors, float* render_alphas, int32_t* last_ids) {
+  return rasterize_fwd_impl(stream, C, N, n_isects, means2d, conics, colors, opacities, backgrounds, width, height,
+                            tile_size, tile_width, tile_height, offsets, flatten_ids, packed, render_colors,
+                            render_alphas, last_ids, nullptr);
+}
+
+// Device-count form (see clmgs_isect2_emit_sort_dev): `capacity` bounds the list, the true count is read on the
+// device; the records are the caller's packed [N,16] lines.
+extern "C" int clmgs_rasterize_fwd_dev(void* stream, int C, int N, int64_t capacity, const int64_t* n_isects_dev,
+                                       const float* backgrounds, int width, int height, int tile_size,
+                                       int tile_width, int tile_height, const int32_t* offsets,
+                                       const int32_t* flatten_ids, void* packed, float* render_colors,
+                                       float* render_alphas, int32_t* last_ids) {
+  CLMGS_CHECK_ARG(n_isects_dev && capacity > 0);
+  return rasterize_fwd_impl(stream, C, N, capacity, nullptr, nullptr, nullptr, nullptr, backgrounds, width, height,
+                            tile_size, tile_width, tile_height, offsets, flatten_ids, packed, render_colors,
+                            render_alphas, last_ids, n_isects_dev);
+}
+
+static int rasterize_bwd_impl(void* stream, int C, int N, int64_t n_isects, const void* packed,
+                              const float* backgrounds, int width, int height, int tile_size,
+                              int tile_width, int tile_height, const int32_t* offsets,
+                              const int32_t* flatten_ids, const float* render_alphas,
+                              const int32_t* last_ids, const float* v_render_colors,
+                              const float* v_render_alphas, void* packed_grad,
+                              float* v_means2d, float* v_conics, float* v_colors,
+                              float* v_opacities, const int32_t* emit_slot,
+                              const int64_t* row_cum, void* partials, const int64_t* n_dev) {
   CLMGS_CHECK_ARG(tile_size == TILE);
   CLMGS_CHECK_ARG(C >= 1 && width > 0 && height > 0 && tile_width * TILE >= width &&
                   tile_height * TILE >= height);
@@ -623,7 +652,7 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
   hipLaunchKernelGGL((rasterize_bwd_kernel<D, P>), dim3(n_blocks), dim3(64), bwd_pad, s, C, N,     \
                      n_isects, (const float4*)packed, backgrounds, width, height, tile_width,      \
                      tile_height, offsets, flatten_ids, render_alphas, last_ids, v_render_colors,  \
-                     v_render_alphas, (float*)packed_grad, emit_slot, (float4*)partials)
+                     v_render_alphas, (float*)packed_grad, emit_slot, (float4*)partials, n_dev)
 #ifdef CLMGS_PROFILE_BUILD
     if (part) {
       if (dbg == 1) CLMGS_LAUNCH_BWD(1, true); else if (dbg == 3) CLMGS_LAUNCH_BWD(3, true);
@@ -649,4 +678,35 @@ extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects,
     CLMGS_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void* packed,
+                                   const float* backgrounds, int width, int height, int tile_size,
+                                   int tile_width, int tile_height, const int32_t* offsets,
+                                   const int32_t* flatten_ids, const float* render_alphas,
+                                   const int32_t* last_ids, const float* v_render_colors,
+                                   const float* v_render_alphas, void* packed_grad,
+                                   float* v_means2d, float* v_conics, float* v_colors,
+                                   float* v_opacities, const int32_t* emit_slot,
+                                   const int64_t* row_cum, void* partials) {
+  return rasterize_bwd_impl(stream, C, N, n_isects, packed, backgrounds, width, height, tile_size, tile_width,
+                            tile_height, offsets, flatten_ids, render_alphas, last_ids, v_render_colors,
+                            v_render_alphas, packed_grad, v_means2d, v_conics, v_colors, v_opacities, emit_slot,
+                            row_cum, partials, nullptr);
+}
+
+// Device-count form of the slot mode (one 64 B partial line per intersection, summed by the caller):
+// `capacity` sizes `partials`, the true count is read on the device (see clmgs_isect2_emit_sort_dev).
+extern "C" int clmgs_rasterize_bwd_dev(void* stream, int C, int N, int64_t capacity, const int64_t* n_isects_dev,
+                                       const void* packed, const float* backgrounds, int width, int height,
+                                       int tile_size, int tile_width, int tile_height, const int32_t* offsets,
+                                       const int32_t* flatten_ids, const float* render_alphas,
+                                       const int32_t* last_ids, const float* v_render_colors,
+                                       const float* v_render_alphas, const int32_t* emit_slot,
+                                       const int64_t* row_cum, void* partials) {
+  CLMGS_CHECK_ARG(n_isects_dev && capacity > 0 && emit_slot && partials);
+  return rasterize_bwd_impl(stream, C, N, capacity, packed, backgrounds, width, height, tile_size, tile_width,
+                            tile_height, offsets, flatten_ids, render_alphas, last_ids, v_render_colors,
+                            v_render_alphas, nullptr, nullptr, nullptr, nullptr, nullptr, emit_slot, row_cum,
+                            partials, n_isects_dev);
 }

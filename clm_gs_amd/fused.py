@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, utils
 from ._lib import check, dptr
-from .gsplat import empty_bucketed, isect2_begin, isect2_finish
+from .gsplat import _record_counts, bucket_size, empty_bucketed, isect2_begin, isect2_counts, isect2_finish
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
@@ -47,11 +47,32 @@ class _CameraPass:
     __slots__ = ("V", "cam", "filt", "sh_rows", "sh_by_filter", "small_in", "small_packed", "radii",
                  "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids",
                  "bg", "v_out", "maps", "loss", "ev_loss", "streams", "deg", "aux", "loss_partials",
-                 "lambda_dssim", "gt_u8", "background", "isect", "sh_index", "means2d")
+                 "lambda_dssim", "gt_u8", "background", "isect", "sh_index", "means2d", "n_dev")
 
 
 def _sptr(torch_stream):
     return ctypes.c_void_p(torch_stream.cuda_stream)
+
+
+# ---- device-side intersection counts (include/clmgs.h "device-count forms").  The reference reads every
+# data-dependent size back before it can go on (base_engine.py:64-69, gsplat's cum[-1].item()); here the
+# consumers of a camera's intersection list are enqueued against a PREDICTED capacity and read the true count
+# on the device, and the host checks the count later (camera_verify, when it enqueues the camera's backward --
+# by then the asynchronous readback has long arrived), redoing the camera exactly if the capacity was exceeded.
+# Predictor: decaying maximum of the counts seen at this image size, x `isect_capacity_margin`.
+_CAPACITY = {}
+
+
+def _observe_count(key, n):
+    _CAPACITY[key] = max(int(n), int(0.98 * _CAPACITY.get(key, 0)))
+
+
+def _capacity_for(key, args):
+    seen = _CAPACITY.get(key)
+    if not seen or not getattr(args, "device_side_counts", True):
+        return None
+    cap = int(seen * float(getattr(args, "isect_capacity_margin", 1.25))) + int(getattr(args, "isect_capacity_floor", 4096))
+    return bucket_size(cap) if cap > 4096 else max(cap, 1)
 
 
 def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
@@ -116,18 +137,27 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
     return p
 
 
-def camera_forward_finish(gaussians, p):
-    """Second half of the binning (waits for the count), alpha-blend forward, loss forward + backward."""
+def camera_forward_finish(gaussians, p, exact=False):
+    """Second half of the binning, alpha-blend forward, loss forward + backward.  With a capacity prediction
+    for this image size (device-side counts, see above) nothing is waited for; otherwise (first cameras of a
+    run, `exact`, device_side_counts=False) the host waits for the intersection count and sizes exactly."""
     L = _lib.lib()
+    args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
     dev = gaussians._xyz.device
     s_front, s_mem, s_raster = p.streams
     V, packed, background, gt_u8, lambda_dssim = p.V, p.packed, p.background, p.gt_u8, p.lambda_dssim
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
+    cap = None if (exact or V == 0) else _capacity_for((W, H), args)
     with torch.cuda.stream(s_front):
         with _lib.host_region("fwd_isect"):
-            p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = isect2_finish(p.isect)
-        p.isect = None
+            p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = isect2_finish(p.isect, capacity=cap)
+        if cap is None:
+            p.isect, p.n_dev = None, None
+            if V:
+                _observe_count((W, H), p.fids.numel())
+        else:
+            p.n_dev = p.isect.totals  # int64[2] on the device: {emitted, reference}; p.isect stays for camera_verify
         p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
         p.alphas = torch.empty((H, W), dtype=F32, device=dev)
         p.last_ids = torch.empty((H, W), dtype=I32, device=dev)
@@ -135,9 +165,14 @@ def camera_forward_finish(gaussians, p):
     if s_raster is not s_front:
         s_raster.wait_stream(s_front)
     n_isects = p.fids.numel()
-    check(L.clmgs_rasterize_fwd(_sptr(s_raster), 1, V, n_isects, None, None, None, None, dptr(p.bg, F32, True),
-                                W, H, TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(packed), dptr(p.out),
-                                dptr(p.alphas), dptr(p.last_ids)))
+    if p.n_dev is None:
+        check(L.clmgs_rasterize_fwd(_sptr(s_raster), 1, V, n_isects, None, None, None, None, dptr(p.bg, F32, True),
+                                    W, H, TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(packed), dptr(p.out),
+                                    dptr(p.alphas), dptr(p.last_ids)))
+    else:
+        check(L.clmgs_rasterize_fwd_dev(_sptr(s_raster), 1, V, n_isects, dptr(p.n_dev), dptr(p.bg, F32, True),
+                                        W, H, TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(packed), dptr(p.out),
+                                        dptr(p.alphas), dptr(p.last_ids)))
     if s_mem is not s_raster:
         ev = torch.cuda.Event()
         ev.record(s_raster)
@@ -185,6 +220,27 @@ def camera_loss(p):
     return p.loss
 
 
+def camera_verify(gaussians, p):
+    """Device-count form: the camera's intersection count against the capacity its lists were built for.  Called
+    before anything of the camera is accumulated (camera_backward); the readback was issued a whole forward ago.
+    Exceeded capacity (a view much denser than any seen so far): the camera's forward is repeated exactly."""
+    c = p.isect
+    if c is None or p.n_dev is None:
+        return
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    n, n_ref = isect2_counts(c)
+    _observe_count((W, H), n)
+    if n <= p.fids.numel():
+        _record_counts(n, n_ref)
+        p.isect = None
+        return
+    _lib.STATS["isect_capacity_redo"] = _lib.STATS.get("isect_capacity_redo", 0) + 1
+    for st in set(p.streams):
+        st.synchronize()
+    p.n_dev = None
+    camera_forward_finish(gaussians, p, exact=True)
+
+
 def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True, stats_delta=None,
                     stats_only_visible=False, visibility_out=None, accumulate_after=None, sh_stamp=None,
                     cur_step=0, release=False):
@@ -196,6 +252,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
     dev = gaussians._xyz.device
+    camera_verify(gaussians, p)
     s_front, s_mem, s_raster = p.streams
     V = p.V
     vm, K, campos = p.cam
@@ -214,10 +271,16 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         partials = empty_bucketed(max(n_isects, 1), (16,), F32, dev)
     if p.ev_loss is not None:
         s_raster.wait_event(p.ev_loss)
-    check(L.clmgs_rasterize_bwd(_sptr(s_raster), 1, V, n_isects, dptr(p.packed), dptr(p.bg, F32, True), W, H,
-                                TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(p.alphas), dptr(p.last_ids),
-                                dptr(p.v_out), None, None, None, None, None, None,
-                                dptr(p.emit_slot), dptr(p.row_cum), dptr(partials)))
+    if p.n_dev is None:
+        check(L.clmgs_rasterize_bwd(_sptr(s_raster), 1, V, n_isects, dptr(p.packed), dptr(p.bg, F32, True), W, H,
+                                    TILE, tw, th, dptr(p.offsets), dptr(p.fids), dptr(p.alphas), dptr(p.last_ids),
+                                    dptr(p.v_out), None, None, None, None, None, None,
+                                    dptr(p.emit_slot), dptr(p.row_cum), dptr(partials)))
+    else:
+        check(L.clmgs_rasterize_bwd_dev(_sptr(s_raster), 1, V, n_isects, dptr(p.n_dev), dptr(p.packed),
+                                        dptr(p.bg, F32, True), W, H, TILE, tw, th, dptr(p.offsets), dptr(p.fids),
+                                        dptr(p.alphas), dptr(p.last_ids), dptr(p.v_out), None,
+                                        dptr(p.emit_slot), dptr(p.row_cum), dptr(partials)))
     if s_mem is not s_raster:
         ev = torch.cuda.Event()
         ev.record(s_raster)
@@ -255,7 +318,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         # front stream and used on the tile and memory streams: tell the allocator, then drop them, so the next
         # cameras reuse the blocks in stream order instead of the whole batch's outputs staying alive until the
         # next batch (4 x 0.7 GB at 4K).  Only what camera_loss() needs is kept.
-        for name in ("radii", "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids"):
+        for name in ("radii", "packed", "fids", "offsets", "emit_slot", "row_cum", "out", "alphas", "last_ids", "n_dev"):
             t = getattr(p, name)
             if t is not None:
                 for st in {s_mem, s_raster} - {s_front}:

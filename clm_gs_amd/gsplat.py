@@ -305,10 +305,32 @@ def isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height, wan
     return c
 
 
+def _record_counts(n_isects, n_ref):
+    _lib.STATS["n_isects"].append(n_ref)        # the reference's (3-sigma box) intersection count
+    _lib.STATS["n_emitted"].append(n_isects)    # what is actually sorted and blended
+    if len(_lib.STATS["n_isects"]) > 4096:
+        del _lib.STATS["n_isects"][:2048]
+        del _lib.STATS["n_emitted"][:2048]
+
+
+def isect2_counts(c):
+    """Wait for the totals of isect2_begin (an event on an asynchronous readback) -> (emitted, reference)."""
+    _t0 = time.perf_counter()
+    c.event.synchronize()
+    n_isects, n_ref = int(c.host[0]), int(c.host[1])
+    _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
+    return n_isects, n_ref
+
+
 @torch.no_grad()
-def isect2_finish(c):
-    """Second half: wait for the totals (the one host wait of the front end), then emit + tile sort +
-    offsets on the CURRENT stream (the stream isect2_begin ran on, or one ordered after it)."""
+def isect2_finish(c, capacity=None):
+    """Second half: emit + tile sort + offsets on the CURRENT stream (the stream isect2_begin ran on, or one
+    ordered after it).
+    capacity None: wait for the totals (the one host wait of the front end) and size everything exactly.
+    capacity = K (device-count form, clmgs_isect2_emit_sort_dev): NOTHING is waited for -- buffers and launches
+    are sized for K intersections and the kernels read the true count from c.totals on the device; the returned
+    lists have K entries of which the first `count` are valid.  The caller must check isect2_counts(c)[0] <= K
+    later (fused.camera_verify) and redo the camera exactly otherwise."""
     L = _lib.lib()
     tile_size, tile_width, tile_height, want_isect_ids, want_slots = c.args
     dev, V = c.dev, c.V
@@ -317,24 +339,26 @@ def isect2_finish(c):
         e = torch.empty(0, dtype=I32, device=dev)
         res = (e, c.offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
         return res + ((e, torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
-    _t0 = time.perf_counter()
-    c.event.synchronize()
-    n_isects, n_ref = int(c.host[0]), int(c.host[1])
-    _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
-    _lib.STATS["n_isects"].append(n_ref)        # the reference's (3-sigma box) intersection count
-    _lib.STATS["n_emitted"].append(n_isects)    # what is actually sorted and blended
-    if len(_lib.STATS["n_isects"]) > 4096:
-        del _lib.STATS["n_isects"][:2048]
-        del _lib.STATS["n_emitted"][:2048]
+    if capacity is None:
+        n_isects, n_ref = isect2_counts(c)
+        _record_counts(n_isects, n_ref)
+    else:
+        n_isects = int(capacity)
     fids = empty_bucketed(n_isects, (), I32, dev)
     ids = empty_bucketed(n_isects, (), I64, dev) if want_isect_ids else None
     sb = L.clmgs_isect2_sort_temp_bytes(n_isects)
     temp2 = empty_bucketed(sb, (), torch.uint8, dev)
     emit_slot = empty_bucketed(n_isects, (), I32, dev) if want_slots else None
-    check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(c.depths), dptr(c.order), dptr(c.cum),
-                                   dptr(c.boxes), tile_width, tile_height, dptr(fids), dptr(c.offsets),
-                                   dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb,
-                                   dptr(c.row_cum, I64, True)))
+    if capacity is None:
+        check(L.clmgs_isect2_emit_sort(stream(), V, n_isects, dptr(c.depths), dptr(c.order), dptr(c.cum),
+                                       dptr(c.boxes), tile_width, tile_height, dptr(fids), dptr(c.offsets),
+                                       dptr(ids, I64, True), dptr(emit_slot, I32, True), dptr(temp2), sb,
+                                       dptr(c.row_cum, I64, True)))
+    else:
+        check(L.clmgs_isect2_emit_sort_dev(stream(), V, n_isects, dptr(c.totals), dptr(c.depths), dptr(c.order),
+                                           dptr(c.cum), dptr(c.boxes), tile_width, tile_height, dptr(fids),
+                                           dptr(c.offsets), dptr(ids, I64, True), dptr(emit_slot, I32, True),
+                                           dptr(temp2), sb, dptr(c.row_cum, I64, True)))
     return (fids, c.offsets, ids, (emit_slot, c.row_cum)) if want_slots else (fids, c.offsets, ids)
 
 

@@ -668,8 +668,10 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                     k1 = k0 + n_first[i]
                     for c0 in range(k0, k1, _HOST_CHUNK_ROWS):
                         c1 = min(k1, c0 + _HOST_CHUNK_ROWS)
+                        _tp = time.perf_counter()
                         gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
                                                     next_g_step=0 if skip_opt else step)
+                        _lib.STATS["host_prepare_s"] = _lib.STATS.get("host_prepare_s", 0.0) + time.perf_counter() - _tp
                         _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[c0:c1]), ctypes_ptr(stage_h[c0:c1]),
                                                         (c1 - c0) * 192, 1))
                     ev = torch.cuda.Event()

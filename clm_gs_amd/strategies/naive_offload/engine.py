@@ -84,8 +84,9 @@ def naive_offload_eval_one_cam(gaussians, scene, camera, background):
 
 
 def render_single_image(gaussians, scene, camera, background=None):
-    """Trajectory / evaluation renderer entry (render_bigcity_images.py:638-722 in essence):
-    strategy-dispatching single-image render, clamped to [0,1]."""
+    """Strategy-dispatching single-image render by MODEL TYPE, clamped to [0,1], -> [3,H,W] (round-1 helper, kept
+    for callers that have no args object).  The reference-shaped entry -- render_bigcity_images.py:638-722's
+    signature, [H,W,3] result, PNG output, camera paths -- is clm_gs_amd.render_trajectory."""
     name = type(gaussians).__name__
     if name == "GaussianModelNaiveOffload":
         img = naive_offload_eval_one_cam(gaussians, scene, camera, background)

@@ -54,6 +54,9 @@ def default_args(**over):
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
+        device_side_counts=True,   # fused engine: consumers of a camera's intersection list read its length on the device
+        isect_capacity_margin=1.25,  # ... from buffers sized (largest count seen at this image size) x margin
+        isect_capacity_floor=4096,   # ... + this many entries
         reference_camera_order=False,  # clm_offload: process (and report) a batch's cameras in the reference's TSP order
         dp_locality=False,  # camera-DP: owner-computes with point-to-point traffic only (dp.py "locality exchange"):
         # a rank fetches just the rows its cameras touch outside its own index range and returns their gradients

@@ -160,6 +160,33 @@ int clmgs_rasterize_bwd(void* stream, int C, int N, int64_t n_isects, const void
                         float* v_conics, float* v_colors, float* v_opacities,
                         const int32_t* emit_slot, const int64_t* row_cum, void* partials);
 
+/* ---- device-count forms (engine fast path): the data-dependent size I of a camera need not reach the host
+ * before the consumers of the list are enqueued.  The reference reads it back synchronously
+ * (strategies/base_engine.py:64-69 `counts.cpu()`, gsplat.isect_tiles' cum[-1].item()); here `capacity` (a
+ * prediction by the caller, >= the true count or the camera is redone) sizes every buffer and launch, and
+ * the TRUE count is read ON THE DEVICE from n_isects_dev = totals[0] of clmgs_isect2_order_count.
+ * Intersections beyond the capacity are dropped (never written out of bounds); the caller compares the count
+ * with the capacity from its asynchronous readback and, if it was exceeded, repeats the camera with the exact
+ * forms above before anything was accumulated.  Same results as the exact forms when count <= capacity
+ * (tests/test_gpu_ops.py).  rasterize_*_dev: slot mode only (C == 1, records in `packed`, partial lines out). */
+int clmgs_isect2_emit_sort_dev(void* stream, int V, int64_t capacity, const int64_t* n_isects_dev,
+                               const float* depths, const int32_t* order, const int64_t* cum,
+                               const uint64_t* boxes, int tile_width, int tile_height,
+                               int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
+                               int32_t* emit_slot, void* temp, size_t temp_bytes, const int64_t* row_cum);
+int clmgs_rasterize_fwd_dev(void* stream, int C, int N, int64_t capacity, const int64_t* n_isects_dev,
+                            const float* backgrounds, int width, int height, int tile_size,
+                            int tile_width, int tile_height, const int32_t* offsets,
+                            const int32_t* flatten_ids, void* packed, float* render_colors,
+                            float* render_alphas, int32_t* last_ids);
+int clmgs_rasterize_bwd_dev(void* stream, int C, int N, int64_t capacity, const int64_t* n_isects_dev,
+                            const void* packed, const float* backgrounds, int width, int height,
+                            int tile_size, int tile_width, int tile_height, const int32_t* offsets,
+                            const int32_t* flatten_ids, const float* render_alphas,
+                            const int32_t* last_ids, const float* v_render_colors,
+                            const float* v_render_alphas, const int32_t* emit_slot,
+                            const int64_t* row_cum, void* partials);
+
 /* ---- fused per-camera front end (engine-internal fast path; same arithmetic as the op chain
  * strategies/clm_offload/engine.py:650-691 forward and :703-742 + densification.py:59-102 backward)
  * For i < V, row g = filter ? filter[i] : i of the RAW parameter tensors (xyz[N,3], opacity_raw[N],

@@ -93,6 +93,7 @@ def hip_camera(gaussians, cam, rows, width, height):
         gaussians.xyz_gradient_accum = torch.zeros((N, 1), device=dev)
         gaussians.denom = torch.zeros((N, 1), device=dev)
         p = fused.camera_forward(gaussians, cam, rows, sh, 0, None, cam.original_image)
+        fused.camera_verify(gaussians, p)  # device-side counts: the forward may have to be redone at exact size
         v_out = p.v_out.clone()            # d loss / d image [H,W,3] (camera_backward frees it)
         means2d = p.means2d.reshape(-1, 2).clone()
         fused.camera_backward(gaussians, p, g_sh, update_stats=True, stats_only_visible=rows is None)

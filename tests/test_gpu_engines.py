@@ -567,9 +567,10 @@ def test_camera_without_intersections_trains_with_zero_gradients(dev):
         V = N if rows is None else 0
         sh = m._parameters.data if rows is None else torch.empty((0, 48), device="cuda")
         g_sh = torch.zeros((max(V, 1), 48), device="cuda")[:V]
+        from clm_gs_amd import _lib
         p = fused.camera_forward(m, cam, rows, sh, 0, None, cam.original_image)
-        assert p.fids.numel() == 0
         fused.camera_backward(m, p, g_sh, update_stats=False)
+        assert V == 0 or _lib.STATS["n_emitted"][-1] == 0
         loss = fused.camera_loss(p)
         torch.cuda.synchronize()
         assert float(p.out.abs().max()) == 0.0 and 0.0 < loss.item() < 1.0
@@ -609,3 +610,40 @@ def test_reference_camera_order_reorders_and_reports_like_the_reference(dev, res
         assert abs(res[True][0][k] - res[False][0][k]) < 1e-6
     for a, b, init in zip(res[True][1], res[False][1], (sc["xyz"], sc["opacity"], sc["scaling"], sc["rotation"], sc["shs48"])):
         assert _frac_differs(a, b.reshape(a.shape), init.cuda().reshape(a.shape), 0.02) < 0.01
+
+
+def test_device_side_counts_equal_exact_sizes_and_survive_overflow(dev):
+    """device_side_counts (fused.py): the consumers of a camera's intersection list run against a predicted
+    capacity and read the count on the device; two batches must end bit for bit where the exact-size path ends --
+    also when the prediction is far too small (isect_capacity_margin 0.5: every camera is verified, found over
+    capacity and redone exactly before anything was accumulated)."""
+    from clm_gs_amd import _lib, fused, utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    res = {}
+    for mode, margin in (("exact", None), ("device", 1.25), ("overflow", 0.5)):
+        args, sc, cams = _setup("clm_offload")
+        args.device_side_counts = mode != "exact"
+        if margin:
+            args.isect_capacity_margin = margin
+            args.isect_capacity_floor = 4096 if margin > 1 else 0
+        fused._CAPACITY.clear()
+        _lib.STATS["isect_capacity_redo"] = 0
+        m = _make("clm_offload", sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        it, losses = 1, []
+        for b in range(2):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            l, _, _ = clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None, comm, gen)
+            losses += [x.item() for x in l]
+            it += BSZ
+        torch.cuda.synchronize()
+        m.flush_lazy_rows()
+        res[mode] = (losses, [t.detach().clone() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters)],
+                     _lib.STATS["isect_capacity_redo"], len(_lib.STATS["n_isects"]))
+    assert res["exact"][2] == 0 and res["device"][2] == 0 and res["overflow"][2] >= BSZ  # batch 1 predicts from batch 0
+    for mode in ("device", "overflow"):
+        assert all(abs(a - b) < 1e-6 for a, b in zip(res[mode][0], res["exact"][0]))
+        for a, b in zip(res[mode][1], res["exact"][1]):
+            assert torch.equal(a, b), mode
+    fused._CAPACITY.clear()

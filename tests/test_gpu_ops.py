@@ -648,3 +648,62 @@ def test_rasterize_with_no_intersections(dev):
                                       else (None,) * 3)))
         for x in outs:
             assert float(x.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("slack", [1.0, 1.4, 0.6])
+def test_device_count_forms_equal_exact_forms(dev, slack):
+    """clmgs_isect2_emit_sort_dev / clmgs_rasterize_fwd_dev / clmgs_rasterize_bwd_dev: lists built for a CAPACITY
+    with the true count read on the device == the exact forms, element for element, when count <= capacity
+    (slack 1.0: capacity == count, 1.4: the usual over-allocation).  slack 0.6: capacity exceeded -- nothing is
+    written out of bounds (guard words intact), the caller sees count > capacity from the totals."""
+    from clm_gs_amd import _lib, gsplat as G
+    from clm_gs_amd._lib import check, dptr, stream
+    L = _lib.lib()
+    w, h, n = 150, 101, 2500
+    s = small_scene(n=n, width=w, height=h, seed=71, log_scale=-1.0)
+    radii, m2, d, cn, _ = _project_cpu(s)
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    g = torch.Generator().manual_seed(5)
+    colors = torch.rand(1, n, 3, generator=g).to(dev)
+    opac = s["opac"].reshape(1, -1).to(dev)
+    m2, radii, d, cn = m2.to(dev), radii.to(dev), d.to(dev), cn.to(dev)
+    # exact forms
+    fids, off, _, (slot, row_cum) = G.isect_tiles_two_level(m2, radii, d, 16, tw, th, want_slots=True)
+    I = fids.numel()
+    packed = torch.empty((n, 16), device=dev)
+    out, al, last = torch.empty((h, w, 3), device=dev), torch.empty((h, w), device=dev), torch.empty((h, w), dtype=torch.int32, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, n, I, dptr(m2), dptr(cn), dptr(colors), dptr(opac), None, w, h, 16, tw, th,
+                                dptr(off), dptr(fids), dptr(packed), dptr(out), dptr(al), dptr(last)))
+    v_out = torch.randn((h, w, 3), generator=torch.Generator().manual_seed(6)).to(dev)
+    part = torch.full((max(I, 1), 16), 7.0, device=dev)
+    check(L.clmgs_rasterize_bwd(stream(), 1, n, I, dptr(packed), None, w, h, 16, tw, th, dptr(off), dptr(fids), dptr(al),
+                                dptr(last), dptr(v_out), None, None, None, None, None, None, dptr(slot), dptr(row_cum),
+                                dptr(part)))
+    # device-count forms
+    cap = max(1, int(I * slack))
+    c = G.isect2_begin(m2, radii, d, 16, tw, th, want_slots=True)
+    GUARD = 64
+    fids2 = torch.full((cap + GUARD,), -12345, dtype=torch.int32, device=dev)
+    slot2 = torch.full((cap + GUARD,), -12345, dtype=torch.int32, device=dev)
+    sb = L.clmgs_isect2_sort_temp_bytes(cap)
+    temp = torch.empty((sb,), dtype=torch.uint8, device=dev)
+    off2 = torch.full((1, th, tw), -1, dtype=torch.int32, device=dev)
+    check(L.clmgs_isect2_emit_sort_dev(stream(), n, cap, dptr(c.totals), dptr(c.depths), dptr(c.order), dptr(c.cum),
+                                       dptr(c.boxes), tw, th, dptr(fids2), dptr(off2), None, dptr(slot2), dptr(temp), sb,
+                                       dptr(c.row_cum)))
+    torch.cuda.synchronize()
+    assert int(c.totals[0]) == I
+    assert bool((fids2[cap:] == -12345).all()) and bool((slot2[cap:] == -12345).all()), "nothing beyond the capacity"
+    if slack < 1.0:
+        return  # capacity exceeded: the caller redoes the camera (fused.camera_verify); only in-bounds writes are promised
+    assert torch.equal(fids2[:I], fids) and torch.equal(slot2[:I], slot) and torch.equal(off2, off)
+    out2, al2, last2 = torch.empty_like(out), torch.empty_like(al), torch.empty_like(last)
+    check(L.clmgs_rasterize_fwd_dev(stream(), 1, n, cap, dptr(c.totals), None, w, h, 16, tw, th, dptr(off2), dptr(fids2[:cap]),
+                                    dptr(packed), dptr(out2), dptr(al2), dptr(last2)))
+    assert torch.equal(out2, out) and torch.equal(al2, al) and torch.equal(last2, last)
+    part2 = torch.full((cap + 4, 16), 7.0, device=dev)
+    check(L.clmgs_rasterize_bwd_dev(stream(), 1, n, cap, dptr(c.totals), dptr(packed), None, w, h, 16, tw, th, dptr(off2),
+                                    dptr(fids2[:cap]), dptr(al2), dptr(last2), dptr(v_out), None, dptr(slot2[:cap]),
+                                    dptr(c.row_cum), dptr(part2)))
+    torch.cuda.synchronize()
+    assert torch.equal(part2[:I], part[:I]) and bool((part2[I:] == 7.0).all())
