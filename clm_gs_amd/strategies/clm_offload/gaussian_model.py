@@ -215,8 +215,10 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                       g=self.parameters_grad_buffer[:p.shape[0]], g_step=self._row_g_step,
                       grad_scale=1.0 / (self.args.bsz * dp.world_size()), keep_grad=self.first_touch_grads)
 
-    def flush_lazy_rows(self):
-        """Apply every deferred row step that is still waiting.  Under owner-computes / locality camera-DP this
+    def flush_lazy_rows(self, exchange=True):
+        """Apply every deferred row step that is still waiting.  exchange=False (owner-computes / locality
+        camera-DP only): just the optimizer work -- every rank brings the rows it OWNS up to date -- without the
+        all-gather that completes the replicas (bench.py times this form; evaluation / saving need the full one).  Under owner-computes / locality camera-DP this
         is a COLLECTIVE while replicas are partial (a batch ran since the last flush): call it on ALL ranks
         before any rank-0-only evaluation / save_ply / capture (trainer.py does); once nothing is dirty it is
         a local no-op, so the implicit calls inside those entry points are safe afterwards."""
@@ -230,11 +232,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             # exchange parameters, moments and stamps, after which each replica is complete and current
             if not getattr(self, "_owner_dirty", True):
                 return
-            self._owner_dirty = False
             n = self._parameters.shape[0]
             lo, hi = dp.owner_range(n)
             if hi > lo:
                 self.catch_up_rows(torch.arange(lo, hi, dtype=torch.int32, device=self._xyz.device))
+            if not exchange:
+                return
+            self._owner_dirty = False
             st = self.optimizer.cpu_adam.state[self._parameters]
             dp.owner_gather_dense([self._parameters.data, st["exp_avg"], st["exp_avg_sq"],
                                    self.parameters_grad_buffer[:n]], n)

@@ -253,6 +253,11 @@ def compare(hip, orc):
         denom_mismatch=int(np.count_nonzero(hip["denom"] != orc["denom"])),
         max_radii2D_mismatch=int(np.count_nonzero(hip["max_radii2D"] != orc["max_radii2D"])),
         cotangent_sign_flips=int(flips.sum()), cotangent_numel=int(flips.size),
+        # a sign flip means gt lies between the two renders, i.e. |image - gt| <= their difference: flips are ties by
+        # construction and their NUMBER only says how close the model is to gt (a converged model has many); what
+        # must stay rare is a pixel where the renders themselves differ visibly (an alpha >= 1/255 or T > 1e-4 tie
+        # moves one Gaussian's contribution, up to ~4e-3, in one pixel)
+        image_big_diff=int(np.count_nonzero(np.abs(ih - io) > 1e-4)), image_max_abs_diff=float(np.abs(ih - io).max()),
         cotangent_flip_max_gap=float(np.abs(io - gt)[flips].max()) if flips.any() else 0.0,
         cotangent_rel_l2=_rel_l2(vh, vo),
         cotangent_rel_l2_without_flips=_rel_l2(vh[keep], vo[keep]),
@@ -291,8 +296,11 @@ def within_tolerance(rep):
         bad.append("stats")
     if rep["cotangent_rel_l2_without_flips"] > TOL["cotangent_rel_l2_without_flips"]:
         bad.append("cotangent")
-    if rep["cotangent_sign_flips"] > 1e-4 * rep["cotangent_numel"]:
-        bad.append("cotangent_flips")
+    # pixels the two renders disagree on by more than 1e-4 are ties of the alpha >= 1/255 test (one Gaussian's
+    # contribution, <= c / 255 ~ 4e-3, enters one render and not the other; measured 2e-4 of the elements at 28 M /
+    # 4K, thousands of ties among 1e9 evaluated pairs): rare, and bounded by a few such contributions
+    if rep["image_big_diff"] > 1e-3 * rep["cotangent_numel"] or rep["image_max_abs_diff"] > 0.02:
+        bad.append("image_ties")
     for k in GRAD_KEYS:
         if rep[k + "_rel_l2"] > max(TOL["natural_rel_l2"], 2 * rep["natural_bound"]):
             bad.append("natural:" + k)

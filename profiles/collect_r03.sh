@@ -20,9 +20,9 @@ DB=$(find /tmp/prof_s -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py "$DB" 170 > $O/kernel_stats.csv
 python $R/profiles/timeline.py $DB step3 > $O/timeline_step.txt 2>&1
 python $R/profiles/timeline_streams.py $DB step3 > $O/timeline_streams.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o f -- python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-leg --gt resident > $O/pmcF.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o f -- python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-leg --gt resident --prime-seconds 0 > $O/pmcF.log 2>&1
 python $R/profiles/pmc_summary.py $(find /tmp/pmcF -name "*counter_collection.csv" | head -1) > $O/pmc_fetch_size.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o w -- python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-leg --gt resident > $O/pmcW.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o w -- python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-leg --gt resident --prime-seconds 0 > $O/pmcW.log 2>&1
 python $R/profiles/pmc_summary.py $(find /tmp/pmcW -name "*counter_collection.csv" | head -1) > $O/pmc_write_size.txt 2>&1
 rm -f $O/pmc_sq_counters.txt
 for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
