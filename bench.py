@@ -97,8 +97,7 @@ def parse():
                          "side stream one batch ahead (the reference: train.py:310-312); resident: all images in HBM before "
                          "the timed region.  The default run reports both (value = host, value_gt_resident)")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
-                    help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality for the dense optimizer, "
-                         "allreduce for sparse_adam configurations")
+                    help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality (Z-ordered rows required)")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -383,7 +382,7 @@ def main():
     dp_mode = a.dp_mode
     if dp_mode == "auto":
         dp_mode = "locality" if (world > 1 and a.strategy == "clm_offload" and a.residency == "hbm"
-                                 and not args.sparse_adam and a.row_order == "morton") else "allreduce"
+                                 and a.row_order == "morton") else "allreduce"
     if world > 1 or under_torchrun:
         args.dp_locality = dp_mode == "locality"
         args.dp_owner_computes = dp_mode == "owner"

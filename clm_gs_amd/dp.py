@@ -310,7 +310,9 @@ def border_params_out(table, pl):
 
 def border_grads_home(tables, stamp, step, pl):
     """D: the gradient rows of this rank's border rows go to their owners, which accumulate them.
-    tables: gradient tables [N, w_i] sharing `stamp` (int32 [N]: the step a row's gradient lines belong to)."""
+    tables: gradient tables [N, w_i] sharing `stamp` (int32 [N]: the step a row's gradient lines belong to;
+    first-touch policy).  stamp None: clearing policy (rows without a gradient hold zeros) -- the owner simply
+    adds, and the sender's border rows are zeroed once handed over."""
     widths = [t.shape[1] for t in tables]
     Wt = sum(widths)
     t0 = tables[0]
@@ -327,40 +329,70 @@ def border_grads_home(tables, stamp, step, pl):
         if not k:
             continue
         ids, seg = pl.serve_rows[off:off + k], recv[off:off + k]
-        fresh = (utils.take_rows(stamp, ids) != step)[:, None]  # no gradient at the owner yet this step: store
         c = 0
-        for t, w in zip(tables, widths):
-            utils.put_rows(t, ids, torch.where(fresh, seg[:, c:c + w], utils.take_rows(t, ids) + seg[:, c:c + w]))
-            c += w
-        utils.fill_rows(stamp, ids, step)
+        if stamp is None:
+            for t, w in zip(tables, widths):
+                utils.put_rows(t, ids, utils.take_rows(t, ids) + seg[:, c:c + w])
+                c += w
+        else:
+            fresh = (utils.take_rows(stamp, ids) != step)[:, None]  # no gradient at the owner yet this step: store
+            for t, w in zip(tables, widths):
+                utils.put_rows(t, ids, torch.where(fresh, seg[:, c:c + w], utils.take_rows(t, ids) + seg[:, c:c + w]))
+                c += w
+            utils.fill_rows(stamp, ids, step)
         off += k
+    if stamp is None and pl.border.numel():
+        for t in tables:
+            utils.fill_rows(t, pl.border, 0.0)
 
 
-def publish_small(small_g, stamp, step, n_total):
-    """F: all-gather of (row id, summed packed small-gradient row) of every owner's rows touched this step; the
-    receivers store the rows and stamp them, so the replicated small-attribute Adam consumes identical sums."""
+def publish_rows(tables, own_rows, n_total):
+    """F, general form: every owner all-gathers (row id, its summed rows of `tables`, side by side) for `own_rows`
+    (ascending absolute ids inside its range); the receivers store the rows.  -> (counts per rank, list of the
+    absolute id tensors received from every other rank)."""
     G, r = world_size(), rank()
-    lo, hi = owner_range(n_total, r, G)
-    own = torch.nonzero(stamp[lo:hi] == step).flatten()  # relative ids, ascending
-    k = torch.tensor([own.numel()], dtype=torch.int64, device=small_g.device)
-    counts = torch.empty((G,), dtype=torch.int64, device=small_g.device)
+    lo, _ = owner_range(n_total, r, G)
+    t0 = tables[0]
+    widths = [t.shape[1] if t.dim() > 1 else 1 for t in tables]
+    W = sum(widths)
+    k = torch.tensor([own_rows.numel()], dtype=torch.int64, device=t0.device)
+    counts = torch.empty((G,), dtype=torch.int64, device=t0.device)
     dist.all_gather_into_tensor(counts, k)
     counts = counts.tolist()  # host read
     chunk = max(1, max(counts))
-    W = small_g.shape[1]
-    send = small_g.new_zeros((chunk, W + 1))
-    if own.numel():
-        send[:own.numel(), :W] = utils.take_rows(small_g, own + lo)
-        send[:own.numel(), W] = own.to(torch.int32).view(torch.float32)  # the id rides along as raw bits
-    recv = small_g.new_empty((G * chunk, W + 1))
+    send = t0.new_zeros((chunk, W + 1))
+    n_own = own_rows.numel()
+    if n_own:
+        c = 0
+        for t, w in zip(tables, widths):
+            send[:n_own, c:c + w] = utils.take_rows(t.reshape(t.shape[0], -1), own_rows)
+            c += w
+        send[:n_own, W] = (own_rows - lo).to(torch.int32).view(torch.float32)  # the id rides along as raw bits
+    recv = t0.new_empty((G * chunk, W + 1))
     dist.all_gather_into_tensor(recv, send)
     _count("all_gather_small", (send.numel() * send.element_size() + 8) * (G - 1))
+    got = []
     for q in range(G):
         if q == r or not counts[q]:
             continue
         seg = recv[q * chunk:q * chunk + counts[q]]
         ids = seg[:, W].contiguous().view(torch.int32).to(torch.int64) + owner_range(n_total, q, G)[0]
-        utils.put_rows(small_g, ids, seg[:, :W])
+        c = 0
+        for t, w in zip(tables, widths):
+            utils.put_rows(t.reshape(t.shape[0], -1), ids, seg[:, c:c + w])
+            c += w
+        got.append(ids)
+    return counts, got
+
+
+def publish_small(small_g, stamp, step, n_total):
+    """F (first-touch policy): the rows of this rank's range stamped `step` are the ones anybody touched; they are
+    published with their summed packed small-gradient row, the receivers store and stamp them, so the replicated
+    small-attribute Adam consumes identical sums everywhere."""
+    lo, hi = owner_range(n_total)
+    own = torch.nonzero(stamp[lo:hi] == step).flatten() + lo
+    counts, got = publish_rows([small_g], own, n_total)
+    for ids in got:
         utils.fill_rows(stamp, ids, step)
     return counts
 

@@ -256,10 +256,14 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                   and not args.stop_update_param)
     # camera-DP, locality exchange (dp.py): every rank works on ITS cameras' rows; no global touched mask
     locality = bool(lazy_mode and dp.active() and getattr(args, "dp_locality", False))
+    # ... and its sparse_adam form (config 5 as the reference scripts it: SelectiveAdam for the small attributes, the
+    # SH rows of visible Gaussians only): eager row optimizer at the owner, clearing-policy gradient tables
+    locality_sparse = bool(dp.active() and getattr(args, "dp_locality", False) and args.sparse_adam and fused
+                           and not args.stop_update_param and not lazy_mode)
     if getattr(args, "dp_locality", False) and dp.active():
-        assert locality and use_packed and touched_rows is not None and gaussians.first_touch_grads, (
-            "dp_locality needs the dense deferred row optimizer, the packed small-attribute tables and "
-            "first-touch gradient stores (defaults of the fused HBM engine)")
+        assert touched_rows is not None and (locality_sparse or (locality and use_packed and gaussians.first_touch_grads)), (
+            "dp_locality needs the fused front end and either the dense deferred row optimizer with the packed "
+            "small-attribute tables and first-touch gradient stores (defaults) or sparse_adam")
     need_mask = touched_rows is None or args.sparse_adam or (dp.active() and not locality) or not lazy_mode
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
@@ -270,7 +274,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 touched.index_fill_(0, f, True)
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
-        if dp.active():
+        if dp.active() and not locality_sparse:  # (locality: the global mask is assembled from what the owners publish)
             touched = dp.allreduce_touched(touched)
             touched_rows = None
     row_adam = gaussians.optimizer.cpu_adam
@@ -312,6 +316,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         if own_rows.numel():
             gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
         dp.border_params_out(params.data, border)
+    elif locality_sparse:
+        with _lib.host_region("dp_border_plan"):
+            border = dp.border_plan(touched_rows.long(), N)
+        gaussians._owner_dirty = True
+        dp.border_params_out(params.data, border)  # the owners' rows are always current (eager row optimizer)
     elif lazy and dp.active() and getattr(args, "dp_owner_computes", False):
         owner = dp.owner_plan(touched_rows.long(), N)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
@@ -476,7 +485,20 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
 
     if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
-        if border is not None:
+        if border is not None and locality_sparse:
+            # D + F, clearing policy: SH gradient rows and the four small gradients of the border rows are added
+            # at their owners; the owners publish the summed small gradients of every row anybody touched, which
+            # also tells every rank the global visibility set SelectiveAdam steps
+            small_grads = [gaussians._xyz.grad, gaussians._opacity.grad, gaussians._scaling.grad, gaussians._rotation.grad]
+            dp.border_grads_home([grad_buf] + small_grads, None, 0, border)
+            own_rows = dp.border_own_rows(border)
+            _, got = dp.publish_rows(small_grads, own_rows, N)
+            touched = torch.zeros((N,), dtype=torch.bool, device=params.device)
+            for ids in [own_rows] + got:
+                if ids.numel():
+                    touched.index_fill_(0, ids, True)
+            touched_rows = own_rows.to(torch.int32)  # the SH rows THIS rank steps
+        elif border is not None:
             # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
             # their owners; the owners publish the summed small-attribute gradients of their touched rows
             dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)

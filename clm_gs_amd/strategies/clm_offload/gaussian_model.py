@@ -226,6 +226,16 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             self.host_rows_prepare(None, None)
             return
         from ... import dp
+        if (not self.lazy_rows) and dp.active() and getattr(self.args, "dp_locality", False) \
+                and getattr(self.args, "sparse_adam", False):
+            # sparse_adam locality: the owners' rows are always current (eager optimizer); completing the replicas
+            # is an all-gather of parameters and moments
+            if getattr(self, "_owner_dirty", True) and exchange:
+                self._owner_dirty = False
+                n = self._parameters.shape[0]
+                st = self.optimizer.cpu_adam.state[self._parameters]
+                dp.owner_gather_dense([self._parameters.data, st["exp_avg"], st["exp_avg_sq"]], n)
+            return
         if self.lazy_rows and dp.active() and (getattr(self.args, "dp_owner_computes", False)
                                                or getattr(self.args, "dp_locality", False)):
             # owner-computes camera-DP: every rank brings the rows it OWNS up to date, then all ranks

@@ -104,7 +104,9 @@ def main():
     from clm_gs_amd import dp, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 
-    args = utils.default_args(bsz=BSZ, sh_residency="hbm")
+    mode_arg = sys.argv[1] if len(sys.argv) > 1 else ""
+    sparse = mode_arg.endswith("_sparse")
+    args = utils.default_args(bsz=BSZ, sh_residency="hbm", sparse_adam=sparse)
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -119,7 +121,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "owner":
         args.dp_owner_computes = True  # rows owned by index range: all-gather params / reduce-scatter grads
     wire = None
-    if len(sys.argv) > 1 and sys.argv[1] == "locality":
+    if mode_arg.startswith("locality"):
         # locality exchange: rows in Z-order (index ranges = regions), cameras dealt to the rank owning most of
         # their rows; the global batch of a step is the union of the ranks' batches (the solo run trains on it)
         args.dp_locality = True
@@ -156,7 +158,7 @@ def main():
     assert dp.world_size() == 1
     if rank != 0:
         return
-    args1 = utils.default_args(bsz=G, sh_residency="hbm")
+    args1 = utils.default_args(bsz=G, sh_residency="hbm", sparse_adam=sparse)
     args1.clm_offload = True
     utils.set_args(args1)
     solo = _train(_model(sc, args1), global_batches, args1)

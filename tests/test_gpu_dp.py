@@ -96,6 +96,20 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev):
     assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
 
 
+def test_locality_exchange_sparse_adam_equals_single_rank(dev):
+    """dp_locality with sparse_adam (BigCity as the reference scripts it, bigcity.sh:54-85: SelectiveAdam for the
+    small attributes, the SH rows of visible Gaussians only): border rows by all_to_all, clearing-policy gradient
+    tables, the owners' published rows double as the global visibility set."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "locality_sparse"])
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert max(res["rel_l2_vs_single"]) < 2e-4, res
+    assert res["wire"]["all_to_all_grads"] > 0 and res["wire"].get("all_reduce", 0) == 0, res
+
+
 def test_trainer_locality_densify_keeps_replicas_identical(dev):
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
