@@ -92,6 +92,8 @@ def parse():
                     help="skip the second leg (the same workload with the SH rows + Adam state in pinned host memory)")
     ap.add_argument("--host-steps", type=int, default=20)
     ap.add_argument("--host-warmup", type=int, default=2)
+    ap.add_argument("--no-host-hint", action="store_true",
+                    help="host-resident leg: do not tell the engine the next batch's cameras (no speculative prefetch)")
     ap.add_argument("--gt", default="host", choices=["host", "resident"],
                     help="host: ground-truth images live in pinned host memory and every batch's images are uploaded on the "
                          "side stream one batch ahead (the reference: train.py:310-312); resident: all images in HBM before "
@@ -166,13 +168,53 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     rep, t = CP.camera_parity(gaussians, cam, width, height, rows="visible", cw=cw2, ch=ch2)
     frac2 = (cw2 * ch2) / float(width * height)
     parity_ok = rep["violations"] == []
+    # ---- the rest of a batch on the CPU (an engine-level baseline): the visibility cull of
+    # calculate_filters (one projection of ALL N rows per camera, base_engine.py:18-76) and the dense Adam over the 59
+    # floats of every row (optimizer.py:91-184), each timed on a contiguous sample of rows and scaled to N
+    import ctypes
+
+    import numpy as np
+    from oracle import gs_oracle as O
+    N = int(gaussians._xyz.shape[0])
+    bsz = int(__import__("clm_gs_amd").utils.get_args().bsz)
+    n_s = min(N, 4_000_000)
+    with torch.no_grad():
+        m_ = gaussians._xyz.detach()[:n_s].cpu().numpy()
+        q_ = torch.nn.functional.normalize(gaussians._rotation.detach()[:n_s]).cpu().numpy()
+        s_ = torch.exp(gaussians._scaling.detach()[:n_s]).cpu().numpy()
+    vm_ = np.ascontiguousarray(cam.world_view_transform.t().contiguous().cpu().numpy(), dtype=np.float32)
+    K_ = np.ascontiguousarray(cam.K.cpu().numpy(), dtype=np.float32)
+    radii = np.zeros(n_s, np.int32)
+    m2, dep, con = np.zeros((n_s, 2), np.float32), np.zeros(n_s, np.float32), np.zeros((n_s, 3), np.float32)
+    P_ = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+    f_ = ctypes.c_float
+    tc0 = time.perf_counter()
+    C.lib().orc_project(n_s, P_(m_), P_(q_), P_(s_), P_(vm_), P_(K_), width, height, f_(0.3), f_(0.01), f_(1e10), f_(0.0),
+                        P_(radii), P_(m2), P_(dep), P_(con))
+    t_cull = (time.perf_counter() - tc0) * N / float(n_s)
+    n_a = min(N, 1_000_000)
+    torch.set_num_threads(usable)
+    g_ = torch.Generator().manual_seed(0)
+    pa, ga = torch.randn(n_a, 59, generator=g_), torch.randn(n_a, 59, generator=g_)
+    ma, va = torch.zeros(n_a, 59), torch.zeros(n_a, 59)
+    O.adam_rows(pa, ga, ma, va, None, torch.full((59,), 1e-3), 0.9, 0.999, 1e-15, 1, 0.25)  # warm the allocator
+    ta0 = time.perf_counter()
+    O.adam_rows(pa, ga, ma, va, None, torch.full((59,), 1e-3), 0.9, 0.999, 1e-15, 2, 0.25)
+    t_adam = (time.perf_counter() - ta0) * N / float(n_a)
+    t_cam = t / frac2
+    batch_s = bsz * (t_cam + t_cull) + t_adam
     return {
-        "value": frac2 / t, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
-        "sample": (f"oracle/clmgs_oracle.c (OpenMP, {C.num_threads()} threads = the CPUs this container may use: cgroup quota / "
-                   f"affinity, of {os.cpu_count()} hardware threads): "
-                   f"1 micro-batch (camera 0, V={rep['rows']} rows in), centred {cw2}x{ch2} window = "
-                   f"{frac2:.4f} of the {width}x{height} image, {rep['n_visible']} visible, {rep['n_isects_oracle']} intersections, "
-                   f"forward+loss+backward in {t:.2f}s; value = window fraction / time"),
+        "value": bsz / batch_s, "unit": "img/s", "cores": C.num_threads(), "kind": "port",
+        "sample": (f"one whole batch of {bsz} cameras on the CPU, assembled from timed samples "
+                   f"({C.num_threads()} threads = the CPUs this container may use: cgroup quota / affinity, of "
+                   f"{os.cpu_count()} hardware threads): per camera the visibility cull of all {N} rows "
+                   f"(oracle/clmgs_oracle.c orc_project on {n_s} rows, scaled: {t_cull:.2f}s) + render forward + loss + "
+                   f"backward of its {rep['rows']} visible rows (oracle/clmgs_oracle.c, centred {cw2}x{ch2} window = "
+                   f"{frac2:.4f} of the {width}x{height} image, {rep['n_isects_oracle']} intersections, {t:.2f}s -> "
+                   f"{t_cam:.2f}s per image); per batch the dense Adam over 59 floats x {N} rows (oracle adam_rows on "
+                   f"{n_a} rows, scaled: {t_adam:.2f}s); value = {bsz} / ({bsz} x ({t_cam:.2f} + {t_cull:.2f}) + {t_adam:.2f}) s"),
+        "render_only_value": frac2 / t,
+        "seconds": {"camera_fwd_loss_bwd": round(t_cam, 3), "cull_per_camera": round(t_cull, 3), "adam_per_batch": round(t_adam, 3)},
         "parity": {"ok": bool(parity_ok),
                    "what": "the same window through the fused HIP path (clm_gs_amd.fused.camera_forward/backward) vs the "
                            "oracle (oracle/camera_parity.py: image >= 60 dB, |loss| <= 1e-5, radii / intersection total "
@@ -187,9 +229,11 @@ def gt_to_pinned_host(cams):
     """Host-resident mode: the cameras' ground-truth images live in pinned host memory, as the reference's
     OffloadSceneDataset keeps them (utils/camera_utils.py:75-126), and are uploaded per batch."""
     from clm_gs_amd.host import pinned_empty
+    use_torch = os.environ.get("CLMGS_BENCH_PIN") == "torch"
     for c in cams:
         if getattr(c, "image_host", None) is None and c.original_image is not None:
-            h = pinned_empty(tuple(c.original_image.shape), dtype=torch.uint8)
+            h = (torch.empty(tuple(c.original_image.shape), dtype=torch.uint8, pin_memory=True) if use_torch
+                 else pinned_empty(tuple(c.original_image.shape), dtype=torch.uint8))
             h.copy_(c.original_image)
             c.image_host, c.original_image = h, None
 
@@ -251,6 +295,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
 
     from clm_gs_amd import _lib, utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+    from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
     from clm_gs_amd.synthetic import synth_gaussians
     host_steps = max(1, min(a.host_steps, len(cams) // bsz - a.host_warmup))
     n_b = a.host_warmup + host_steps
@@ -292,6 +337,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
         upload_gt(batch, comm)
         utils.set_cur_iter(it[0])
         g.update_learning_rate(it[0])
+        hint_next_batch(g, cams[(b + 1) * bsz:(b + 2) * bsz] if not a.no_host_hint else None)  # what a data loader knows
         ls, _, _ = clm_offload_train_one_batch(g, _Scene, batch, g.parameters_grad_buffer, None, None, comm, gen)
         for c in batch:
             c.original_image = None
@@ -322,6 +368,9 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
            "steps": host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
            "pinned_host_bytes": int(4 * g.parameters_buffer.shape[0] * 192),
            "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
+           "late_rows_per_batch": (round(sum(_lib.STATS.get("host_late_rows", [])[-host_steps:]) / host_steps, 1)
+                                   if _lib.STATS.get("host_late_rows") else None),
+           "speculative_prefetch": not a.no_host_hint,
            "final_flush_ms": round((dt - t_batches) * 1e3, 1),
            "value_steady": round(host_steps * bsz / t_batches, 3),
            "value_note": "value = timed batches + the flush of the deferred host row steps still waiting after the last batch "
@@ -416,6 +465,12 @@ def main():
     else:
         cams = all_cams[rank::world]
     make_gt_images(cams, scene, args, W, H)
+    gt_mode = {"v": "host" if (a.gt == "host" or (a.strategy == "clm_offload" and a.residency == "host")) else "resident"}
+    if gt_mode["v"] == "host" and os.environ.get("CLMGS_BENCH_EXP") != "late":
+        # to pinned host memory BEFORE the model is built: the 4.8 GB the renders occupied go back to the driver
+        # first, so the model's tables and the per-camera buffers do not end up around a hole
+        gt_to_pinned_host(cams)
+        torch.cuda.empty_cache()
 
     if a.strategy == "clm_offload":
         from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
@@ -441,8 +496,7 @@ def main():
 
     state = {"iteration": 1}
 
-    gt_mode = {"v": "host" if (a.gt == "host" or (a.strategy == "clm_offload" and a.residency == "host")) else "resident"}
-    if gt_mode["v"] == "host":
+    if gt_mode["v"] == "host" and os.environ.get("CLMGS_BENCH_EXP") == "late":
         gt_to_pinned_host(cams)
         torch.cuda.empty_cache()
     feeder = GtFeeder(torch.cuda.Stream())
@@ -455,6 +509,9 @@ def main():
         utils.set_cur_iter(state["iteration"])
         gaussians.update_learning_rate(state["iteration"])
         if a.strategy == "clm_offload":
+            if a.residency == "host" and not a.no_host_hint:
+                from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
+                hint_next_batch(gaussians, cams[(batch_idx + 1) * bsz:(batch_idx + 2) * bsz])
             losses, _, sparsity = clm_offload_train_one_batch(
                 gaussians, _Scene, batch, gaussians.parameters_grad_buffer, None, None, comm_stream,
                 perm_generator)

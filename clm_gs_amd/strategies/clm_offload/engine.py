@@ -381,18 +381,16 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # and the latency-bound kernels fill the memory system underneath it.  The per-camera
             # tensors stay alive until the end-of-batch synchronisation (several streams read them).
             s_front, s_mem, s_raster = sts["mem"][0], sts["mem"][1], sts["raster"][0]
-            # The tile kernels' one-wave workgroups refill every freed wave slot of the chip, so the
-            # multi-wave workgroups of the front end wait for them.  When the front end is the long
-            # pole (many visible rows per tile: 53 at 28 M / 4K, +2 %) some CUs are kept out of the
-            # tile stream's CU mask (measured at 28 M, three interleaved rounds: 32 CUs 147.5, 48 149.8,
-            # 64 150.1, 96 146.8 img/s); with light front ends (19 rows per tile at 10 M: -2.5 %) the
-            # tile kernels keep the whole chip.  raster_reserve_cus: -1 = this rule, >= 0 = fixed.
+            # CU mask of the tile stream (raster_reserve_cus CUs kept for the other streams; -1 = the measured default).
+            # Round 2 kept 64 CUs out of the tile stream's mask at 28 M / 4K (+1.8 %: the tile kernels' one-wave
+            # workgroups refill every freed wave slot and the multi-wave workgroups of the front end waited for them).
+            # Re-measured in round 3 (three interleaved rounds in one call, GT resident): 0 CUs 157.7 / 156.2 / 158.1,
+            # 64 CUs 152.3 / 151.6 / 151.0, 16 CUs 148.9 / 148.2 / 149.4 img/s -- with Z-ordered rows, first-touch
+            # stores and the folded row sum the front end is no longer the long pole, and the masked stream (default
+            # priority) costs more than it protects.  Default: no mask, the low-priority tile stream.
             reserve = int(getattr(args, "raster_reserve_cus", -1))
             if reserve < 0:
-                rows_per_tile = sum(int(f.shape[0]) for f in filters) / float(max(1, bsz) * max(1, n_tiles))
-                # small images (BigCity 1080p: 8 160 tiles = 1.6 rounds of the chip's wave slots) lose
-                # more to the shorter rounds than the front end gains: 0 CUs 231-239, 32 233-234, 64 223-232 img/s
-                reserve = 64 if rows_per_tile >= 32.0 and n_tiles >= 20000 else 0
+                reserve = 0
             if reserve > 0:
                 if reserve not in sts["raster_masked"]:
                     sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
@@ -566,23 +564,59 @@ def _bit_of(bitmap, ids, bit):
 _HOST_CHUNK_ROWS = 262144  # staging granularity: 48 MB of parameter rows per hipMemcpyAsync
 
 
+def _host_tables(gaussians, dev):
+    """Row-indexed scratch of the host-resident mode (independent of the batch size): row -> slot, two row masks."""
+    N = gaussians._xyz.shape[0]
+    ht = getattr(gaussians, "_host_tabs", None)
+    if ht is None or ht["N"] != N:
+        ht = gaussians._host_tabs = dict(N=N, slot_of=torch.zeros((N,), dtype=torch.int32, device=dev),
+                                         mark=torch.zeros((N,), dtype=torch.bool, device=dev),
+                                         in_spec=torch.zeros((N,), dtype=torch.bool, device=dev))
+    return ht
+
+
 def _host_buffers(gaussians, T, dev):
     """Per-batch buffers of the host-resident mode, kept between batches (bucketed capacity):
-    pinned row list + pinned staging rows on the host, staging parameter / gradient rows and the
-    row -> slot table on the GPU."""
+    pinned row lists + pinned staging rows on the host (one set for the batch's late rows, one for the
+    speculative rows of the next batch), TWO staging parameter tables on the GPU (the batch in flight renders
+    from one while the next batch's speculative rows land in the other) and the gradient staging table.
+    `gen` counts re-allocations: rows staged into an older generation are gone."""
     from ...gsplat import bucket_size
     hb = getattr(gaussians, "_host_bufs", None)
-    cap = bucket_size(max(T, 1))
     N = gaussians._xyz.shape[0]
     if hb is None or hb["cap"] < T or hb["N"] != N:
+        cap = bucket_size(max(int(T), 1))
         hb = gaussians._host_bufs = dict(
-            cap=cap, N=N,
-            rows_h=pinned_empty((cap,), dtype=torch.int32),
-            stage_h=pinned_empty((cap, 48)),
-            sh_stage=torch.empty((cap, 48), device=dev),
-            g_stage=torch.empty((cap, 48), device=dev),
-            slot_of=torch.zeros((N,), dtype=torch.int32, device=dev))
+            cap=cap, N=N, cur=0, gen=(hb["gen"] + 1 if hb else 0),
+            rows_h=pinned_empty((cap,), dtype=torch.int32), stage_h=pinned_empty((cap, 48)),
+            spec_rows_h=None, spec_stage_h=None,
+            sh_stage=[torch.empty((cap, 48), device=dev), None],
+            g_stage=torch.empty((cap, 48), device=dev))
     return hb
+
+
+def _host_spec_buffers(hb, dev):
+    """The second staging table + its pinned twin: allocated when the first hint arrives (a caller that never
+    hints pays nothing for the speculative prefetch)."""
+    if hb["sh_stage"][1] is None:
+        cap = hb["cap"]
+        hb["sh_stage"][1] = torch.empty((cap, 48), device=dev)
+        hb["spec_rows_h"] = pinned_empty((cap,), dtype=torch.int32)
+        hb["spec_stage_h"] = pinned_empty((cap, 48))
+
+
+def hint_next_batch(gaussians, cameras):
+    """Host-resident mode: tell the engine which cameras the NEXT call of clm_offload_train_one_batch will get
+    (a data loader knows; `trainer.training` and `bench.py` call this).  The engine then selects that batch's rows
+    early (on the positions current NOW), and while the present batch still renders, the otherwise idle host pool
+    brings the rows the present batch does not touch up to date and ships them -- speculation that is verified
+    against the exact selection when the batch arrives (late rows are staged then, unused ones un-stamped).
+    Without a hint, or with a wrong one, the engine behaves as before."""
+    gaussians._next_batch_hint = list(cameras) if cameras else None
+
+
+def _drop_speculation(gaussians):
+    gaussians.drop_host_speculation()
 
 
 def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
@@ -603,6 +637,12 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
       batch) and copies them into a contiguous pinned staging buffer, chunk by chunk; each finished chunk
       goes to the GPU with a hipMemcpyAsync on the side stream (SDMA engine: no compute unit is taken from
       the renderer) while the pool works on the next chunk.
+    * SPECULATIVE PREFETCH (hint_next_batch): the host pool is busy for the first ~60 % of a batch and the link
+      for less; the rows of the NEXT batch that the present one does not touch (their state is final until
+      then) are prepared and shipped in that idle time into the second staging table.  When the next batch
+      arrives, its exact selection is compared with what was staged: only the LATE rows (touched by both
+      batches: their gradient had to come home first -- plus the few a position update moved into view) go
+      through the feeder at batch time, so the first camera waits for a third of its rows instead of all.
     * The cameras render from / accumulate into GPU staging tables ([T,48] parameters and gradients, row
       -> slot through an index the fused front end follows).
     * GPU -> host: zero-copy scatter STORES of the gradient rows into the pinned gradient table (plain
@@ -624,6 +664,10 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     if getattr(gaussians, "_host_out_stream", None) is None:
         gaussians._host_out_stream = torch.cuda.Stream()
     out_stream = gaussians._host_out_stream
+    hint = getattr(gaussians, "_next_batch_hint", None)
+    gaussians._next_batch_hint = None
+    if skip_opt or not getattr(args, "host_speculative_prefetch", True):
+        hint = None
     with torch.no_grad():
         with _lib.host_region("select_filters"):
             filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
@@ -635,41 +679,106 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
             _, batched_cameras, filters, sparsity, ordered_cams = order_calculation(
                 list(filters), list(batched_cameras), N, bsz, perm_generator, args)[:5]
-        hb = _host_buffers(gaussians, T, dev)
-        rows_h, stage_h = hb["rows_h"][:T], hb["stage_h"][:T]
-        sh_stage, g_stage, slot_of = hb["sh_stage"][:T], hb["g_stage"][:T], hb["slot_of"]
-        # ---- group the union by first use (slot order) and by last use (gradient hand-back order)
+        # ---- what was staged for this batch while the previous one rendered
+        spec = getattr(gaussians, "_host_spec", None)
+        hb0 = getattr(gaussians, "_host_bufs", None)
+        if spec is not None and (spec["key"] != tuple(sorted(id(c) for c in batched_cameras)) or spec["N"] != N
+                                 or hb0 is None or spec["gen"] != hb0["gen"]):
+            _drop_speculation(gaussians)
+            spec = None
+        gaussians._host_spec = None
+        n_p = 0
+        if spec is not None:
+            with _lib.host_region("spec_join"):
+                spec["thread"].join()
+            if spec["err"]:
+                raise spec["err"][0]
+            n_p = spec["n"]
+        ht = _host_tables(gaussians, dev)
+        slot_of, mark, in_spec = ht["slot_of"], ht["mark"], ht["in_spec"]
         with _lib.host_region("host_groups"):
+            mark.zero_()
+            mark.index_fill_(0, touched_rows, True)          # rows this batch touches
+            wasted = touched_rows[:0]
+            late_rows = touched_rows
+            if spec is not None and n_p:
+                P = spec["rows"]                                 # staged rows, slot k = P[k]
+                wasted = P[~mark[P]]                             # staged but not touched: no gradient will land
+                in_spec.zero_()
+                in_spec.index_fill_(0, P, True)
+                late_rows = touched_rows[~in_spec[touched_rows]]
+            n_late = int(late_rows.shape[0])                     # (shape of a boolean selection: one host read)
+            hb = _host_buffers(gaussians, n_p + n_late, dev)
+            if spec is not None and spec["gen"] != hb["gen"]:
+                # the staging tables had to grow: what was staged went with the old ones -- everything is late
+                # (re-preparing a current row is the identity; the stamps of the touched rows stay right)
+                late_rows, n_late, n_p, spec = touched_rows, T, 0, None
+            if spec is not None and n_p:
+                slot_of[spec["rows"]] = torch.arange(n_p, dtype=torch.int32, device=dev)
+            sh_stage = hb["sh_stage"][hb["cur"]]
+            T_slots = n_p + n_late
+            _lib.STATS.setdefault("host_late_rows", []).append(n_late)
+            g_stage = hb["g_stage"][:T_slots]
+            # ---- group the LATE rows by first use (slot order); all touched rows by last use (hand-back order)
             bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
-            bm = (bitmap[touched_rows].to(torch.int32) & ((1 << bsz) - 1)) if bsz < 32 else None
-            if bm is not None:
-                # float64 holds every bitmap word below 2^53 exactly: floor(log2) is the index of the top bit
-                first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float64))).to(torch.int64)   # earliest camera
-                low = bm & (-bm)
-                last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float64))).to(torch.int64)   # latest camera
-            else:  # bsz 32 / 64: per-camera membership instead of float log2 on wide words
-                first = torch.full((T,), bsz, dtype=torch.int64, device=dev)
-                last = torch.zeros((T,), dtype=torch.int64, device=dev)
-                pos = torch.empty((N,), dtype=torch.int64, device=dev)
-                pos[touched_rows] = torch.arange(T, device=dev)
+
+            def first_last(rows):
+                if bsz < 32:
+                    bm = bitmap[rows].to(torch.int32) & ((1 << bsz) - 1)
+                    # float64 holds every bitmap word below 2^53 exactly: floor(log2) is the index of the top bit
+                    first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float64))).to(torch.int64)   # earliest camera
+                    low = bm & (-bm)
+                    last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float64))).to(torch.int64)   # latest camera
+                    return first, last
+                # bsz 32 / 64: per-camera membership instead of log2 on wide words
+                n_r = rows.shape[0]
+                first = torch.full((n_r,), bsz, dtype=torch.int64, device=dev)
+                last = torch.zeros((n_r,), dtype=torch.int64, device=dev)
+                pos = torch.full((N,), -1, dtype=torch.int64, device=dev)
+                pos[rows] = torch.arange(n_r, device=dev)
                 for i, f in enumerate(filters):
                     pf = pos[f]
+                    pf = pf[pf >= 0]
                     first[pf] = torch.minimum(first[pf], torch.full_like(pf, i))
                     last[pf] = i
-            ord_first = torch.sort(first, stable=True).indices
-            union = touched_rows[ord_first]                               # slot k holds row union[k]
-            rows32 = union.to(torch.int32)
-            counts = torch.cat((torch.bincount(first, minlength=bsz), torch.bincount(last, minlength=bsz)))
-            _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), T * 4, 2))
-            slot_of[union] = torch.arange(T, dtype=torch.int32, device=dev)
+                return first, last
+
+            first_l, _ = first_last(late_rows)
+            ord_first = torch.sort(first_l, stable=True).indices
+            late_sorted = late_rows[ord_first]                          # slot n_p + k holds row late_sorted[k]
+            rows32 = late_sorted.to(torch.int32)
+            _, last_all = first_last(touched_rows)
+            # a staged row's camera can start once the staged block has landed: first-use groups of the late rows only
+            counts = torch.cat((torch.bincount(first_l, minlength=bsz), torch.bincount(last_all, minlength=bsz)))
+            rows_h, stage_h = hb["rows_h"][:n_late], hb["stage_h"][:n_late]
+            if n_late:
+                _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), n_late * 4, 2))
+                slot_of[late_sorted] = torch.arange(n_p, n_p + n_late, dtype=torch.int32, device=dev)
             sh_index = [slot_of[f] for f in filters]
-            ord_last = torch.sort(last, stable=True).indices
+            ord_last = torch.sort(last_all, stable=True).indices
             rows_by_last = touched_rows[ord_last]
             slots_by_last = slot_of[rows_by_last]
+            # ---- the NEXT batch's rows on the positions current now; what this batch touches cannot be staged early
+            spec_rows = None
+            if hint is not None:
+                _, t_next = select_filters(hint, gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                           gaussians._rotation.detach())
+                spec_rows = t_next[~mark[t_next]]
+                n_s = int(spec_rows.shape[0])
+                del t_next
+                if n_s and n_s <= hb["cap"]:
+                    _host_spec_buffers(hb, dev)
+                    _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(hb["spec_rows_h"][:n_s]),
+                                                    ctypes_ptr(spec_rows.to(torch.int32)), n_s * 4, 2))
+                else:
+                    spec_rows = None
             _t0 = time.perf_counter()
             cl = counts.tolist()                                          # one host read: 2*bsz group sizes
+            wasted_h = wasted.cpu() if wasted.numel() else None
             _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
         n_first, n_last = cl[:bsz], cl[bsz:]
+        if wasted_h is not None:  # staged for this batch but not touched by it: they expect no gradient after all
+            gaussians._host_g_step[wasted_h] = 0
         prev = gaussians._host_grads_event
         if prev is not None:  # the previous batch's scatter still reads g_stage
             default_stream.wait_event(prev)
@@ -685,6 +794,8 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
 
         def feeder():
             try:
+                if prev is not None:  # gradients of the previous batch must have landed before any row is stepped
+                    prev.synchronize()
                 k0 = 0
                 for i in range(bsz):
                     k1 = k0 + n_first[i]
@@ -692,10 +803,10 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                         c1 = min(k1, c0 + _HOST_CHUNK_ROWS)
                         _tp = time.perf_counter()
                         gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
-                                                    next_g_step=0 if skip_opt else step)
+                                                    next_g_step=0 if skip_opt else step, sync_grads=False)
                         _lib.STATS["host_prepare_s"] = _lib.STATS.get("host_prepare_s", 0.0) + time.perf_counter() - _tp
-                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[c0:c1]), ctypes_ptr(stage_h[c0:c1]),
-                                                        (c1 - c0) * 192, 1))
+                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[n_p + c0:n_p + c1]),
+                                                        ctypes_ptr(stage_h[c0:c1]), (c1 - c0) * 192, 1))
                     ev = torch.cuda.Event()
                     ev.record(comm_stream)
                     ev_group[i] = ev
@@ -706,11 +817,46 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                 for r in ready:
                     r.set()
 
+        if prev is not None:
+            gaussians._host_grads_event = None  # consumed by the feeder above
         worker = threading.Thread(target=feeder, name="clmgs-host-feeder")
         worker.start()
+        # ---- speculation for the next batch: after this batch's late rows, in the pool's idle time
+        new_spec = None
+        if spec_rows is not None:
+            nb = 1 - hb["cur"]
+            n_s = int(spec_rows.shape[0])
+            s_rows_h, s_stage_h, s_dst = hb["spec_rows_h"][:n_s], hb["spec_stage_h"][:n_s], hb["sh_stage"][nb]
+            ev_list = torch.cuda.Event()
+            ev_list.record(default_stream)   # the row list has reached pinned memory once this has passed
+            spec_err, spec_done = [], torch.cuda.Event()
+
+            def speculate():
+                try:
+                    worker.join()            # after this batch's own rows
+                    ev_list.synchronize()
+                    for c0 in range(0, n_s, _HOST_CHUNK_ROWS):
+                        c1 = min(n_s, c0 + _HOST_CHUNK_ROWS)
+                        _tp = time.perf_counter()
+                        gaussians.host_rows_prepare(s_rows_h[c0:c1], s_stage_h[c0:c1], to_step=step,
+                                                    next_g_step=step + 1, sync_grads=False)
+                        _lib.STATS["host_prepare_s"] = _lib.STATS.get("host_prepare_s", 0.0) + time.perf_counter() - _tp
+                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(s_dst[c0:c1]), ctypes_ptr(s_stage_h[c0:c1]),
+                                                        (c1 - c0) * 192, 1))
+                    spec_done.record(comm_stream)
+                except BaseException as e:
+                    spec_err.append(e)
+
+            th = threading.Thread(target=speculate, name="clmgs-host-speculate")
+            new_spec = dict(key=tuple(sorted(id(c) for c in hint)), N=N, rows=spec_rows, n=n_s, buf=nb, thread=th,
+                            gen=hb["gen"], event=spec_done, err=spec_err, rows_h=hb["spec_rows_h"])
         # ---- render: one camera after the other (the mode is bound by the host side, not by the GPU: the
         # camera pipeline of the HBM mode would only add its per-camera buffers to the peak)
         _zero_small_grads(gaussians)
+        if spec is not None:
+            default_stream.wait_event(spec["event"])  # the staged block has landed
+        if new_spec is not None:
+            new_spec["thread"].start()
         losses = []
         l0 = 0
         for i in range(bsz):
@@ -727,14 +873,22 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
             if l1 > l0:
                 out_stream.wait_stream(default_stream)
                 with torch.cuda.stream(out_stream):
+                    # (launch width: the kernel is bound by the link -- 51 GB/s of stores -- and its stalled waves take
+                    # wave slots from the render kernels next to it (preprocess_fwd 0.3 -> 4.7 ms in the trace), but
+                    # narrowing it to the reference's grid_size_H = 32 / 128 / 512 workgroups measured 101.3 / 100.6 /
+                    # 101.1 ms per batch against 99.1 at full width: the batch is bound by the link either way)
                     clm_kernels._rows("clmgs_rows_gather", parameters_grad_buffer[:N, :], g_stage,
-                                      rows_by_last[l0:l1], slots_by_last[l0:l1].to(torch.int64), 0)
+                                      rows_by_last[l0:l1], slots_by_last[l0:l1].to(torch.int64),
+                                      int(getattr(args, "host_scatter_grid", 0)))
             l0 = l1
         worker.join()
         ev_g = torch.cuda.Event()
         ev_g.record(out_stream)
         gaussians._host_grads_event = ev_g
-        gaussians._host_keep = (rows32, sh_index, touched_rows, filters, rows_by_last, slots_by_last, union)
+        gaussians._host_keep = (rows32, sh_index, touched_rows, filters, rows_by_last, slots_by_last, late_sorted)
+        if new_spec is not None:
+            hb["cur"] = new_spec["buf"]      # the next batch renders from the table its staged rows are landing in
+            gaussians._host_spec = new_spec
     if skip_opt:
         torch.cuda.synchronize()
         return losses, ordered_cams, sparsity

@@ -262,17 +262,32 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def deferred_host_rows(self):
         return getattr(self, "_host_last_step", None) is not None
 
-    def host_rows_prepare(self, rows_host, stage_host, to_step=None, next_g_step=0, n_rows=None):
+    def drop_host_speculation(self):
+        """Forget the rows the engine staged for a hinted batch that is not coming (model resized / flushed /
+        evaluated / different cameras): they were stamped as expecting that batch's gradient, which will never
+        land (clm_offload/engine.py speculative prefetch)."""
+        sp = getattr(self, "_host_spec", None)
+        self._host_spec = None
+        if sp is None:
+            return
+        sp["thread"].join()
+        if sp["n"]:
+            self._host_g_step[sp["rows_h"][:sp["n"]].long()] = 0
+
+    def host_rows_prepare(self, rows_host, stage_host, to_step=None, next_g_step=0, n_rows=None, sync_grads=True):
         """Bring host rows (int32 pinned/CPU row list, None = all) up to `to_step` (default: the optimizer's
         current step): waiting gradients are applied at their own step, skipped zero-gradient steps are
         replayed; copies the current parameter rows into stage_host[k] when given.  Blocks until the rows
-        are done (host threads, GIL released)."""
+        are done (host threads, GIL released).  sync_grads=False: the engine's feeder threads, which have
+        ordered themselves after the gradient hand-back already and must not touch the model's bookkeeping."""
         import ctypes
         from ... import _lib
         assert self.deferred_host_rows
-        if self._host_grads_event is not None:  # the waiting gradients must have landed
-            self._host_grads_event.synchronize()
-            self._host_grads_event = None
+        if sync_grads:
+            self.drop_host_speculation()
+            if self._host_grads_event is not None:  # the waiting gradients must have landed
+                self._host_grads_event.synchronize()
+                self._host_grads_event = None
         opt = self.optimizer.cpu_adam
         g = opt.param_groups[0]
         p = self._parameters

@@ -147,21 +147,29 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         deal()
     timer = End2endTimer()
     timer.start()
+    next_batch = None
     for iteration in range(1, iterations + 1, gbsz):
         utils.set_cur_iter(iteration)
         gaussians.update_learning_rate(iteration)
         if utils.check_update_at_this_iter(iteration, gbsz, 1000, 0):
             gaussians.oneupSHdegree()
-        if locality:
-            if len(order) < bsz:  # new epoch of THIS rank's pool
-                order = list(pool)
-                rng.shuffle(order)
-            batch = [train_cameras[order.pop()] for _ in range(bsz)]
-        else:
+        def draw():
+            nonlocal order
+            if locality:
+                if len(order) < bsz:  # new epoch of THIS rank's pool
+                    order = list(pool)
+                    rng.shuffle(order)
+                return [train_cameras[order.pop()] for _ in range(bsz)]
             if len(order) < gbsz:  # new epoch: shuffle, drop_last (train.py:156-167)
                 order = list(range(len(train_cameras)))
                 rng.shuffle(order)
-            batch = [train_cameras[order.pop()] for _ in range(gbsz)][rk::ws]
+            return [train_cameras[order.pop()] for _ in range(gbsz)][rk::ws]
+        # the loader is one batch ahead: the host-resident engine stages the next batch's untouched rows early
+        batch = next_batch if next_batch is not None else draw()
+        next_batch = draw() if iteration + gbsz <= iterations else None
+        if clm and getattr(args, "sh_residency", "hbm") == "host":
+            from .strategies.clm_offload.engine import hint_next_batch
+            hint_next_batch(gaussians, next_batch)
         if naive:
             losses, visibility = naive_offload_train_one_batch(gaussians, scene, batch, background,
                                                                sparse_adam=args.sparse_adam)
@@ -193,6 +201,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             gaussians.spatial_sort()  # clones / splits were appended at the end of the tables
             if locality and abs(gaussians.get_xyz.shape[0] - dealt_at) > 0.1 * dealt_at:
                 deal()
+                next_batch = None  # drawn from the old pool
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
                 iteration, gbsz, args.densification_interval, 0):
             log_file.write(memory_line(iteration, gbsz, gaussians))

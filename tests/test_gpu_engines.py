@@ -647,3 +647,55 @@ def test_device_side_counts_equal_exact_sizes_and_survive_overflow(dev):
         for a, b in zip(res[mode][1], res["exact"][1]):
             assert torch.equal(a, b), mode
     fused._CAPACITY.clear()
+
+
+def test_host_speculative_prefetch_is_exact(dev):
+    """Host-resident mode with hint_next_batch: the next batch's untouched rows are brought up to date and shipped
+    while the present batch renders, verified against the exact selection when the batch arrives.  Four batches
+    (overlapping cameras, so late / staged / wasted rows all occur) must end BIT FOR BIT where the run without
+    hints ends -- also with a wrong hint (dropped: its rows are un-stamped) and with a hint that is never used
+    (flush drops it)."""
+    from clm_gs_amd import _lib, utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_eval_one_cam, clm_offload_train_one_batch
+    from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
+    from clm_gs_amd.synthetic import nadir_cameras
+    res = {}
+    for mode in ("plain", "hinted", "wrong"):
+        args, sc, _ = _setup("clm_offload", "host")
+        cams = nadir_cameras(5 * BSZ, N, W, H, 0.35, seed=11, device="cuda")
+        g = torch.Generator().manual_seed(5)
+        for c in cams:
+            c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+        batches = [cams[0:4], cams[2:6], cams[9:13], cams[4:8]]  # overlapping / disjoint / returning cameras
+        m = _make("clm_offload", sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        _lib.STATS["host_late_rows"] = []
+        it, losses = 1, []
+        for b, batch in enumerate(batches):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            if mode == "hinted" and b + 1 < len(batches):
+                hint_next_batch(m, batches[b + 1])
+            if mode == "wrong":
+                hint_next_batch(m, cams[13:17] if b % 2 == 0 else (batches[b + 1] if b + 1 < len(batches) else cams[16:20]))
+            l, _, _ = clm_offload_train_one_batch(m, _Scene, batch, m.parameters_grad_buffer, None, None, comm, gen)
+            losses += [x.item() for x in l]
+            it += BSZ
+        late = list(_lib.STATS["host_late_rows"])
+        img = clm_offload_eval_one_cam(cams[1], m, None, _Scene)  # drops an outstanding speculation, then reads rows
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        res[mode] = (losses, [t.detach().clone() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters,
+                                                           st["exp_avg"], st["exp_avg_sq"])], img.clone(), late,
+                     m._host_g_step.clone(), m._host_last_step.clone())
+    touched = res["plain"][3]
+    # from the second batch on only the late rows go through the feeder
+    assert res["hinted"][3][0] == touched[0] and all(a < b for a, b in zip(res["hinted"][3][1:], touched[1:])), (res["hinted"][3], touched)
+    for mode in ("hinted", "wrong"):
+        assert res[mode][0] == res["plain"][0], mode
+        for a, b in zip(res[mode][1], res["plain"][1]):
+            assert torch.equal(a, b), mode
+        assert torch.equal(res[mode][2], res["plain"][2])
+        assert torch.equal(res[mode][5], res["plain"][5])                      # every row current as of the same step
+        assert torch.equal(res[mode][4], res["plain"][4])                      # and no stamp left behind by a dropped hint

@@ -250,6 +250,9 @@ def test_clm_offload_three_batches_match_reference_engine(dev, fx, residency, fu
     for b in range(int(d0["n_batches"])):
         utils.set_cur_iter(it)
         m.update_learning_rate(it)
+        if residency == "host":  # what a loader knows: the speculative prefetch of the host-resident engine runs
+            from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
+            hint_next_batch(m, cams[(b + 1) * bsz:(b + 2) * bsz])
         losses, order, _ = _clm_batch(m, Scene, cams[b * bsz:(b + 1) * bsz], comm, gen)
         ref = dict(zip(d[f"ordered_cams_b{b}"].tolist(), d[f"losses_b{b}"].tolist()))
         for k, l in zip(order, losses):
