@@ -626,7 +626,7 @@ def test_device_side_counts_equal_exact_sizes_and_survive_overflow(dev):
         if margin:
             args.isect_capacity_margin = margin
             args.isect_capacity_floor = 4096 if margin > 1 else 0
-        fused._CAPACITY.clear()
+        fused._CAPACITY.clear(); fused._CAP_HELD.clear()
         _lib.STATS["isect_capacity_redo"] = 0
         m = _make("clm_offload", sc, args)
         comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
@@ -646,7 +646,7 @@ def test_device_side_counts_equal_exact_sizes_and_survive_overflow(dev):
         assert all(abs(a - b) < 1e-6 for a, b in zip(res[mode][0], res["exact"][0]))
         for a, b in zip(res[mode][1], res["exact"][1]):
             assert torch.equal(a, b), mode
-    fused._CAPACITY.clear()
+    fused._CAPACITY.clear(); fused._CAP_HELD.clear()
 
 
 def test_host_speculative_prefetch_is_exact(dev):
