@@ -474,7 +474,8 @@ def main():
         # to pinned host memory BEFORE the model is built: the 4.8 GB the renders occupied go back to the driver
         # first, so the model's tables and the per-camera buffers do not end up around a hole
         gt_to_pinned_host(cams)
-        torch.cuda.empty_cache()
+        if os.environ.get("CLMGS_BENCH_EXP") != "noempty":
+            torch.cuda.empty_cache()
 
     if a.strategy == "clm_offload":
         from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
@@ -503,6 +504,8 @@ def main():
     if gt_mode["v"] == "host" and os.environ.get("CLMGS_BENCH_EXP") == "late":
         gt_to_pinned_host(cams)
         torch.cuda.empty_cache()
+    if os.environ.get("CLMGS_BENCH_EXP") == "pinjunk":  # experiment: does pinned host memory by itself slow the GPU?
+        _junk = [torch.empty((3, H, W), dtype=torch.uint8, pin_memory=True) for _ in range(len(cams))]
     feeder = GtFeeder(torch.cuda.Stream())
 
     def step(batch_idx):

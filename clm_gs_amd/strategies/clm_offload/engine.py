@@ -585,9 +585,13 @@ def _host_buffers(gaussians, T, dev):
     hb = getattr(gaussians, "_host_bufs", None)
     N = gaussians._xyz.shape[0]
     if hb is None or hb["cap"] < T or hb["N"] != N:
-        cap = bucket_size(max(int(T), 1))
+        cap = bucket_size(max(int(T * 1.06), 1))  # staged-but-unused rows of a hinted batch ride along: a few percent
+        gen = hb["gen"] + 1 if hb else 0
+        if hb is not None:
+            hb.clear()  # the old tables go back to the allocator BEFORE the new ones are requested
+        gaussians._host_bufs = None
         hb = gaussians._host_bufs = dict(
-            cap=cap, N=N, cur=0, gen=(hb["gen"] + 1 if hb else 0),
+            cap=cap, N=N, cur=0, gen=gen,
             rows_h=pinned_empty((cap,), dtype=torch.int32), stage_h=pinned_empty((cap, 48)),
             spec_rows_h=None, spec_stage_h=None,
             sh_stage=[torch.empty((cap, 48), device=dev), None],
@@ -681,9 +685,9 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                 list(filters), list(batched_cameras), N, bsz, perm_generator, args)[:5]
         # ---- what was staged for this batch while the previous one rendered
         spec = getattr(gaussians, "_host_spec", None)
-        hb0 = getattr(gaussians, "_host_bufs", None)
+        gen0 = (getattr(gaussians, "_host_bufs", None) or {}).get("gen")
         if spec is not None and (spec["key"] != tuple(sorted(id(c) for c in batched_cameras)) or spec["N"] != N
-                                 or hb0 is None or spec["gen"] != hb0["gen"]):
+                                 or spec["gen"] != gen0):
             _drop_speculation(gaussians)
             spec = None
         gaussians._host_spec = None
