@@ -764,9 +764,14 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
             slots_by_last = slot_of[rows_by_last]
             # ---- the NEXT batch's rows on the positions current now; what this batch touches cannot be staged early
             spec_rows = None
+            t_next = None
             if hint is not None:
-                _, t_next = select_filters(hint, gaussians._xyz.detach(), gaussians._scaling.detach(),
-                                           gaussians._rotation.detach())
+                try:
+                    _, t_next = select_filters(hint, gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                               gaussians._rotation.detach())
+                except AssertionError:  # a hinted camera sees nothing yet: that batch will complain itself
+                    t_next = None
+            if t_next is not None:
                 spec_rows = t_next[~mark[t_next]]
                 n_s = int(spec_rows.shape[0])
                 del t_next
