@@ -247,7 +247,7 @@ class GtFeeder:
     host memory to HBM on the side stream (SDMA, no compute unit involved) into a ring of preallocated device
     buffers (3 batches deep: no allocation inside the timed region; a slot is overwritten only after the batch
     that read it has been enqueued completely -- release() records the event the next upload waits for)."""
-    DEPTH = 3
+    DEPTH = int(os.environ.get("CLMGS_GT_RING", "3"))
 
     def __init__(self, stream):
         self.stream, self.pending, self.ring, self.freed = stream, {}, {}, {}

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, utils
 from ._lib import check, dptr, stream
 
 F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
@@ -248,7 +248,7 @@ def adam_catch_up(p, m, v, last_step, rows, col_lr, beta1, beta2, eps, to_step, 
     if rows is None:
         last_step[: p.shape[0]].fill_(int(to_step))
     else:
-        last_step.index_fill_(0, rows.long(), int(to_step))  # scalar as kernel argument: no blocking H2D copy
+        utils.fill_rows(last_step, rows.long(), int(to_step))  # scalar as kernel argument: no blocking H2D copy
 
 
 def densify_stats(filter_idx, v_means2d, radii, width, height, max_radii2D, xyz_gradient_accum,

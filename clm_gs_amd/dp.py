@@ -291,9 +291,9 @@ def border_own_rows(pl):
     dev = pl.mine.device
     mark = torch.zeros((max(1, pl.hi - pl.lo),), dtype=torch.bool, device=dev)
     if pl.mine.numel():
-        mark.index_fill_(0, pl.mine - pl.lo, True)
+        utils.fill_rows(mark, pl.mine - pl.lo, True)
     if pl.serve_rows.numel():
-        mark.index_fill_(0, pl.serve_rows - pl.lo, True)
+        utils.fill_rows(mark, pl.serve_rows - pl.lo, True)
     return torch.nonzero(mark).flatten() + pl.lo
 
 
@@ -455,7 +455,7 @@ def exchange_bytes(touched_per_rank, n_total):
     cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
     mark = torch.zeros((n_total,), dtype=torch.bool, device=dev)
     for t in touched_per_rank:
-        mark.index_fill_(0, t, True)
+        utils.fill_rows(mark, t, True)
     U = int(mark.sum())
     cs = torch.cumsum(mark.to(torch.int64), 0)
     ends = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), cs[cuts[1:] - 1])).tolist()

@@ -268,10 +268,10 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     if need_mask:
         touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
         if touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
-            touched.index_fill_(0, touched_rows, True)
+            utils.fill_rows(touched, touched_rows, True)
         else:
             for f in filters:
-                touched.index_fill_(0, f, True)
+                utils.fill_rows(touched, f, True)
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
         if dp.active() and not locality_sparse:  # (locality: the global mask is assembled from what the owners publish)
@@ -494,7 +494,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             touched = torch.zeros((N,), dtype=torch.bool, device=params.device)
             for ids in [own_rows] + got:
                 if ids.numel():
-                    touched.index_fill_(0, ids, True)
+                    utils.fill_rows(touched, ids, True)
             touched_rows = own_rows.to(torch.int32)  # the SH rows THIS rank steps
         elif border is not None:
             # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
@@ -542,7 +542,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         # to the device and block the host until the whole batch has drained)
         stamp = touched_rows[owner.lo:owner.hi] if owner is not None else touched_rows
         if stamp.numel() and ft_stamp is None:  # first-touch mode: the backward kernels stamped their rows
-            gaussians._row_g_step.index_fill_(0, stamp.long(), step)
+            utils.fill_rows(gaussians._row_g_step, stamp.long(), step)
     elif not args.stop_update_param:
         row_update(touched_rows)
     st["step"] = step
@@ -702,14 +702,14 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         slot_of, mark, in_spec = ht["slot_of"], ht["mark"], ht["in_spec"]
         with _lib.host_region("host_groups"):
             mark.zero_()
-            mark.index_fill_(0, touched_rows, True)          # rows this batch touches
+            utils.fill_rows(mark, touched_rows, True)          # rows this batch touches
             wasted = touched_rows[:0]
             late_rows = touched_rows
             if spec is not None and n_p:
                 P = spec["rows"]                                 # staged rows, slot k = P[k]
                 wasted = P[~mark[P]]                             # staged but not touched: no gradient will land
                 in_spec.zero_()
-                in_spec.index_fill_(0, P, True)
+                utils.fill_rows(in_spec, P, True)
                 late_rows = touched_rows[~in_spec[touched_rows]]
             n_late = int(late_rows.shape[0])                     # (shape of a boolean selection: one host read)
             hb = _host_buffers(gaussians, n_p + n_late, dev)
@@ -904,7 +904,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
     visibility_mask = None
     if args.sparse_adam:
         visibility_mask = torch.zeros((N,), dtype=torch.bool, device=dev)
-        visibility_mask.index_fill_(0, touched_rows, True)
+        utils.fill_rows(visibility_mask, touched_rows, True)
     _gpu_adam_step(gaussians, args, visibility_mask)
     gaussians.invalidate_small_packed()
     row_adam.global_step = step
