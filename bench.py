@@ -98,10 +98,12 @@ def parse():
     ap.add_argument("--host-warmup", type=int, default=2)
     ap.add_argument("--no-host-hint", action="store_true",
                     help="host-resident leg: do not tell the engine the next batch's cameras (no speculative prefetch)")
-    ap.add_argument("--gt", default="host", choices=["host", "resident"],
-                    help="host: ground-truth images live in pinned host memory and every batch's images are uploaded on the "
-                         "side stream one batch ahead (the reference: train.py:310-312); resident: all images in HBM before "
-                         "the timed region.  The default run reports both (value = host, value_gt_resident)")
+    ap.add_argument("--gt", default="both", choices=["both", "resident", "host"],
+                    help="where the ground-truth images are when the timed region starts.  resident: in HBM (the bench "
+                         "contract: inputs resident before the timed region; `value`); host: in pinned host memory, every "
+                         "batch's images uploaded on a side stream one batch ahead (the reference: train.py:310-312); both "
+                         "(default): `value` with resident images, then the same K steps again with streamed images as "
+                         "`value_gt_streamed`")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
                     help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality (Z-ordered rows required)")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
@@ -233,11 +235,9 @@ def gt_to_pinned_host(cams):
     """Host-resident mode: the cameras' ground-truth images live in pinned host memory, as the reference's
     OffloadSceneDataset keeps them (utils/camera_utils.py:75-126), and are uploaded per batch."""
     from clm_gs_amd.host import pinned_empty
-    use_torch = os.environ.get("CLMGS_BENCH_PIN") == "torch"
     for c in cams:
         if getattr(c, "image_host", None) is None and c.original_image is not None:
-            h = (torch.empty(tuple(c.original_image.shape), dtype=torch.uint8, pin_memory=True) if use_torch
-                 else pinned_empty(tuple(c.original_image.shape), dtype=torch.uint8))
+            h = pinned_empty(tuple(c.original_image.shape), dtype=torch.uint8)
             h.copy_(c.original_image)
             c.image_host, c.original_image = h, None
 
@@ -247,7 +247,7 @@ class GtFeeder:
     host memory to HBM on the side stream (SDMA, no compute unit involved) into a ring of preallocated device
     buffers (3 batches deep: no allocation inside the timed region; a slot is overwritten only after the batch
     that read it has been enqueued completely -- release() records the event the next upload waits for)."""
-    DEPTH = int(os.environ.get("CLMGS_GT_RING", "3"))
+    DEPTH = 3
 
     def __init__(self, stream):
         self.stream, self.pending, self.ring, self.freed = stream, {}, {}, {}
@@ -470,12 +470,9 @@ def main():
         cams = all_cams[rank::world]
     make_gt_images(cams, scene, args, W, H)
     gt_mode = {"v": "host" if (a.gt == "host" or (a.strategy == "clm_offload" and a.residency == "host")) else "resident"}
-    if gt_mode["v"] == "host" and os.environ.get("CLMGS_BENCH_EXP") != "late":
-        # to pinned host memory BEFORE the model is built: the 4.8 GB the renders occupied go back to the driver
-        # first, so the model's tables and the per-camera buffers do not end up around a hole
+    if gt_mode["v"] == "host":
         gt_to_pinned_host(cams)
-        if os.environ.get("CLMGS_BENCH_EXP") != "noempty":
-            torch.cuda.empty_cache()
+        torch.cuda.empty_cache()
 
     if a.strategy == "clm_offload":
         from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
@@ -501,11 +498,6 @@ def main():
 
     state = {"iteration": 1}
 
-    if gt_mode["v"] == "host" and os.environ.get("CLMGS_BENCH_EXP") == "late":
-        gt_to_pinned_host(cams)
-        torch.cuda.empty_cache()
-    if os.environ.get("CLMGS_BENCH_EXP") == "pinjunk":  # experiment: does pinned host memory by itself slow the GPU?
-        _junk = [torch.empty((3, H, W), dtype=torch.uint8, pin_memory=True) for _ in range(len(cams))]
     feeder = GtFeeder(torch.cuda.Stream())
 
     def step(batch_idx):
@@ -622,13 +614,14 @@ def main():
     if owner_dp:
         gaussians.flush_lazy_rows()  # replicas complete again (collective), outside the timed region
     n_loss_timed = len(all_losses)
-    # ---- the same K steps once more with every ground-truth image already in HBM (what round 1 / 2 measured as
-    # the headline): reported beside `value` as value_gt_resident; the passes below (instrumented, solo) keep it
+    # ---- the same K steps once more with the ground-truth images where the reference keeps them (pinned host
+    # memory, train.py:310-312), every batch's images uploaded on a side stream one batch ahead: reported beside
+    # `value` as value_gt_streamed; the passes below (instrumented, solo) keep that mode
     dt_res = peak_res = None
-    if gt_mode["v"] == "host" and not (a.strategy == "clm_offload" and a.residency == "host"):
-        for c in cams[a.warmup * bsz:(a.warmup + a.steps) * bsz]:
-            c.original_image = c.image_host.to("cuda")
-        gt_mode["v"] = "resident"
+    if a.gt == "both" and gt_mode["v"] == "resident":
+        gt_to_pinned_host(cams)  # (no empty_cache: the allocator keeps the blocks the steps have been using)
+        gt_mode["v"] = "host"
+        feeder.start(a.warmup, cams[a.warmup * bsz:(a.warmup + 1) * bsz])  # ring buffers + first batch: before the clock
         fence()
         torch.cuda.reset_peak_memory_stats()
         tr0 = time.perf_counter()
@@ -808,15 +801,17 @@ def main():
                    "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
         "gt_images": ("pinned host memory, every batch uploaded on a side stream one batch ahead (train.py:310-312)"
-                      if (a.gt == "host" or a.residency == "host") else "all resident in HBM before the timed region"),
-        "value_gt_resident": round(n_images * world / dt_res, 4) if dt_res else None,
+                      if (a.gt == "host" or a.residency == "host") else
+                      "all resident in HBM before the timed region (bench contract); value_gt_streamed = the same K steps with "
+                      "the images in pinned host memory, uploaded per batch as the reference does (train.py:310-312)"),
+        "value_gt_streamed": round(n_images * world / dt_res, 4) if dt_res else None,
         "peak_gpu_bytes": int(peak),
-        "peak_gpu_bytes_gt_resident": int(peak_res) if peak_res else None,
+        "peak_gpu_bytes_gt_streamed": int(peak_res) if peak_res else None,
         "peak_gpu_bytes_note": ("sh_residency=hbm keeps the whole model + optimizer state in HBM by design (SURVEY 7: 288 GB): "
                                 f"{944 * N / 1e9:.1f} GB of the peak are the {N} x 944 B of parameters, moments and gradient rows, "
                                 f"{60 * N / 1e9:.1f} GB the packed small-attribute mirror / gradient / stamp tables; the rest is one "
-                                "to two cameras' working set (stream-ordered frees) and, in the gt_resident figure, "
-                                f"{a.steps * bsz} resident GT images ({a.steps * bsz * 3 * H * W / 1e9:.1f} GB).  The reference's 13.0 GB "
+                                "to two cameras' working set (stream-ordered frees) and the resident GT images of the run "
+                                f"({len(cams)} x {3 * H * W / 1e6:.1f} MB = {len(cams) * 3 * H * W / 1e9:.1f} GB; not in the gt_streamed figure).  The reference's 13.0 GB "
                                 "is its offloading configuration (SH rows + Adam state in host memory): compare host_resident.peak_gpu_bytes"),
         "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
                      "I_emitted_avg": round(I_emitted, 1), "I_emitted_first_last": [emitted[0], emitted[-1]] if emitted else None,

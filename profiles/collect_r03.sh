@@ -9,7 +9,7 @@ timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_28m_final.log 2> $O
 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --opt overlap_cameras=false --no-host-leg > $O/bench_28m_no_overlap.log 2>&1
 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --opt device_side_counts=false > $O/bench_28m_exact_sizes.log 2>&1
 timeout 300 python bench.py --config rubble10m --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_rubble10m_clm.log 2>&1
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-kernel-timing --gt resident > $O/bench_28m_gt_resident.log 2>&1
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-kernel-timing --gt host > $O/bench_28m_gt_host.log 2>&1
 timeout 300 python bench.py --residency host --steps 20 --warmup 4 --no-cpu-baseline --no-kernel-timing --prime-seconds 0 --no-host-hint > $O/bench_28m_host_no_hint.log 2>&1
 timeout 200 python bench.py --config bicycle6m --strategy no_offload --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_bicycle6m_no_offload.log 2>&1
 timeout 200 python bench.py --config bicycle6m --steps 10 --warmup 3 --no-cpu-baseline --no-host-leg > $O/bench_bicycle6m_clm.log 2>&1
