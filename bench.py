@@ -22,6 +22,13 @@ import os
 import sys
 import time
 
+# Two hardware queues for the process's HIP streams (the runtime's default is 4): the camera pipeline's three streams
+# by kernel type then share two queues.  Measured interleaved, three rounds in one call (28 M, GT resident): 1 queue
+# 147.2 / 146.9 / 148.2, 2 queues 155.8 / 157.9 / 157.0, 3: 153.0 / 155.4 / 155.7, 4: 154.5 / 154.5 / 155.6, default
+# 153.6 / 154.0 / 155.5 img/s.  Single-GPU runs only (RCCL's own streams want their queues); an exported value wins.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -798,7 +805,8 @@ def main():
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
                    "camera_order": a.camera_order, "row_order": a.row_order,
-                   "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb},
+                   "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb,
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
         "gt_images": ("pinned host memory, every batch uploaded on a side stream one batch ahead (train.py:310-312)"
                       if (a.gt == "host" or a.residency == "host") else
