@@ -22,7 +22,10 @@ constexpr int RS_THREADS = 256;
 // Keys per thread: 4 (1024 keys per block, 12-20 KB of LDS).  8 is ~10 % faster solo, but the
 // sorts run concurrently with the alpha-blend kernels, whose small blocks keep most of each CU's
 // LDS and registers occupied: 35-42 KB blocks were starved (1-2 ms per pass instead of 0.03-0.12).
-constexpr int RS_DEFAULT_ITEMS = 4;
+#ifndef CLMGS_RS_ITEMS
+#define CLMGS_RS_ITEMS 4
+#endif
+constexpr int RS_DEFAULT_ITEMS = CLMGS_RS_ITEMS;
 constexpr int RS_MIN_CHUNK = RS_THREADS * RS_DEFAULT_ITEMS;
 
 template <typename KeyT, int RS_ITEMS>

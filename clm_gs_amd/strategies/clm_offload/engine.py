@@ -365,6 +365,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
             except AttributeError:
                 lo, hi = 0, -1
+            if getattr(args, "flat_stream_priorities", False):  # experiment knob: every stream at the default priority
+                lo = hi = 0
             sts = gaussians._clmgs_streams = {
                 "aux": torch.cuda.Stream(),
                 "mem": [torch.cuda.Stream(priority=hi) for _ in range(max(2, n_lanes))],

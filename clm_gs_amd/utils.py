@@ -54,6 +54,7 @@ def default_args(**over):
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
+        flat_stream_priorities=False,
         host_speculative_prefetch=True,  # host-resident mode: stage the hinted next batch's untouched rows early
         device_side_counts=True,   # fused engine: consumers of a camera's intersection list read its length on the device
         isect_capacity_margin=1.25,  # ... from buffers sized (largest count seen at this image size) x margin
