@@ -51,9 +51,53 @@ def _train(force, locality=False):
     return [t.detach().clone() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters)]
 
 
+def big_index_mode():
+    """Every exchange of dp.py with MORE THAN 2^26 row ids in one call (the size at which raw `t[idx]` / index_select
+    silently drop rows on this stack, profiles/repro_index_defect.py): a 1-rank RCCL group runs the collectives as the
+    identity, so every table must come back unchanged -- through the pack / unpack index paths at full size."""
+    from clm_gs_amd import dp
+    os.environ["CLMGS_DP_FORCE"] = "1"
+    n = 70_000_000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    keep = torch.rand(n, generator=g, device="cuda") < 0.975
+    idx = torch.nonzero(keep).flatten()
+    assert idx.numel() > (1 << 26), idx.numel()
+    del keep
+    res = {"n_rows": int(idx.numel())}
+    i64 = torch.arange(n, device="cuda", dtype=torch.int64)
+    t4 = torch.stack([((i64 * 7 + j) % (1 << 24)).to(torch.float32) for j in range(4)], dim=1).contiguous()
+    t12 = torch.stack([((i64 * 3 + j) % (1 << 24)).to(torch.float32) for j in range(12)], dim=1).contiguous()
+    del i64
+    a4, a12 = t4.clone(), t12.clone()
+    dp.allreduce_tables_rows([a4, a12], idx, n, dense_above=2.0)     # packed path: take_rows / put_rows of 68 M rows
+    res["tables_packed"] = bool(torch.equal(a4, t4) and torch.equal(a12, t12))
+    dp.allreduce_rows(a12, None, average=False, rows=idx[: idx.numel() // 3])
+    res["rows_packed"] = bool(torch.equal(a12, t12))
+    pl = dp.owner_plan(idx, n)
+    dp.owner_reduce_rows(a4, pl)
+    dp.owner_gather_rows(a4, pl)
+    res["owner_exchange"] = bool(torch.equal(a4, t4))
+    del pl
+    bp = dp.border_plan(idx, n)
+    dp.border_params_out(a12, bp)
+    stamp = torch.zeros(n, dtype=torch.int32, device="cuda")
+    from clm_gs_amd import utils
+    utils.fill_rows(stamp, idx, 9)
+    dp.border_grads_home([a12, a4], stamp, 9, bp)
+    counts = dp.publish_small(a12, stamp, 9, n)
+    own = dp.border_own_rows(bp)
+    res["locality_exchange"] = bool(torch.equal(a12, t12) and torch.equal(a4, t4) and counts == [idx.numel()]
+                                    and torch.equal(own, idx) and int((stamp == 9).sum()) == idx.numel())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("NCCLRESULT " + json.dumps(res))
+
+
 def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        return big_index_mode()
     from clm_gs_amd import dp
     assert dist.get_backend() == "nccl" and dp.world_size() == 1
     os.environ["CLMGS_DP_FORCE"] = "1"

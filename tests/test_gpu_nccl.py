@@ -37,6 +37,17 @@ def test_dp_collectives_and_engine_exchange_on_rccl_world1(dev):
     assert all(res.values()), res
 
 
+def test_dp_exchanges_with_more_than_2p26_row_ids_on_rccl_world1(dev):
+    """The index paths of every camera-DP exchange at the size where raw advanced indexing breaks on this stack
+    (> 2^26 indices, profiles/r03_index_defect.json): 68 M row ids of a 70 M-row model through the all-reduce,
+    owner-computes and locality exchanges on a 1-rank RCCL group -- every table must come back bit for bit."""
+    out = _torchrun([os.path.join(ROOT, "tests", "nccl_worker.py"), "big"], timeout=600)
+    line = [l for l in out.splitlines() if l.startswith("NCCLRESULT ")][-1]
+    res = json.loads(line[len("NCCLRESULT "):])
+    assert res["n_rows"] > (1 << 26)
+    assert all(v for k, v in res.items() if k != "n_rows"), res
+
+
 def test_bench_under_torchrun_world1_uses_rccl(dev):
     env = dict(os.environ, CLMGS_DP_FORCE="1")
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
