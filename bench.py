@@ -798,7 +798,8 @@ def main():
                 "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
                 "by_collective_per_step": {k: round(v / a.steps, 1) for k, v in wire.items() if k != "total"},
                 "note": "bytes rank 0 SENDS per batch (clm_gs_amd.dp.wire_bytes: ring model for all-reduce, exact sizes for "
-                        "all_to_all / all_gather); includes the final flush of the timed region"}
+                        "all_to_all / all_gather); the timed region ends with every rank catching up the rows it owns, the "
+                        "all-gather that completes the replicas for evaluation / saving runs after it and is not counted"}
                if (world > 1 or under_torchrun) else None),
         "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,

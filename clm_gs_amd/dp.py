@@ -258,7 +258,8 @@ def owner_gather_dense(tables, n_total):
 #                           needs every row's position on every rank) sees the same global sum everywhere
 # Nothing else travels: a row deep inside a rank's region costs 52 B per peer (step F) instead of 240 B x 2 (G-1)/G.
 class BorderPlan:
-    __slots__ = ("n_ranks", "rank", "lo", "hi", "n_total", "mine", "border", "need", "serve", "serve_rows")
+    __slots__ = ("n_ranks", "rank", "lo", "hi", "n_total", "mine", "border", "need", "serve", "serve_rows",
+                 "own_rows", "own_counts")
 
 
 def border_plan(touched_rows, n_total):
@@ -283,6 +284,14 @@ def border_plan(touched_rows, n_total):
     pl.serve_rows = torch.empty((sum(serve_l),), dtype=torch.int64, device=dev)
     dist.all_to_all_single(pl.serve_rows, pl.border, output_split_sizes=serve_l, input_split_sizes=need_l)
     _count("all_to_all_ids", 8 * (G + pl.border.numel()))
+    # the rows of this rank's range anybody touches this batch, and how many every rank has: known NOW, so the
+    # end-of-batch publication of the small-gradient sums (step F) needs no size readback of its own
+    pl.own_rows = border_own_rows(pl)
+    k = torch.tensor([pl.own_rows.numel()], dtype=torch.int64, device=dev)
+    counts = torch.empty((G,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, k)
+    pl.own_counts = counts.tolist()
+    _count("all_gather_small", 8 * (G - 1))
     return pl
 
 
@@ -346,21 +355,24 @@ def border_grads_home(tables, stamp, step, pl):
             utils.fill_rows(t, pl.border, 0.0)
 
 
-def publish_rows(tables, own_rows, n_total):
+def publish_rows(tables, own_rows, n_total, counts=None):
     """F, general form: every owner all-gathers (row id, its summed rows of `tables`, side by side) for `own_rows`
-    (ascending absolute ids inside its range); the receivers store the rows.  -> (counts per rank, list of the
-    absolute id tensors received from every other rank)."""
+    (ascending absolute ids inside its range); the receivers store the rows.  `counts`: len(own_rows) of every rank
+    if the caller exchanged them already (border_plan does) -- no host read here then.
+    -> (counts per rank, list of the absolute id tensors received from every other rank)."""
     G, r = world_size(), rank()
     lo, _ = owner_range(n_total, r, G)
     t0 = tables[0]
     widths = [t.shape[1] if t.dim() > 1 else 1 for t in tables]
     W = sum(widths)
-    k = torch.tensor([own_rows.numel()], dtype=torch.int64, device=t0.device)
-    counts = torch.empty((G,), dtype=torch.int64, device=t0.device)
-    dist.all_gather_into_tensor(counts, k)
-    counts = counts.tolist()  # host read
+    if counts is None:
+        k = torch.tensor([own_rows.numel()], dtype=torch.int64, device=t0.device)
+        counts = torch.empty((G,), dtype=torch.int64, device=t0.device)
+        dist.all_gather_into_tensor(counts, k)
+        counts = counts.tolist()  # host read
+        _count("all_gather_small", 8 * (G - 1))
     chunk = max(1, max(counts))
-    send = t0.new_zeros((chunk, W + 1))
+    send = t0.new_empty((chunk, W + 1))  # rows beyond this rank's count are padding nobody reads
     n_own = own_rows.numel()
     if n_own:
         c = 0
@@ -370,7 +382,7 @@ def publish_rows(tables, own_rows, n_total):
         send[:n_own, W] = (own_rows - lo).to(torch.int32).view(torch.float32)  # the id rides along as raw bits
     recv = t0.new_empty((G * chunk, W + 1))
     dist.all_gather_into_tensor(recv, send)
-    _count("all_gather_small", (send.numel() * send.element_size() + 8) * (G - 1))
+    _count("all_gather_small", send.numel() * send.element_size() * (G - 1))
     got = []
     for q in range(G):
         if q == r or not counts[q]:
@@ -385,13 +397,17 @@ def publish_rows(tables, own_rows, n_total):
     return counts, got
 
 
-def publish_small(small_g, stamp, step, n_total):
-    """F (first-touch policy): the rows of this rank's range stamped `step` are the ones anybody touched; they are
-    published with their summed packed small-gradient row, the receivers store and stamp them, so the replicated
-    small-attribute Adam consumes identical sums everywhere."""
-    lo, hi = owner_range(n_total)
-    own = torch.nonzero(stamp[lo:hi] == step).flatten() + lo
-    counts, got = publish_rows([small_g], own, n_total)
+def publish_small(small_g, stamp, step, n_total, pl=None):
+    """F (first-touch policy): the rows of this rank's range anybody touched (all stamped `step` by now: by this
+    rank's backward kernels or by border_grads_home) are published with their summed packed small-gradient row, the
+    receivers store and stamp them, so the replicated small-attribute Adam consumes identical sums everywhere.
+    With the batch's BorderPlan the row list and every rank's count are at hand: no scan, no host read."""
+    if pl is not None:
+        counts, got = publish_rows([small_g], pl.own_rows, n_total, counts=pl.own_counts)
+    else:
+        lo, hi = owner_range(n_total)
+        own = torch.nonzero(stamp[lo:hi] == step).flatten() + lo
+        counts, got = publish_rows([small_g], own, n_total)
     for ids in got:
         utils.fill_rows(stamp, ids, step)
     return counts

@@ -312,7 +312,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         with _lib.host_region("dp_border_plan"):
             border = dp.border_plan(touched_rows.long(), N)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
-        own_rows = dp.border_own_rows(border)
+        own_rows = border.own_rows
         if own_rows.numel():
             gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
         dp.border_params_out(params.data, border)
@@ -491,8 +491,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # also tells every rank the global visibility set SelectiveAdam steps
             small_grads = [gaussians._xyz.grad, gaussians._opacity.grad, gaussians._scaling.grad, gaussians._rotation.grad]
             dp.border_grads_home([grad_buf] + small_grads, None, 0, border)
-            own_rows = dp.border_own_rows(border)
-            _, got = dp.publish_rows(small_grads, own_rows, N)
+            own_rows = border.own_rows
+            _, got = dp.publish_rows(small_grads, own_rows, N, counts=border.own_counts)
             touched = torch.zeros((N,), dtype=torch.bool, device=params.device)
             for ids in [own_rows] + got:
                 if ids.numel():
@@ -502,7 +502,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
             # their owners; the owners publish the summed small-attribute gradients of their touched rows
             dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
-            dp.publish_small(small_gk, ft_stamp, step, N)
+            dp.publish_small(small_gk, ft_stamp, step, N, border)
         elif owner is not None:
             # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
             # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);

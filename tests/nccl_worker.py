@@ -84,7 +84,7 @@ def big_index_mode():
     from clm_gs_amd import utils
     utils.fill_rows(stamp, idx, 9)
     dp.border_grads_home([a12, a4], stamp, 9, bp)
-    counts = dp.publish_small(a12, stamp, 9, n)
+    counts = dp.publish_small(a12, stamp, 9, n, bp)
     own = dp.border_own_rows(bp)
     res["locality_exchange"] = bool(torch.equal(a12, t12) and torch.equal(a4, t4) and counts == [idx.numel()]
                                     and torch.equal(own, idx) and int((stamp == 9).sum()) == idx.numel())
@@ -146,7 +146,7 @@ def main():
     stamp[idx] = 5
     g48, g12 = t48.clone(), t12.clone()
     dp.border_grads_home([g48, g12], stamp, 5, bp)
-    counts = dp.publish_small(g12, stamp, 5, n)
+    counts = dp.publish_small(g12, stamp, 5, n, bp)
     res["locality_exchange"] = bool(torch.equal(p48, t48) and torch.equal(g48, t48) and torch.equal(g12, t12)
                                     and bp.border.numel() == 0 and counts == [idx.numel()]
                                     and torch.equal(dp.border_own_rows(bp), idx))

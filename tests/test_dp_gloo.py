@@ -162,7 +162,7 @@ def _locality_worker(rank, world, port, out):
     dense_sh[T], dense_small[T] = my_sh, my_small
     dp.border_grads_home([g_sh, g_small], stamp, step, pl)
     own_touched = dp.border_own_rows(pl)
-    dp.publish_small(g_small, stamp, step, N)
+    dp.publish_small(g_small, stamp, step, N, pl)
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(dense_sh=dense_sh, dense_small=dense_small, T=T))
     want_sh = sum(x["dense_sh"] for x in gathered)
