@@ -26,6 +26,39 @@ import torch.distributed as dist
 from . import utils
 
 
+def _take_into(out, table, idx):
+    """out[:] = table[idx] without a temporary when the fast path applies (out: contiguous [len(idx), cols] view)."""
+    if table.is_cuda and table.dtype == torch.float32 and table.dim() == 2 and table.shape[1] % 4 == 0 \
+            and table.is_contiguous() and out.is_contiguous() and idx.numel():
+        from .clm_kernels import _rows
+        _rows("clmgs_rows_gather", out, table, None, idx.contiguous(), 0)
+    elif idx.numel():
+        out.copy_(utils.take_rows(table, idx))
+
+
+def _take(table, idx):
+    """table[idx] for the exchanges' pack steps: the library's own row mover (64-bit row arithmetic, one pass at HBM
+    speed; clmgs_rows_gather) for fp32 device tables with 16-byte rows, the chunked torch form otherwise (CPU tensors
+    of the gloo tests, stamps, odd widths)."""
+    if table.is_cuda and table.dtype == torch.float32 and table.dim() == 2 and table.shape[1] % 4 == 0 \
+            and table.is_contiguous() and idx.numel():
+        from .clm_kernels import _rows
+        out = table.new_empty((idx.numel(), table.shape[1]))
+        _rows("clmgs_rows_gather", out, table, None, idx.contiguous(), 0)
+        return out
+    return utils.take_rows(table, idx)
+
+
+def _put(table, idx, src):
+    """table[idx] = src (unique ids), the unpack twin of _take."""
+    if table.is_cuda and table.dtype == torch.float32 and table.dim() == 2 and table.shape[1] % 4 == 0 \
+            and table.is_contiguous() and src.dtype == torch.float32 and idx.numel():
+        from .clm_kernels import _rows
+        _rows("clmgs_rows_gather", table, src.contiguous(), idx.contiguous(), None, 0)
+        return
+    utils.put_rows(table, idx, src)
+
+
 WIRE = {}  # exchange kind -> bytes this rank has sent since reset_wire()
 
 
@@ -309,12 +342,12 @@ def border_own_rows(pl):
 def border_params_out(table, pl):
     """B: table[border] <- the owners' rows."""
     W = table.shape[1]
-    send = utils.take_rows(table, pl.serve_rows) if pl.serve_rows.numel() else table.new_empty((0, W))
+    send = _take(table, pl.serve_rows) if pl.serve_rows.numel() else table.new_empty((0, W))
     recv = table.new_empty((pl.border.numel(), W))
     dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=pl.need, input_split_sizes=pl.serve)
     _count("all_to_all_params", send.numel() * send.element_size())
     if pl.border.numel():
-        utils.put_rows(table, pl.border, recv)
+        _put(table, pl.border, recv)
 
 
 def border_grads_home(tables, stamp, step, pl):
@@ -326,7 +359,7 @@ def border_grads_home(tables, stamp, step, pl):
     Wt = sum(widths)
     t0 = tables[0]
     if pl.border.numel():
-        send = torch.cat([utils.take_rows(t, pl.border) for t in tables], dim=1)
+        send = torch.cat([_take(t, pl.border) for t in tables], dim=1)
     else:
         send = t0.new_empty((0, Wt))
     recv = t0.new_empty((pl.serve_rows.numel(), Wt))
@@ -341,12 +374,12 @@ def border_grads_home(tables, stamp, step, pl):
         c = 0
         if stamp is None:
             for t, w in zip(tables, widths):
-                utils.put_rows(t, ids, utils.take_rows(t, ids) + seg[:, c:c + w])
+                _put(t, ids, _take(t, ids) + seg[:, c:c + w])
                 c += w
         else:
             fresh = (utils.take_rows(stamp, ids) != step)[:, None]  # no gradient at the owner yet this step: store
             for t, w in zip(tables, widths):
-                utils.put_rows(t, ids, torch.where(fresh, seg[:, c:c + w], utils.take_rows(t, ids) + seg[:, c:c + w]))
+                _put(t, ids, torch.where(fresh, seg[:, c:c + w], _take(t, ids) + seg[:, c:c + w]))
                 c += w
             utils.fill_rows(stamp, ids, step)
         off += k
@@ -372,26 +405,36 @@ def publish_rows(tables, own_rows, n_total, counts=None):
         counts = counts.tolist()  # host read
         _count("all_gather_small", 8 * (G - 1))
     chunk = max(1, max(counts))
-    send = t0.new_empty((chunk, W + 1))  # rows beyond this rank's count are padding nobody reads
+    # one message per rank: [chunk, W] summed rows, then chunk row ids (int32, relative to the owner's range, carried
+    # as raw bits in a float lane) -- two contiguous blocks, so the pack is one gather per table and one copy
+    send = t0.new_empty((chunk * (W + 1),))
+    rows_blk, ids_blk = send[:chunk * W].view(chunk, W), send[chunk * W:]
     n_own = own_rows.numel()
     if n_own:
-        c = 0
-        for t, w in zip(tables, widths):
-            send[:n_own, c:c + w] = utils.take_rows(t.reshape(t.shape[0], -1), own_rows)
-            c += w
-        send[:n_own, W] = (own_rows - lo).to(torch.int32).view(torch.float32)  # the id rides along as raw bits
-    recv = t0.new_empty((G * chunk, W + 1))
+        if len(tables) == 1 and tables[0].dim() == 2:
+            _take_into(rows_blk[:n_own], tables[0], own_rows)
+        else:
+            c = 0
+            for t, w in zip(tables, widths):
+                rows_blk[:n_own, c:c + w] = utils.take_rows(t.reshape(t.shape[0], -1), own_rows)
+                c += w
+        ids_blk[:n_own] = (own_rows - lo).to(torch.int32).view(torch.float32)
+    recv = t0.new_empty((G * chunk * (W + 1),))
     dist.all_gather_into_tensor(recv, send)
     _count("all_gather_small", send.numel() * send.element_size() * (G - 1))
     got = []
     for q in range(G):
         if q == r or not counts[q]:
             continue
-        seg = recv[q * chunk:q * chunk + counts[q]]
-        ids = seg[:, W].contiguous().view(torch.int32).to(torch.int64) + owner_range(n_total, q, G)[0]
+        blk = recv[q * chunk * (W + 1):(q + 1) * chunk * (W + 1)]
+        seg = blk[:chunk * W].view(chunk, W)[:counts[q]]
+        ids = blk[chunk * W:chunk * W + counts[q]].contiguous().view(torch.int32).to(torch.int64) + owner_range(n_total, q, G)[0]
         c = 0
         for t, w in zip(tables, widths):
-            utils.put_rows(t.reshape(t.shape[0], -1), ids, seg[:, c:c + w])
+            if len(tables) == 1 and t.dim() == 2:
+                _put(t, ids, seg)
+            else:
+                utils.put_rows(t.reshape(t.shape[0], -1), ids, seg[:, c:c + w])
             c += w
         got.append(ids)
     return counts, got
