@@ -147,18 +147,18 @@ def allreduce_rows(grad_rows, touched_global, average=True, rows=None):
             grad_rows /= ws
         return
     rows = rows.long()
-    buf = utils.take_rows(grad_rows, rows)
+    buf = _take(grad_rows, rows)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     _count("all_reduce", _allreduce_bytes(buf.numel() * buf.element_size()))
     if average:
         buf /= ws
-    utils.put_rows(grad_rows, rows, buf)
+    _put(grad_rows, rows, buf)
 
 
 def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85):
     """Sum (average) several row tables [N, d_i] over ranks, moving ONLY `rows` (the globally
-    touched set, identical on every rank): the rows of all tables are packed side by side into one
-    [n, sum d_i] message -> ONE collective per batch (236+ B per touched Gaussian) -> unpacked.
+    touched set, identical on every rank): the rows of every table are packed into a contiguous message
+    (236+ B per touched Gaussian in all), the collectives issued back to back, then unpacked.
     xGMI all-reduce bandwidth is ~20x below HBM bandwidth, so packing pays until almost every row
     is touched (pack + unpack cost 2 HBM passes; break-even at ~89 % touched): above `dense_above`
     the tables are reduced in place instead."""
@@ -178,14 +178,17 @@ def allreduce_tables_rows(tables, rows, n_total, average=False, dense_above=0.85
                 t /= ws
         return
     rows = rows.long()
-    widths = [t.shape[1] for t in tables]
-    buf = torch.cat([utils.take_rows(t, rows) for t in tables], dim=1)  # chunked: see utils.gather_rows
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    _count("all_reduce", _allreduce_bytes(buf.numel() * buf.element_size()))
-    if average:
-        buf /= ws
-    for t, piece in zip(tables, torch.split(buf, widths, dim=1)):
-        utils.put_rows(t, rows, piece)
+    # one packed message per table (contiguous rows: packed and unpacked by the library's row mover in one pass each),
+    # the collectives issued back to back
+    bufs = [_take(t, rows) for t in tables]
+    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in bufs]
+    for w in works:
+        w.wait()
+    _count("all_reduce", sum(_allreduce_bytes(b.numel() * b.element_size()) for b in bufs))
+    for t, b in zip(tables, bufs):
+        if average:
+            b /= ws
+        _put(t, rows, b)
 
 
 # ------------------------------------------------------------------ owner-computes exchange
@@ -233,11 +236,11 @@ def owner_gather_rows(table, pl):
     W = table.shape[1]
     send = torch.zeros((pl.chunk, W), dtype=table.dtype, device=table.device)
     if pl.hi > pl.lo:
-        send[: pl.hi - pl.lo] = utils.take_rows(table, pl.rows[pl.lo:pl.hi])
+        _take_into(send[: pl.hi - pl.lo], table, pl.rows[pl.lo:pl.hi])
     recv = torch.empty((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
     dist.all_gather_into_tensor(recv, send)
     _count("all_gather", send.numel() * send.element_size() * (pl.n_ranks - 1))
-    utils.put_rows(table, pl.rows, utils.take_rows(recv, pl.pos))
+    _put(table, pl.rows, _take(recv, pl.pos))
 
 
 def owner_reduce_rows(table, pl):
@@ -247,13 +250,13 @@ def owner_reduce_rows(table, pl):
         return
     W = table.shape[1]
     buf = torch.zeros((pl.n_ranks * pl.chunk, W), dtype=table.dtype, device=table.device)
-    utils.put_rows(buf, pl.pos, utils.take_rows(table, pl.rows))
+    _put(buf, pl.pos, _take(table, pl.rows))
     mine = torch.empty((pl.chunk, W), dtype=table.dtype, device=table.device)
     dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
     _count("reduce_scatter", mine.numel() * mine.element_size() * (pl.n_ranks - 1))
     utils.fill_rows(table, pl.rows, 0.0)
     if pl.hi > pl.lo:
-        utils.put_rows(table, pl.rows[pl.lo:pl.hi], mine[: pl.hi - pl.lo])
+        _put(table, pl.rows[pl.lo:pl.hi], mine[: pl.hi - pl.lo])
 
 
 def owner_gather_dense(tables, n_total):
