@@ -114,20 +114,27 @@ def test_dp_is_noop_without_process_group():
     assert dp.allreduce_touched(t) is t
 
 
-def _locality_worker(rank, world, port, out):
+def _locality_worker(rank, world, port, out, mode="mixed"):
     """The four locality collectives against plain dense arithmetic: every rank 'renders' a touched set
-    concentrated in its own range plus a spill-over into the other ranks' ranges."""
+    concentrated in its own range plus a spill-over into the other ranks' ranges.  Edge shapes (`mode`):
+    "idle" = rank 0's cameras see nothing at all; "foreign" = the last rank sees ONLY other ranks' rows;
+    "disjoint" = nobody leaves its own range (no border row anywhere)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from clm_gs_amd import dp
-    N, step = 3000, 7
+    N, step = 3001, 7                                                                    # not a multiple of any world size used
     dp.reset_wire()
     lo, hi = dp.owner_range(N)
     g = torch.Generator().manual_seed(50 + rank)
     pick = torch.zeros(N, dtype=torch.bool)
     pick[lo + torch.randperm(hi - lo, generator=g)[: (hi - lo) // 2]] = True          # half of my own range
-    pick[torch.randperm(N, generator=g)[:200]] = True                                    # spill-over anywhere
+    if mode != "disjoint":
+        pick[torch.randperm(N, generator=g)[:200]] = True                                # spill-over anywhere
+    if mode == "idle" and rank == 0:
+        pick[:] = False
+    if mode == "foreign" and rank == world - 1:
+        pick[lo:hi] = False
     T = torch.nonzero(pick).flatten()
     pl = dp.border_plan(T, N)
     fails = []
@@ -193,6 +200,8 @@ def _locality_worker(rank, world, port, out):
         fails.append(13)
     if not (acct["locality"][rank] < acct["allreduce"][rank]):
         fails.append(14)
+    if mode == "disjoint" and not (pl.border.numel() == 0 and pl.serve_rows.numel() == 0):
+        fails.append(15)
     res = [None] * world
     dist.all_gather_object(res, list(fails))
     if rank == 0:
@@ -201,11 +210,11 @@ def _locality_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _run_world(target, world):
+def _run_world(target, world, *extra):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, out) + extra) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -220,6 +229,13 @@ def test_dp_locality_exchange_world2_gloo():
 
 def test_dp_locality_exchange_world3_gloo():
     _run_world(_locality_worker, 3)
+
+
+def test_dp_locality_exchange_edge_shapes_gloo():
+    """A rank whose cameras see nothing, a rank that sees only foreign rows, and a batch without any border row."""
+    _run_world(_locality_worker, 2, "idle")
+    _run_world(_locality_worker, 3, "foreign")
+    _run_world(_locality_worker, 4, "disjoint")
 
 
 def test_assign_cameras_by_locality_is_balanced_and_local():
