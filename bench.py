@@ -111,6 +111,10 @@ def parse():
                          "batch's images uploaded on a side stream one batch ahead (the reference: train.py:310-312); both "
                          "(default): `value` with resident images, then the same K steps again with streamed images as "
                          "`value_gt_streamed`")
+    ap.add_argument("--gt-layout", default="chw", choices=["chw", "hwc"],
+                    help="memory layout of the synthetic ground-truth images: chw = planar contiguous [3,H,W] as the "
+                         "reference's Camera holds them (default); hwc = the strided view rounds 1-3 used by accident "
+                         "(kept for A/B: costs a transposing copy per camera)")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
                     help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality (Z-ordered rows required)")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
@@ -131,7 +135,12 @@ def make_gt_images(cams, scene, args_ns, width, height):
     gt_model.active_sh_degree = 3
     for c in cams:
         img = clm_offload_eval_one_cam(c, gt_model, None, None)
+        # [3,H,W] planar CONTIGUOUS like the reference's Camera holds it (scene/cameras.py:74); the renderer's
+        # image is an [H,W,3] buffer viewed as [3,H,W], and until round 3 the quantised copy inherited those
+        # strides: every timed camera then paid a transposing u8 copy (47.8 MB, 0.04-1.6 ms) in the loss stage
         c.original_image = (img.clamp(0, 1) * 255.0).round().to(torch.uint8)
+        if getattr(args_ns, "gt_layout", "chw") == "chw":
+            c.original_image = c.original_image.contiguous()
     del gt_model
     torch.cuda.empty_cache()
 
@@ -475,6 +484,7 @@ def main():
                      "cameras_per_rank": len(cams)}
     else:
         cams = all_cams[rank::world]
+    args.gt_layout = a.gt_layout
     make_gt_images(cams, scene, args, W, H)
     gt_mode = {"v": "host" if (a.gt == "host" or (a.strategy == "clm_offload" and a.residency == "host")) else "resident"}
     if gt_mode["v"] == "host":

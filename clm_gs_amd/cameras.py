@@ -17,7 +17,9 @@ class Camera:
         self.image_name = image_name or f"cam_{uid:05d}"
         w2c = torch.as_tensor(world_to_cam, dtype=torch.float32)
         self.world_view_transform = w2c.t().contiguous().to(device)
-        self.original_image = image_u8.to(device) if image_u8 is not None else None
+        # planar and contiguous, as the reference keeps it (scene/cameras.py:74 "image.contiguous()"): the loss
+        # kernels read it in place; a strided image would cost fused.camera_forward_finish a copy per camera
+        self.original_image = image_u8.to(device).contiguous() if image_u8 is not None else None
         self.K = self.create_k_on_gpu(device)
         c2w = torch.inverse(w2c)
         self.camtoworlds = c2w[None].to(device)  # [1,4,4] as train.py:293-301
