@@ -75,3 +75,36 @@ def test_row_permutation_helpers():
     step_sorted = (p[1:] - p[:-1]).norm(dim=1).median()
     step_random = (xyz[1:, :2] - xyz[:-1, :2]).norm(dim=1).median()
     assert step_sorted < 0.1 * step_random  # consecutive rows are spatial neighbours
+
+
+def test_intersection_capacity_hysteresis():
+    """fused._capacity_for: the capacity the per-camera intersection lists are built for (device-count forms).
+    None until a count has been seen; at least margin x the largest recent count; unchanged while the count drifts by a
+    few per cent (no reallocation, no hipMalloc); regrown before the count can reach it; shrunk once the scene has
+    become much sparser; off with device_side_counts=False."""
+    from types import SimpleNamespace
+    from clm_gs_amd import fused
+    key = ("test", 1)
+    fused._CAPACITY.pop(key, None)
+    fused._CAP_HELD.pop(key, None)
+    a = SimpleNamespace(device_side_counts=True, isect_capacity_margin=1.25, isect_capacity_floor=4096)
+    assert fused._capacity_for(key, a) is None
+    fused._observe_count(key, 1_000_000)
+    cap0 = fused._capacity_for(key, a)
+    assert cap0 >= 1_250_000 + 4096 and cap0 <= 1.13 * (1_250_000 + 4096)
+    changes, cap, n = 0, cap0, 1_000_000
+    for _ in range(200):                       # +0.1 % per camera: 22 % in all
+        n = int(n * 1.001)
+        fused._observe_count(key, n)
+        c = fused._capacity_for(key, a)
+        assert c >= int(n * 1.10)              # always room for the next camera's growth
+        changes += c != cap
+        cap = c
+    assert changes <= 2                        # not one reallocation per 1/8-octave bucket
+    for _ in range(400):                       # the scene thins out (pruning): the decaying maximum follows, 2 % per camera
+        fused._observe_count(key, 100_000)
+    small = fused._capacity_for(key, a)
+    assert small < cap / 4 and small >= 125_000
+    assert fused._capacity_for(key, SimpleNamespace(device_side_counts=False)) is None
+    fused._CAPACITY.pop(key, None)
+    fused._CAP_HELD.pop(key, None)
