@@ -22,18 +22,61 @@ import os
 import sys
 import time
 
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _requested_gpus(argv):
+    """--gpus N from the command line, before argparse (and before torch is imported)."""
+    for i, tok in enumerate(argv):
+        if tok == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if tok.startswith("--gpus="):
+            return int(tok.split("=", 1)[1])
+    return 1
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment (the driver's plain
+    command form): this process becomes the launcher -- it re-executes itself as N ranks, one per GPU, under
+    torch.distributed.run (127.0.0.1 rendezvous on a free port), exactly the command the contract gives for
+    N > 1; rank 0 prints the ONE JSON line on the inherited stdout.  Fewer than N visible devices is an error
+    (CLMGS_SHARE_GPU=1, the test hook for several ranks on one device, lifts it)."""
+    n = _requested_gpus(sys.argv[1:])
+    if n <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import torch  # device count only: no context is created, and this process is replaced below
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("CLMGS_SHARE_GPU") != "1":
+        sys.stderr.write(f"bench: --gpus {n} but only {have} GPU(s) are visible to this process "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n")
+        sys.exit(2)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what the host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+_self_launch()
+
 # Two hardware queues for the process's HIP streams (the runtime's default is 4): the camera pipeline's three streams
 # by kernel type then share two queues.  Measured interleaved, three rounds in one call (28 M, GT resident): 1 queue
 # 147.2 / 146.9 / 148.2, 2 queues 155.8 / 157.9 / 157.0, 3: 153.0 / 155.4 / 155.7, 4: 154.5 / 154.5 / 155.6, default
 # 153.6 / 154.0 / 155.5 img/s.  Single-GPU runs only (RCCL's own streams want their queues); an exported value wins.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# The same default is applied by the product's own entry points (clm_gs_amd.utils.single_gpu_runtime_defaults, called
+# by `python -m clm_gs_amd.trainer` before HIP initialises), so a trainer run and a bench run share the configuration.
+from clm_gs_amd.runtime_env import single_gpu_runtime_defaults  # noqa: E402  (no torch import inside)
+single_gpu_runtime_defaults()
 
-import torch
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+import torch  # noqa: E402
 
 CONFIGS = {
     # name: (N gaussians, W, H, bsz, visible fraction per camera, description)
@@ -430,7 +473,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
+    if world != a.gpus:
+        sys.stderr.write(f"bench: --gpus {a.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {a.gpus} "
+                         f"(or plain `python bench.py --gpus {a.gpus}`, which starts its own ranks)\n")
+        sys.exit(2)
+    if world > 1 and os.environ.get("CLMGS_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
+        sys.stderr.write(f"bench: {world} ranks but {torch.cuda.device_count()} visible GPU(s)\n")
+        sys.exit(2)
 
     from clm_gs_amd import _lib, utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians

@@ -8,3 +8,7 @@ without the built library raises.
 """
 
 __version__ = "0.1.0"
+
+from .runtime_env import single_gpu_runtime_defaults as _defaults
+
+_defaults()  # hardware-queue default for single-GPU processes (runtime_env.py); a no-op once HIP has initialised

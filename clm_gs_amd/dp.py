@@ -363,6 +363,13 @@ def border_grads_home(tables, stamp, step, pl):
     t0 = tables[0]
     if pl.border.numel():
         send = torch.cat([_take(t, pl.border) for t in tables], dim=1)
+        if stamp is not None:
+            # The plan lists every border row of the FILTERS; the backward stores (and stamps) only rows that were drawn
+            # (radius > 0).  A filtered row the exact projection did not draw (fast-accept vs exact tie, a camera redone
+            # over capacity) keeps the gradient lines of an EARLIER step under first-touch stores: it travels as zeros,
+            # never as that stale content (the owner then adds / stores nothing for it).
+            live = (utils.take_rows(stamp, pl.border) == step)[:, None]
+            send = torch.where(live, send, torch.zeros((), dtype=send.dtype, device=send.device))
     else:
         send = t0.new_empty((0, Wt))
     recv = t0.new_empty((pl.serve_rows.numel(), Wt))
@@ -391,10 +398,11 @@ def border_grads_home(tables, stamp, step, pl):
             utils.fill_rows(t, pl.border, 0.0)
 
 
-def publish_rows(tables, own_rows, n_total, counts=None):
+def publish_rows(tables, own_rows, n_total, counts=None, live=None):
     """F, general form: every owner all-gathers (row id, its summed rows of `tables`, side by side) for `own_rows`
     (ascending absolute ids inside its range); the receivers store the rows.  `counts`: len(own_rows) of every rank
     if the caller exchanged them already (border_plan does) -- no host read here then.
+    `live` (bool per own row, optional): rows whose line is not of this step are sent as zeros (sizes stay the plan's).
     -> (counts per rank, list of the absolute id tensors received from every other rank)."""
     G, r = world_size(), rank()
     lo, _ = owner_range(n_total, r, G)
@@ -421,6 +429,8 @@ def publish_rows(tables, own_rows, n_total, counts=None):
             for t, w in zip(tables, widths):
                 rows_blk[:n_own, c:c + w] = utils.take_rows(t.reshape(t.shape[0], -1), own_rows)
                 c += w
+        if live is not None:  # bool[n_own]: rows whose line does not belong to this step travel as zeros
+            rows_blk[:n_own].masked_fill_(~live[:, None], 0.0)
         ids_blk[:n_own] = (own_rows - lo).to(torch.int32).view(torch.float32)
     recv = t0.new_empty((G * chunk * (W + 1),))
     dist.all_gather_into_tensor(recv, send)
@@ -449,7 +459,12 @@ def publish_small(small_g, stamp, step, n_total, pl=None):
     receivers store and stamp them, so the replicated small-attribute Adam consumes identical sums everywhere.
     With the batch's BorderPlan the row list and every rank's count are at hand: no scan, no host read."""
     if pl is not None:
-        counts, got = publish_rows([small_g], pl.own_rows, n_total, counts=pl.own_counts)
+        # own rows no camera drew after all (see border_grads_home) hold an earlier step's line: published as zeros
+        # -- the sizes of the exchange stay the plan's (known before rendering, no readback), its CONTENT follows the
+        # stamps; a zero line stamped `step` is what the replicated small-attribute Adam reads for an unstamped row
+        own = pl.own_rows
+        live = (utils.take_rows(stamp, own) == step) if own.numel() else None
+        counts, got = publish_rows([small_g], own, n_total, counts=pl.own_counts, live=live)
     else:
         lo, hi = owner_range(n_total)
         own = torch.nonzero(stamp[lo:hi] == step).flatten() + lo
@@ -469,8 +484,8 @@ def camera_shares(filters, n_total, n_ranks):
 
 def assign_cameras(shares, per_rank=None):
     """Deal cameras to ranks by locality: camera c prefers the rank owning most of its rows (shares[c, q]);
-    every rank gets the same number of cameras (`per_rank`, default len / ranks): cameras are taken in order
-    of how much they lose by not getting their first choice, each goes to its best rank with room left.
+    every rank gets at most `per_rank` (default ceil(len / ranks)) and at least floor(len / ranks) cameras: cameras are
+    taken in order of how much they lose by not getting their first choice, each goes to its best rank with room left.
     -> list of rank per camera (deterministic: every rank computes the same deal)."""
     shares = torch.as_tensor(shares).to(torch.float64)
     n, G = shares.shape
@@ -479,14 +494,22 @@ def assign_cameras(shares, per_rank=None):
     regret = (top2[:, 0] - (top2[:, 1] if G > 1 else 0)).tolist()
     order = sorted(range(n), key=lambda c: (-regret[c], c))
     room = [cap] * G
+    # every rank is guaranteed floor(n / G) cameras (a cap alone lets the last ranks run short or empty: 30 cameras over
+    # 8 ranks dealt 4,4,4,4,4,4,4,2): while the cameras left only just cover the outstanding minimums, a camera may
+    # only go to a rank that is still below its minimum
+    owed = [min(cap, n // G)] * G
     out = [0] * n
     pref = torch.argsort(shares, dim=1, descending=True, stable=True).tolist()
+    left = n
     for c in order:
+        must = left <= sum(owed)
         for q in pref[c]:
-            if room[q] > 0:
+            if room[q] > 0 and (not must or owed[q] > 0):
                 out[c] = q
                 room[q] -= 1
+                owed[q] = max(0, owed[q] - 1)
                 break
+        left -= 1
     return out
 
 

@@ -60,8 +60,18 @@ def _sptr(torch_stream):
 # on the device, and the host checks the count later (camera_verify, when it enqueues the camera's backward --
 # by then the asynchronous readback has long arrived), redoing the camera exactly if the capacity was exceeded.
 # Predictor: decaying maximum of the counts seen at this image size, x `isect_capacity_margin`.
-_CAPACITY = {}   # image size -> decaying maximum of the counts seen
-_CAP_HELD = {}   # image size -> the capacity the buffers are currently built for
+_CAPACITY = {}   # (image size, model) -> decaying maximum of the counts seen
+_CAP_HELD = {}   # (image size, model) -> the capacity the buffers are currently built for
+_CAP_IDS = __import__("itertools").count(1)
+
+
+def _cap_key(gaussians, W, H):
+    """Predictions are per MODEL and image size: a second scene in the same process (a ground-truth renderer, a
+    sub-scene of a test) must not inherit the first one's intersection counts."""
+    k = getattr(gaussians, "_clmgs_cap_id", None)
+    if k is None:
+        k = gaussians._clmgs_cap_id = next(_CAP_IDS)
+    return (int(W), int(H), k)
 
 
 def _observe_count(key, n):
@@ -89,16 +99,20 @@ def _capacity_for(key, args):
 
 
 def camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
-                   lambda_dssim=0.2, small_packed=None, streams=None, sh_index=None):
+                   lambda_dssim=0.2, small_packed=None, streams=None, sh_index=None, exact=True):
     """Projection + binning (stream `front`), alpha-blend forward (stream `raster`), loss forward +
     backward (stream `mem`) of one camera; returns the _CameraPass for camera_backward.  The three
     streams may be one and the same; distinct streams are chained by events, so the caller can put
     all cameras' tile kernels on one low-priority stream and order them RF0 RF1 RB0 RF2 RB1 ...
     (software pipelining over the cameras of a batch: the tile stream never waits for a loss).
-    = camera_front (nothing blocks) + camera_forward_finish (waits for the intersection count)."""
+    = camera_front (nothing blocks) + camera_forward_finish.
+    exact=True (default: forward-only callers -- evaluation-style use, parity checks -- get a COMPLETE image): the host
+    waits for the intersection count and sizes the lists exactly.  exact=False: lists built for the predicted capacity
+    (device-count forms); the render is only valid once camera_verify / camera_backward has checked the count --
+    train_one_camera, which runs the backward right after, passes False."""
     return camera_forward_finish(gaussians, camera_front(
         gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8, lambda_dssim,
-        small_packed, streams, sh_index))
+        small_packed, streams, sh_index), exact=exact)
 
 
 def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
@@ -153,7 +167,11 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
 def camera_forward_finish(gaussians, p, exact=False):
     """Second half of the binning, alpha-blend forward, loss forward + backward.  With a capacity prediction
     for this image size (device-side counts, see above) nothing is waited for; otherwise (first cameras of a
-    run, `exact`, device_side_counts=False) the host waits for the intersection count and sizes exactly."""
+    run, `exact`, device_side_counts=False) the host waits for the intersection count and sizes exactly.
+    OBLIGATION of the caller when a capacity was used (p.n_dev is not None): the image, loss and lists are built
+    from capacity-sized lists whose overflow is DROPPED -- call camera_verify(gaussians, p) (camera_backward does)
+    before consuming or accumulating anything of this camera; it redoes the forward exactly if the count exceeded
+    the capacity."""
     L = _lib.lib()
     args = utils.get_args()
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
@@ -161,14 +179,14 @@ def camera_forward_finish(gaussians, p, exact=False):
     s_front, s_mem, s_raster = p.streams
     V, packed, background, gt_u8, lambda_dssim = p.V, p.packed, p.background, p.gt_u8, p.lambda_dssim
     tw, th = math.ceil(W / float(TILE)), math.ceil(H / float(TILE))
-    cap = None if (exact or V == 0) else _capacity_for((W, H), args)
+    cap = None if (exact or V == 0) else _capacity_for(_cap_key(gaussians, W, H), args)
     with torch.cuda.stream(s_front):
         with _lib.host_region("fwd_isect"):
             p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = isect2_finish(p.isect, capacity=cap)
         if cap is None:
             p.isect, p.n_dev = None, None
             if V:
-                _observe_count((W, H), p.fids.numel())
+                _observe_count(_cap_key(gaussians, W, H), p.fids.numel())
         else:
             p.n_dev = p.isect.totals  # int64[2] on the device: {emitted, reference}; p.isect stays for camera_verify
         p.out = torch.empty((H, W, 3), dtype=F32, device=dev)
@@ -242,7 +260,7 @@ def camera_verify(gaussians, p):
         return
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
     n, n_ref = isect2_counts(c)
-    _observe_count((W, H), n)
+    _observe_count(_cap_key(gaussians, W, H), n)
     if n <= p.fids.numel():
         _record_counts(n, n_ref)
         p.isect = None
@@ -368,7 +386,7 @@ def train_one_camera(gaussians, camera, this_filter, sh_rows, sh_by_filter, g_sh
     cur = torch.cuda.current_stream()
     p = camera_forward(gaussians, camera, this_filter, sh_rows, sh_by_filter, background, gt_u8,
                        lambda_dssim, small_packed, (cur, cur, raster_stream if raster_stream is not None else cur),
-                       sh_index)
+                       sh_index, exact=False)  # verified by camera_backward below
     camera_backward(gaussians, p, g_sh_rows, small_grad, update_stats, stats_delta,
                     stats_only_visible, visibility_out, accumulate_after, sh_stamp, cur_step)
     loss = camera_loss(p)  # on `cur`, which the loss kernels ran on

@@ -590,6 +590,11 @@ def _host_buffers(gaussians, T, dev):
         cap = bucket_size(max(int(T * 1.06), 1))  # staged-but-unused rows of a hinted batch ride along: a few percent
         gen = hb["gen"] + 1 if hb else 0
         if hb is not None:
+            # The staging tables are written by hipMemcpyAsync issued through ctypes on the side streams (speculative
+            # prefetch, feeder): the caching allocator knows nothing of that use, and a dropped speculation is only
+            # JOINED (its last copy may still be in flight).  Growing the tables is rare (bucketed capacity): drain the
+            # device before the old blocks go back to the allocator, so no late copy can land in a recycled block.
+            torch.cuda.synchronize()
             hb.clear()  # the old tables go back to the allocator BEFORE the new ones are requested
         gaussians._host_bufs = None
         hb = gaussians._host_bufs = dict(

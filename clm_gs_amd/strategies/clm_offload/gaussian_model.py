@@ -271,6 +271,9 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if sp is None:
             return
         sp["thread"].join()
+        ev = sp.get("event")
+        if ev is not None:
+            ev.synchronize()  # the thread's last hipMemcpyAsync into the second staging table has landed
         if sp["n"]:
             self._host_g_step[sp["rows_h"][:sp["n"]].long()] = 0
 

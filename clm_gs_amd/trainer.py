@@ -140,8 +140,18 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     def deal():
         nonlocal pool, dealt_at, order
         ranks_of, _ = dp.deal_cameras(train_cameras, gaussians, ws)
-        pool = [i for i, q in enumerate(ranks_of) if q == rk]
         dealt_at, order = gaussians.get_xyz.shape[0], []
+        # every rank computes the same deal, so every rank sees the same smallest pool -- no collective needed to agree.
+        # A rank with fewer than bsz cameras could not draw a batch while the others are already inside the batch's
+        # collectives (hang): then ALL ranks fall back to the strided deal of the global shuffled order (the locality
+        # exchange is correct for any camera assignment, it just moves more border rows).
+        smallest = min(sum(1 for q in ranks_of if q == r_) for r_ in range(ws))
+        if smallest < bsz:
+            pool = None
+            log_file.write("camera-DP locality deal: smallest pool {} < bsz {} ({} cameras / {} ranks): strided deal\n".format(
+                smallest, bsz, len(train_cameras), ws))
+        else:
+            pool = [i for i, q in enumerate(ranks_of) if q == rk]
     if locality:
         assert spatial, "dp_locality needs the Z-ordered row tables (spatial_row_order)"
         deal()
@@ -155,7 +165,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             gaussians.oneupSHdegree()
         def draw():
             nonlocal order
-            if locality:
+            if locality and pool is not None:
                 if len(order) < bsz:  # new epoch of THIS rank's pool
                     order = list(pool)
                     rng.shuffle(order)
@@ -272,6 +282,8 @@ def train_from_colmap(source_path, model_path, strategy="clm_offload", iteration
 
 
 if __name__ == "__main__":  # python -m clm_gs_amd.trainer -s <colmap dir> -m <output dir> [--clm_offload] ...
+    # (clm_gs_amd/__init__.py has applied runtime_env.single_gpu_runtime_defaults() before torch was imported: the
+    # hardware-queue default bench.py runs with is the trainer's too)
     import argparse
     ap = argparse.ArgumentParser(description="train a 3DGS model from a COLMAP directory (flag names of train.py)")
     ap.add_argument("-s", "--source_path", required=True)

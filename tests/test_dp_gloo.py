@@ -167,6 +167,12 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     g_sh[T], g_small[T], stamp[T] = my_sh, my_small, step
     dense_sh, dense_small = torch.zeros(N, 48), torch.zeros(N, 12)           # what an all-reduce would sum
     dense_sh[T], dense_small[T] = my_sh, my_small
+    if mode == "undrawn":
+        # filter rows the backward did not draw (radius 0 at render time): they are in the plan, but their lines are
+        # an earlier step's (stale 9.0, old stamp) and must not reach anybody's sum
+        dead = T[::7]
+        g_sh[dead], g_small[dead], stamp[dead] = 9.0, 9.0, 3
+        dense_sh[dead], dense_small[dead] = 0.0, 0.0
     dp.border_grads_home([g_sh, g_small], stamp, step, pl)
     own_touched = dp.border_own_rows(pl)
     dp.publish_small(g_small, stamp, step, N, pl)
@@ -180,14 +186,16 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     own_U = torch.nonzero(U[lo:hi]).flatten() + lo
     if not (torch.equal(own_touched, own_U)):
         fails.append(6)
-    if not (torch.allclose(g_sh[own_U], want_sh[own_U], atol=1e-6)):  # owners hold the summed SH gradient rows
+    # what the optimizers consume: a row's line counts only under this step's stamp (first-touch policy)
+    eff = lambda tab, rows_: torch.where((stamp[rows_] == step)[:, None], tab[rows_], torch.zeros(()))
+    if not (torch.allclose(eff(g_sh, own_U), want_sh[own_U], atol=1e-6)):  # owners hold the summed SH gradient rows
         fails.append(7)
-    if not (bool((stamp[own_U] == step).all())):
+    if mode != "undrawn" and not (bool((stamp[own_U] == step).all())):
         fails.append(8)
     rows_U = torch.nonzero(U).flatten()
-    if not (torch.allclose(g_small[rows_U], want_small[rows_U], atol=1e-6)):  # everybody holds the summed small rows
+    if not (torch.allclose(eff(g_small, rows_U), want_small[rows_U], atol=1e-6)):  # everybody holds the summed small rows
         fails.append(9)
-    if not (bool((stamp[rows_U] == step).all())):
+    if mode != "undrawn" and not (bool((stamp[rows_U] == step).all())):
         fails.append(10)
     if not (bool((stamp[~U] == 3).all()) and bool((g_small[~U] == 9.0).all())):  # untouched rows: untouched
         fails.append(11)
@@ -238,6 +246,13 @@ def test_dp_locality_exchange_edge_shapes_gloo():
     _run_world(_locality_worker, 4, "disjoint")
 
 
+def test_dp_locality_exchange_ignores_rows_the_backward_did_not_draw():
+    """a filter row with radius 0 at render time keeps an earlier step's gradient lines under first-touch
+    stores; the exchange takes its SIZES from the plan but its CONTENT from the stamps -- stale lines travel as zeros."""
+    _run_world(_locality_worker, 2, "undrawn")
+    _run_world(_locality_worker, 3, "undrawn")
+
+
 def test_assign_cameras_by_locality_is_balanced_and_local():
     from clm_gs_amd import dp
     # 12 cameras over 4 ranks; camera c sees mostly rank c % 4's range, a few see two ranges equally
@@ -253,3 +268,16 @@ def test_assign_cameras_by_locality_is_balanced_and_local():
     # more first choices than room: the cameras that lose least are the ones moved
     shares = torch.tensor([[100, 0], [90, 80], [95, 10], [5, 50]])
     assert dp.assign_cameras(shares) == [0, 1, 0, 1]
+
+
+def test_assign_cameras_guarantees_a_minimum_per_rank():
+    """a cap of ceil(n / G) alone left the last ranks short (30 cameras / 8 ranks: ..., 2) or empty; every
+    rank now gets between floor(n / G) and ceil(n / G) cameras whatever the preferences."""
+    from clm_gs_amd import dp
+    g = torch.Generator().manual_seed(0)
+    for n, G in ((30, 8), (9, 8), (17, 4), (8, 8), (5, 8)):
+        shares = torch.randint(0, 1000, (n, G), generator=g)
+        shares[:, 0] += 5000  # everybody prefers rank 0
+        deal = dp.assign_cameras(shares)
+        counts = [deal.count(q) for q in range(G)]
+        assert sum(counts) == n and min(counts) >= n // G and max(counts) <= -(-n // G), (n, G, counts)

@@ -145,3 +145,29 @@ def test_bench_two_ranks_one_gpu(dev):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["global_batch"] == 2 * j["config"]["bsz_per_gpu"]
+
+
+def test_bench_plain_python_starts_its_own_ranks(dev):
+    """The driver's command form: `python bench.py --gpus 2` with NO RANK / WORLD_SIZE in the environment must start
+    its own two ranks (bench._self_launch -> torch.distributed.run) and print ONE line with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1")
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                "--config", "small", "--prime-seconds", "0"], env=env)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["dp"]["mode"] == "locality" and j["dp"]["dp_exchange_bytes_per_step"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(dev):
+    """Without the sharing hook, --gpus N on a box with fewer than N devices fails loudly (exit 2), it does not
+    silently run one rank."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CLMGS_SHARE_GPU")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                           "--config", "small"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 2 and "visible" in proc.stderr, (proc.returncode, proc.stderr[-500:])
+    assert not [l for l in proc.stdout.splitlines() if l.startswith("{")]
