@@ -665,6 +665,7 @@ def main():
     t_enq = time.perf_counter() - t0  # host: enqueue work + size readbacks, before the final fence
     fence()
     dt = time.perf_counter() - t0
+    _lib.check_device_errors()  # a look-back scan / sort pass of the binning chain that gave up raises here
     host_wait = _lib.STATS["host_wait_s"]
     n_redo = int(_lib.STATS.get("isect_capacity_redo", 0))
     ms1 = torch.cuda.memory_stats()
@@ -895,6 +896,9 @@ def main():
                      "16-core host; img/s derived there from published training time / iterations)"}
         if ref_img_s else None,
         "roofline": roofline, "kernels": kernels,
+        # the same C-ABI calls with NOTHING co-running (one extra untimed batch on a single stream): what a call costs
+        # by itself, as opposed to its stretched duration next to the other streams' kernels
+        "kernels_solo_ms": {k: round(v, 4) for k, v in sorted(solo.items())} if solo else None,
     }
     if not a.no_cpu_baseline and world == 1:
         try:

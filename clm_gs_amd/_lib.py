@@ -70,6 +70,7 @@ SIGNATURES = {
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_knn3_mean_dist2": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
+    "clmgs_device_errors": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),
     "clmgs_pinned_free": (_i, [_vp]),
 }
@@ -112,7 +113,7 @@ class _Namespace:
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
               "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_usable_cpus", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
-              "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters"}
+              "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters", "clmgs_device_errors"}
 
 
 def timing_summary():
@@ -147,6 +148,16 @@ def check(rc):
     if rc != 0:
         msg = lib().clmgs_last_error()
         raise ClmgsError(f"libclmgs_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def check_device_errors():
+    """Raises if a look-back scan / sort pass of the binning chain timed out since the last check
+    (clmgs_device_errors; synchronises the device).  Called where the host synchronises anyway."""
+    bits = ctypes.c_uint32(0)
+    check(lib().clmgs_device_errors(ctypes.byref(bits), 1))
+    if bits.value:
+        raise ClmgsError(f"binning chain: look-back timed out on the device (bits {bits.value}: 1 = scan, 2 = sort pass); "
+                         "the intersection lists built since the last check are invalid")
 
 
 HOST_REGIONS = None  # set to {} to accumulate host wall time per engine region (diagnostics)

@@ -3,11 +3,56 @@
 // gsplat.isect_offset_encode (strategies/base_engine.py:175-186,
 // strategies/no_offload/engine.py:75-84, strategies/clm_offload/engine.py:89-100).
 // Sorting and scanning are the hand-written kernels of radix.h (no rocPRIM / hipCUB).
+#include <stdlib.h>
+
 #include "common.h"
 #include "gs_math.h"
 #include "radix.h"
+#include "onesweep.h"
 
 namespace clmgs {
+
+// Device error word of the look-back primitives (onesweep.h): bit 0 = scan look-back timed out, bit 1 = sort
+// look-back timed out.  Read (and cleared) by clmgs_device_errors().
+__device__ uint32_t g_dev_err;
+uint32_t* device_error_word() {
+  static thread_local uint32_t* p[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!p[dev]) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_dev_err)) == hipSuccess) p[dev] = (uint32_t*)a;
+  }
+  return p[dev];
+}
+
+// CLMGS_LEGACY_BINNING=1: the round-3 chain (three launches per radix digit, three per scan) -- kept for A/B
+// measurements and as the second, independent route of the equality tests.
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+static int os_rounds(const char* name, int dflt) {
+  const int r = env_int(name, dflt);
+  return (r == 1 || r == 2 || r == 4 || r == 8) ? r : dflt;
+}
+// Three routes through the binning chain, all producing the same lists element for element (CLMGS_BINNING, read per
+// call so that tests can switch inside one process):
+//   fused    (default) three kernels per radix digit with a multi-chunk histogram kernel and a segment-per-thread row
+//            scan; the two scans folded into their producers + ONE finishing launch each; the last tile-sort pass
+//            writes flatten_ids / emit_slot directly
+//   lookback round 4's single-launch passes by decoupled look-back (onesweep.h) -- measured SLOWER on MI355X (a sort
+//            pass of 3.3 M keys 60-79 us against 30 + 11 + 11 us, of 9.3 M keys 155-205 against 106 + 34 + 34;
+//            DESIGN.md section 3): kept as a tested alternative and as the evidence
+//   legacy   the round-3 chain
+enum { BIN_FUSED = 0, BIN_LOOKBACK = 1, BIN_LEGACY = 2 };
+static int binning_route() {
+  const char* e = getenv("CLMGS_BINNING");
+  if (e && e[0] == 'l' && e[1] == 'o') return BIN_LOOKBACK;
+  if (e && e[0] == 'l' && e[1] == 'e') return BIN_LEGACY;
+  return BIN_FUSED;
+}
+static bool legacy_binning() { return binning_route() == BIN_LEGACY; }
 
 struct TileBox { int x0, y0, x1, y1; };
 
@@ -148,7 +193,8 @@ extern "C" int clmgs_isect_emit_sort(void* stream, int C, int N, int64_t n_isect
   CLMGS_LAUNCH_CHECK();
   uint64_t* sorted = nullptr;  // the caller's isect_ids doubles as the second key buffer
   int rc = radix_sort_pairs<uint64_t>(s, n_isects, keys_a, (uint64_t*)isect_ids, vals_a, vals_b,
-                                      flatten_ids, 0, 32 + tile_bits + cam_bits, table, &sorted);
+                                      flatten_ids, 0, 32 + tile_bits + cam_bits, table, &sorted, nullptr,
+                                      !legacy_binning());
   if (rc) return rc;
   if (sorted != (uint64_t*)isect_ids)
     CLMGS_HIP(hipMemcpyAsync(isect_ids, sorted, (size_t)n_isects * 8, hipMemcpyDeviceToDevice, s));
@@ -342,12 +388,292 @@ isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int 
   }
 }
 
+
+// ======================================================================================
+// Round 4: the same chain in 11 launches instead of ~30 (onesweep.h).
+//   memset(control block) -> keys_lb (keys, boxes, masks, per-row counts + their scan = row_cum, digit counts of all
+//   four depth-sort passes) -> 4 x onesweep pass -> count_lb (boxes in depth order, counts + their scan = cum, totals)
+//   | memset(control block) -> emit_lb (tile ids + payload, digit counts of the tile sort) -> 2 x onesweep pass (the last
+//   one writes flatten_ids / emit_slot directly) -> offsets.
+// Every list is element for element the legacy chain's (stable LSD passes in the same digit order).
+// ======================================================================================
+constexpr int LBK_ROUNDS = 4;
+constexpr int LBK_CHUNK = 256 * LBK_ROUNDS;  // rows (ranks) per ticket of the keys / count kernels
+
+__host__ __device__ static inline int lbk_chunks(int V) { return (V + LBK_CHUNK - 1) / LBK_CHUNK; }
+
+// LOOKBACK = false (default route): chunk = blockIdx.x, the scan stays block-relative (row_cum gets the inclusive
+// scan inside the chunk, block_tot[chunk] its total; scan_i64_finish_kernel adds the offsets), no digit counts.
+template <bool LOOKBACK>
+__global__ void __launch_bounds__(256)
+isect2_keys_lb_kernel(int V, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                      const float* __restrict__ means2d, const float4* __restrict__ packed, float tile_size,
+                      int tile_w, int tile_h, uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                      unsigned long long* __restrict__ box_by_row, int64_t* __restrict__ row_cum,
+                      uint32_t* __restrict__ ghist /*[4][256]*/, unsigned long long* __restrict__ status,
+                      uint32_t* __restrict__ ticket_ctr, int64_t* __restrict__ totals, uint32_t* err,
+                      int64_t* __restrict__ block_tot) {
+  __shared__ uint32_t hist[LOOKBACK ? 4 : 1][256];
+  __shared__ long long wsum[4];
+  __shared__ long long sh[2];
+  __shared__ int ticket_s;
+  const int tid = threadIdx.x;
+  if constexpr (LOOKBACK) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hist[p][tid] = 0;
+  }
+  const int n_chunks = lbk_chunks(V);
+  for (int iter = 0;; ++iter) {
+    int chunk;
+    if constexpr (LOOKBACK) {
+      __syncthreads();
+      if (tid == 0) ticket_s = (int)atomicAdd(ticket_ctr, 1u);
+      __syncthreads();
+      chunk = ticket_s;
+    } else {
+      chunk = blockIdx.x + iter * gridDim.x;
+    }
+    if (chunk >= n_chunks) break;
+    if (chunk == 0 && tid == 0) { totals[0] = 0; totals[1] = 0; }  // the count kernel accumulates into them (later launch)
+    long long c[LBK_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < LBK_ROUNDS; ++r) {
+      const int i = chunk * LBK_CHUNK + r * 256 + tid;
+      c[r] = 0;
+      if (i < V) {
+        const int rad = radii[i];
+        const uint32_t key = rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+        keys[i] = key;
+        vals[i] = i;
+        unsigned long long b = 0ull, m = ~0ull;
+        int cnt = 0;
+        if (rad > 0) {
+          const float2 mm = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
+          const TileBox tb = tile_box(mm.x, mm.y, (float)rad, tile_size, tile_w, tile_h);
+          b = pack_box(tb);
+          if (packed) m = exact_tile_mask(packed + 4 * (size_t)i, tb.x0, tb.y0, tb.x1, tb.y1);
+          const int nt = (tb.x1 - tb.x0) * (tb.y1 - tb.y0);
+          cnt = nt <= 64 ? __popcll(m & (nt == 64 ? ~0ull : ((1ull << nt) - 1ull))) : nt;
+        }
+        box_by_row[2 * (size_t)i] = b;
+        box_by_row[2 * (size_t)i + 1] = m;
+        c[r] = cnt;
+        if constexpr (LOOKBACK) {
+          atomicAdd(&hist[0][key & 0xFFu], 1u);
+          atomicAdd(&hist[1][(key >> 8) & 0xFFu], 1u);
+          atomicAdd(&hist[2][(key >> 16) & 0xFFu], 1u);
+          atomicAdd(&hist[3][key >> 24], 1u);
+        }
+      }
+    }
+    if (row_cum) {  // inclusive scan of the emitted counts in ROW order (the slot ranges of the backward)
+      long long inc[LBK_ROUNDS];
+      long long carry = 0;
+#pragma unroll
+      for (int r = 0; r < LBK_ROUNDS; ++r) {
+        const long long incl = block_incl_scan_i64(c[r], wsum);
+        inc[r] = carry + incl;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      }
+      long long excl = 0;
+      if constexpr (LOOKBACK) excl = lb_chunk_prefix(status, chunk, carry, sh, err);
+      else if (tid == 0) block_tot[chunk] = carry;
+#pragma unroll
+      for (int r = 0; r < LBK_ROUNDS; ++r) {
+        const int i = chunk * LBK_CHUNK + r * 256 + tid;
+        if (i < V) row_cum[i] = excl + inc[r];
+      }
+    }
+  }
+  if constexpr (LOOKBACK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t v = hist[p][tid];
+      if (v) atomicAdd(&ghist[p * 256 + tid], v);
+    }
+  }
+}
+
+// boxes / masks in depth order, cum = inclusive scan of the emitted counts in that order, totals[0] = the grand
+// total, totals[1] += the un-culled count (both zeroed by keys_lb).
+template <bool LOOKBACK>
+__global__ void __launch_bounds__(256)
+isect2_count_lb_kernel(int V, const int32_t* __restrict__ order,
+                       const unsigned long long* __restrict__ box_by_row,
+                       unsigned long long* __restrict__ boxes, int64_t* __restrict__ cum,
+                       int64_t* __restrict__ totals, unsigned long long* __restrict__ status,
+                       uint32_t* __restrict__ ticket_ctr, uint32_t* err, int64_t* __restrict__ block_tot) {
+  __shared__ long long wsum[4];
+  __shared__ long long sh[2];
+  __shared__ unsigned long long rsum[4];
+  __shared__ int ticket_s;
+  const int tid = threadIdx.x;
+  const int n_chunks = lbk_chunks(V);
+  unsigned long long ref = 0ull;
+  for (int iter = 0;; ++iter) {
+    int chunk;
+    if constexpr (LOOKBACK) {
+      __syncthreads();
+      if (tid == 0) ticket_s = (int)atomicAdd(ticket_ctr, 1u);
+      __syncthreads();
+      chunk = ticket_s;
+    } else {
+      chunk = blockIdx.x + iter * gridDim.x;
+    }
+    if (chunk >= n_chunks) break;
+    long long inc[LBK_ROUNDS];
+    long long carry = 0;
+#pragma unroll
+    for (int r = 0; r < LBK_ROUNDS; ++r) {
+      const int j = chunk * LBK_CHUNK + r * 256 + tid;
+      long long cnt = 0;
+      if (j < V) {
+        const int i = order[j];
+        const unsigned long long b = box_by_row[2 * (size_t)i], m = box_by_row[2 * (size_t)i + 1];
+        const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
+        const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
+        const int nt = (x1 - x0) * (y1 - y0);
+        cnt = nt <= 64 ? __popcll(m & (nt == 64 ? ~0ull : ((1ull << nt) - 1ull))) : nt;
+        boxes[2 * (size_t)j] = cnt > 0 ? b : 0ull;
+        boxes[2 * (size_t)j + 1] = m;
+        ref += (unsigned long long)nt;
+      }
+      const long long incl = block_incl_scan_i64(cnt, wsum);
+      inc[r] = carry + incl;
+      carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    long long excl = 0;
+    if constexpr (LOOKBACK) excl = lb_chunk_prefix(status, chunk, carry, sh, err);
+    else if (tid == 0) block_tot[chunk] = carry;
+#pragma unroll
+    for (int r = 0; r < LBK_ROUNDS; ++r) {
+      const int j = chunk * LBK_CHUNK + r * 256 + tid;
+      if (j < V) cum[j] = excl + inc[r];
+    }
+    if (LOOKBACK && chunk == n_chunks - 1 && tid == 0) totals[0] = excl + carry;
+  }
+  ref = (unsigned long long)wave_sum_i64((long long)ref);
+  __syncthreads();
+  if ((tid & 63) == 0) rsum[tid >> 6] = ref;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long tot = rsum[0] + rsum[1] + rsum[2] + rsum[3];
+    if (tot) atomicAdd((unsigned long long*)(totals + 1), tot);
+  }
+}
+
+// emit + the digit counts of every pass of the tile sort (entries beyond the capacity are neither written nor
+// counted, so the counts always describe the min(capacity, total) keys the passes sort)
+__global__ void __launch_bounds__(256)
+isect2_emit_lb_kernel(int V, const int32_t* __restrict__ order,
+                      const unsigned long long* __restrict__ boxes,
+                      const int64_t* __restrict__ cum, int tile_w, uint32_t* __restrict__ tkeys,
+                      int32_t* __restrict__ vals, int2* __restrict__ vals2,
+                      const int64_t* __restrict__ row_cum, int64_t cap, int n_pass,
+                      uint32_t* __restrict__ ghist /*[4][256]*/) {
+  __shared__ uint32_t hist[4][256];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) hist[p][threadIdx.x] = 0;
+  __syncthreads();
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
+    const unsigned long long b = boxes[2 * (size_t)j];
+    if (b == 0ull) continue;
+    const unsigned long long m = boxes[2 * (size_t)j + 1];
+    const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
+    const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
+    const bool masked = (x1 - x0) * (y1 - y0) <= 64;
+    const int i = order[j];
+    int64_t cur = (j == 0) ? 0 : cum[j - 1];
+    int slot = (vals2 && i > 0) ? (int)row_cum[i - 1] : 0;
+    int t = 0;
+    for (int ty = y0; ty < y1 && cur < cap; ++ty)
+      for (int tx = x0; tx < x1; ++tx, ++t) {
+        if (masked && !((m >> t) & 1ull)) continue;
+        if (cur >= cap) break;  // device-count mode, capacity exceeded: dropped (the caller compares the totals)
+        const uint32_t key = (uint32_t)(ty * tile_w + tx);
+        tkeys[cur] = key;
+        if (vals2) vals2[cur] = make_int2(i, slot++);
+        else vals[cur] = i;
+        ++cur;
+        atomicAdd(&hist[0][key & 0xFFu], 1u);
+        if (n_pass > 1) atomicAdd(&hist[1][(key >> 8) & 0xFFu], 1u);
+        if (n_pass > 2) atomicAdd(&hist[2][(key >> 16) & 0xFFu], 1u);
+        if (n_pass > 3) atomicAdd(&hist[3][key >> 24], 1u);
+      }
+  }
+  __syncthreads();
+  for (int p = 0; p < n_pass; ++p) {
+    const uint32_t v = hist[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], v);
+  }
+}
+
+// offsets from the sorted tile ids (+ optional isect_ids); a true count of 0 leaves no entry to derive them from:
+// the grid fills them with zeros itself (no memset launch).
+__global__ void __launch_bounds__(256)
+isect2_offsets_lb_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int n_tiles,
+                         int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+                         const float* __restrict__ depths, int64_t* __restrict__ isect_ids,
+                         const int64_t* __restrict__ n_dev) {
+  if (n_dev) n_isects = min(n_isects, *n_dev);
+  if (n_isects <= 0) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x) offsets[t] = 0;
+    return;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_isects;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cur = (int)tkeys[i];
+    if (i == 0) {
+      for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+    } else {
+      const int prev = (int)tkeys[i - 1];
+      for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+    }
+    if (i == n_isects - 1)
+      for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
+    if (isect_ids)
+      isect_ids[i] = ((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[flatten_ids[i]]);
+  }
+}
+
+// Second half of a scan whose producer left block-relative inclusive values (chunks of LBK_CHUNK) and the chunk totals:
+// every block sums the totals of the chunks before its own (a block-wide reduction over <= a few thousand L2-resident
+// words) and adds that offset -- one launch instead of scan-the-totals + add.  last_out: the grand total.
+__global__ void __launch_bounds__(256)
+scan_i64_finish_kernel(int n, int64_t* __restrict__ data, const int64_t* __restrict__ block_tot,
+                       int64_t* __restrict__ last_out) {
+  __shared__ long long wsum[4];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  long long part = 0;
+  for (int j = tid; j < chunk; j += 256) part += block_tot[j];
+  part = wave_sum_i64(part);
+  if ((tid & 63) == 0) wsum[tid >> 6] = part;
+  __syncthreads();
+  const long long off = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (chunk > 0) {
+#pragma unroll
+    for (int r = 0; r < LBK_ROUNDS; ++r) {
+      const int i = chunk * LBK_CHUNK + r * 256 + tid;
+      if (i < n) data[i] += off;
+    }
+  }
+  if (last_out && chunk == (int)gridDim.x - 1 && tid == 0) *last_out = off + block_tot[chunk];
+}
+
+// control block of clmgs_isect2_order_count: [4][256] digit counts | 16 ticket words | scan status of keys_lb | scan
+// status of count_lb | 4 x sort status
+static inline size_t order_ctrl_bytes(int V) {
+  return 4096 + 256 + 2 * align_up((size_t)lbk_chunks(V) * 8, 256) + 4 * os_status_bytes(V);
+}
+static inline size_t sort_ctrl_bytes(int64_t n) { return 4096 + 256 + 4 * os_status_bytes(n); }
+
 }  // namespace clmgs
 
 extern "C" size_t clmgs_isect2_order_temp_bytes(int V) {
   if (V <= 0) return 256;
-  return 4 * align_up((size_t)V * 4, 256) + align_up((size_t)V * 16, 256) + radix_table_bytes(V) +
-         scan_scratch_bytes(V) + 256;
+  const size_t legacy = radix_table_bytes(V) + max(scan_scratch_bytes(V), (size_t)2 * lbk_chunks(V) * sizeof(int64_t) + 256);
+  return 4 * align_up((size_t)V * 4, 256) + align_up((size_t)V * 16, 256) + max(legacy, order_ctrl_bytes(V)) + 256;
 }
 
 // order[V] i32 (rows by depth, culled last), cum[V] i64 (inclusive tile counts in that order),
@@ -376,13 +702,67 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   unsigned long long* box_by_row = (unsigned long long*)base; base += align_up((size_t)V * 16, 256);
   uint32_t* table = (uint32_t*)base; base += radix_table_bytes(V);
   int64_t* scan_tmp = (int64_t*)base;
+  if (binning_route() == BIN_FUSED) {
+    int64_t* tot_a = scan_tmp;                      // chunk totals of the two scans
+    int64_t* tot_b = scan_tmp + lbk_chunks(V);
+    const int nck = lbk_chunks(V);
+    hipLaunchKernelGGL((isect2_keys_lb_kernel<false>), dim3(nck), dim3(256), 0, s, V, radii, depths, means2d,
+                       (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a, box_by_row,
+                       row_cum, (uint32_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, totals,
+                       (uint32_t*)nullptr, tot_a);
+    if (row_cum)
+      hipLaunchKernelGGL(scan_i64_finish_kernel, dim3(nck), dim3(256), 0, s, V, row_cum, tot_a, (int64_t*)nullptr);
+    CLMGS_LAUNCH_CHECK();
+    uint32_t* sorted = nullptr;
+    int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
+    if (rc) return rc;
+    hipLaunchKernelGGL((isect2_count_lb_kernel<false>), dim3(nck), dim3(256), 0, s, V, order, box_by_row,
+                       (unsigned long long*)boxes, cum, totals, (unsigned long long*)nullptr, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, tot_b);
+    hipLaunchKernelGGL(scan_i64_finish_kernel, dim3(nck), dim3(256), 0, s, V, cum, tot_b, totals);
+    CLMGS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (binning_route() == BIN_LOOKBACK) {
+    // control block (zeroed by ONE memset): digit counts | tickets | scan status x 2 | sort status x 4
+    char* ctrl = (char*)table;  // (the legacy routes' radix table + scan scratch: the temp size is the max of both)
+    uint32_t* ghist = (uint32_t*)ctrl;
+    uint32_t* tickets = (uint32_t*)(ctrl + 4096);
+    const size_t sb = align_up((size_t)lbk_chunks(V) * 8, 256);
+    unsigned long long* st_keys = (unsigned long long*)(ctrl + 4096 + 256);
+    unsigned long long* st_count = (unsigned long long*)(ctrl + 4096 + 256 + sb);
+    char* st_sort = ctrl + 4096 + 256 + 2 * sb;
+    const size_t ssb = os_status_bytes(V);
+    uint32_t* err = device_error_word();
+    CLMGS_CHECK_ARG(err != nullptr);
+    CLMGS_HIP(hipMemsetAsync(ctrl, 0, order_ctrl_bytes(V), s));
+    const int nck = lbk_chunks(V);
+    hipLaunchKernelGGL((isect2_keys_lb_kernel<true>), dim3(min(nck, 1024)), dim3(256), 0, s, V, radii, depths, means2d,
+                       (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a, box_by_row,
+                       row_cum, ghist, st_keys, tickets + 0, totals, err, (int64_t*)nullptr);
+    uint32_t* ksrc = k_a;
+    uint32_t* kdst = k_b;
+    int32_t* vsrc = v_a;
+    for (int p = 0; p < 4; ++p) {
+      int32_t* vdst = (p == 3) ? order : (vsrc == v_a ? v_b : v_a);
+      launch_onesweep_pass<int32_t, false>(s, os_rounds("CLMGS_OS_ROUNDS_V", 8), (int64_t)V, (const int64_t*)nullptr, ksrc,
+                                           vsrc, kdst, vdst, (int32_t*)nullptr, (int32_t*)nullptr, 8 * p,
+                                           ghist + 256 * p, (uint32_t*)(st_sort + ssb * p), tickets + 2 + p, err);
+      uint32_t* t_ = ksrc; ksrc = kdst; kdst = t_;
+      vsrc = vdst;
+    }
+    hipLaunchKernelGGL((isect2_count_lb_kernel<true>), dim3(min(nck, 1024)), dim3(256), 0, s, V, order, box_by_row,
+                       (unsigned long long*)boxes, cum, totals, st_count, tickets + 1, err, (int64_t*)nullptr);
+    CLMGS_LAUNCH_CHECK();
+    return 0;
+  }
   const int grid = min(ceil_div(V, 256), 256 * 16);
   hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, means2d,
                      (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a,
                      box_by_row, row_cum);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
-  int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted);
+  int rc = radix_sort_pairs<uint32_t>(s, V, k_a, k_b, v_a, v_b, order, 0, 32, table, &sorted, nullptr, false);
   if (rc) return rc;
   if (row_cum) {
     rc = inclusive_scan_i64(s, V, row_cum, scan_tmp);
@@ -397,7 +777,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
 
 extern "C" size_t clmgs_isect2_sort_temp_bytes(int64_t n_isects) {
   if (n_isects <= 0) return 256;
-  return 8 * align_up((size_t)n_isects * 4, 256) + radix_table_bytes(n_isects) + 256;
+  return 8 * align_up((size_t)n_isects * 4, 256) + max(radix_table_bytes(n_isects), sort_ctrl_bytes(n_isects)) + 256;
 }
 
 // flatten_ids[I] i32 (row ids, sorted by tile then depth), offsets[tile_w*tile_h] i32,
@@ -412,7 +792,9 @@ static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const fl
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
-  if (n_isects == 0 || n_dev) {  // device-count mode: a true count of 0 leaves no thread to write the offsets
+  const bool lb = binning_route() == BIN_LOOKBACK && n_isects < ((int64_t)1 << 30);  // 30-bit counts in the look-back words
+  const bool fused = binning_route() == BIN_FUSED;
+  if (n_isects == 0 || (n_dev && !lb && !fused)) {  // device-count mode: a true count of 0 leaves no thread to write the offsets
     CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
     if (n_isects == 0) return 0;
   }
@@ -430,18 +812,75 @@ static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const fl
   const bool slots = emit_slot != nullptr;
   CLMGS_CHECK_ARG(!slots || row_cum);
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
+  if (lb) {
+    const int n_pass = (tile_bits + 7) / 8;
+    char* ctrl = (char*)table;
+    uint32_t* ghist = (uint32_t*)ctrl;
+    uint32_t* tickets = (uint32_t*)(ctrl + 4096);
+    char* st_sort = ctrl + 4096 + 256;
+    const size_t ssb = os_status_bytes(n_isects);
+    uint32_t* err = device_error_word();
+    CLMGS_CHECK_ARG(err != nullptr);
+    CLMGS_HIP(hipMemsetAsync(ctrl, 0, 4096 + 256 + (size_t)n_pass * ssb, s));
+    hipLaunchKernelGGL(isect2_emit_lb_kernel, dim3(min(ceil_div(V, 256), 1024)), dim3(256), 0, s, V, order,
+                       (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
+                       slots ? (int2*)v_a : nullptr, row_cum, n_isects, n_pass, ghist);
+    uint32_t* ksrc = k_a;
+    uint32_t* kdst = k_b;
+    char* vsrc = v_a;
+    const int rounds = os_rounds("CLMGS_OS_ROUNDS_I", 8);
+    for (int p = 0; p < n_pass; ++p) {
+      const bool last = p == n_pass - 1;
+      char* vdst = (vsrc == v_a) ? v_b : v_a;
+      uint32_t* st = (uint32_t*)(st_sort + ssb * p);
+      if (slots) {
+        if (last)
+          launch_onesweep_pass<int2, true>(s, rounds, n_isects, n_dev, ksrc, (const int2*)vsrc, kdst, (int2*)nullptr,
+                                           flatten_ids, emit_slot, 8 * p, ghist + 256 * p, st, tickets + p, err);
+        else
+          launch_onesweep_pass<int2, false>(s, rounds, n_isects, n_dev, ksrc, (const int2*)vsrc, kdst, (int2*)vdst,
+                                            (int32_t*)nullptr, (int32_t*)nullptr, 8 * p, ghist + 256 * p, st,
+                                            tickets + p, err);
+      } else {
+        launch_onesweep_pass<int32_t, false>(s, rounds, n_isects, n_dev, ksrc, (const int32_t*)vsrc, kdst,
+                                             last ? flatten_ids : (int32_t*)vdst, (int32_t*)nullptr,
+                                             (int32_t*)nullptr, 8 * p, ghist + 256 * p, st, tickets + p, err);
+      }
+      uint32_t* t_ = ksrc; ksrc = kdst; kdst = t_;
+      vsrc = vdst;
+    }
+    hipLaunchKernelGGL(isect2_offsets_lb_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0, s,
+                       n_isects, ksrc, n_tiles, offsets, flatten_ids, depths, isect_ids, n_dev);
+    CLMGS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
                      order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
                      slots ? (int2*)v_a : nullptr, row_cum, n_isects);
   CLMGS_LAUNCH_CHECK();
   uint32_t* sorted = nullptr;
   int rc;
+  if (fused) {
+    // the last pass writes flatten_ids / emit_slot itself (no int2 list to split afterwards); the offsets kernel then
+    // reads the sorted tile ids only and zero-fills the offsets itself when the true count is 0
+    if (slots)
+      rc = radix_sort_pairs_impl<uint32_t, int2, RS_DEFAULT_ITEMS>(s, n_isects, k_a, k_b, (int2*)v_a, (int2*)v_b, (int2*)nullptr,
+                                                                    0, tile_bits, table, &sorted, n_dev, flatten_ids, emit_slot);
+    else
+      rc = radix_sort_pairs<uint32_t, int32_t>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b, flatten_ids, 0,
+                                               tile_bits, table, &sorted, n_dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(isect2_offsets_lb_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0, s,
+                       n_isects, sorted, n_tiles, offsets, flatten_ids, depths, isect_ids, n_dev);
+    CLMGS_LAUNCH_CHECK();
+    return 0;
+  }
   if (slots)
     rc = radix_sort_pairs<uint32_t, int2>(s, n_isects, k_a, k_b, (int2*)v_a, (int2*)v_b, (int2*)v_f, 0,
-                                          tile_bits, table, &sorted, n_dev);
+                                          tile_bits, table, &sorted, n_dev, false);
   else
     rc = radix_sort_pairs<uint32_t, int32_t>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b,
-                                             flatten_ids, 0, tile_bits, table, &sorted, n_dev);
+                                             flatten_ids, 0, tile_bits, table, &sorted, n_dev, false);
   if (rc) return rc;
   hipLaunchKernelGGL(isect2_offsets_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0,
                      s, n_isects, sorted, n_tiles, offsets, flatten_ids, emit_slot,
@@ -671,7 +1110,7 @@ visibility_emit_kernel(int C, int N, int W64, const unsigned long long* __restri
 
 extern "C" size_t clmgs_visibility_select_temp_bytes(int C, int N) {
   const size_t words = (size_t)(C + 1) * (size_t)((N + 63) / 64);
-  return 2 * align_up(words * 8, 256) + scan_scratch_bytes((int64_t)words) + 256;
+  return 2 * align_up(words * 8, 256) + max(scan_scratch_bytes((int64_t)words), lb_scan_ctrl_bytes((int64_t)words)) + 256;
 }
 
 extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const float* means,
@@ -694,7 +1133,13 @@ extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const f
                      dim3(256), 0, s, C, N, W64, means, quats_raw, log_scales, viewmats, Ks,
                      (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, bits, counts);
   CLMGS_LAUNCH_CHECK();
-  int rc = inclusive_scan_i64(s, (int64_t)words, counts, scratch);
+  int rc;
+  if (binning_route() == BIN_LOOKBACK) {  // one launch (decoupled look-back) + the memset of its control words
+    CLMGS_HIP(hipMemsetAsync(scratch, 0, lb_scan_ctrl_bytes((int64_t)words), s));
+    rc = lb_inclusive_scan_i64(s, (int64_t)words, counts, scratch);
+  } else {
+    rc = inclusive_scan_i64(s, (int64_t)words, counts, scratch);
+  }
   if (rc) return rc;
   // cum_totals[r] = number of set bits in rows 0..r (device array of C+1, read back by the caller)
   for (int r = 0; r <= C; ++r)
@@ -717,3 +1162,17 @@ extern "C" int clmgs_visibility_select_emit(void* stream, int C, int N, const vo
   return 0;
 }
 
+
+// Device error word of the look-back primitives: *out = bits (1 = a scan look-back, 2 = a sort look-back gave up
+// after its spin bound: a workgroup of the launch never published -- results of that call are invalid); cleared when
+// `reset`.  Synchronises the device.
+extern "C" int clmgs_device_errors(uint32_t* out, int reset) {
+  CLMGS_CHECK_ARG(out);
+  CLMGS_HIP(hipDeviceSynchronize());
+  CLMGS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(clmgs::g_dev_err), sizeof(uint32_t)));
+  if (reset && *out) {
+    const uint32_t z = 0;
+    CLMGS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(clmgs::g_dev_err), &z, sizeof(z)));
+  }
+  return 0;
+}

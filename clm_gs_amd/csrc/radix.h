@@ -82,13 +82,83 @@ radix_scan_rows_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __r
   if (threadIdx.x == 0) row_tot[blockIdx.x] = carry_s;
 }
 
-template <typename KeyT, typename ValT, int RS_ITEMS>
+// Round 4 variants (the default route; the round-3 kernels above stay for CLMGS_BINNING=legacy):
+// histogram -- one block counts HB consecutive chunks: HB x RS_ITEMS independent loads in flight per thread instead
+// of RS_ITEMS, a quarter of the blocks (the kernel is a load -> LDS atomic -> store latency chain, not bandwidth).
+constexpr int RS_HIST_HB = 4;
+template <typename KeyT, int RS_ITEMS>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_hist_multi_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int n_blocks,
+                        uint32_t* __restrict__ table /*[256][n_blocks]*/, const int64_t* __restrict__ n_dev) {
+  constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
+  if (n_dev) n = min(n, *n_dev);
+  __shared__ uint32_t h[RS_HIST_HB][256];
+#pragma unroll
+  for (int c = 0; c < RS_HIST_HB; ++c) h[c][threadIdx.x] = 0;
+  __syncthreads();
+  const int c0 = blockIdx.x * RS_HIST_HB;
+  KeyT k[RS_HIST_HB][RS_ITEMS];
+  bool have[RS_HIST_HB][RS_ITEMS];
+#pragma unroll
+  for (int c = 0; c < RS_HIST_HB; ++c)
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      const int64_t i = (int64_t)(c0 + c) * RS_CHUNK + it * RS_THREADS + threadIdx.x;
+      have[c][it] = i < n;
+      k[c][it] = have[c][it] ? keys[i] : KeyT{};
+    }
+#pragma unroll
+  for (int c = 0; c < RS_HIST_HB; ++c)
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it)
+      if (have[c][it]) atomicAdd(&h[c][(unsigned)((k[c][it] >> shift) & 0xFF)], 1u);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < RS_HIST_HB; ++c)
+    if (c0 + c < n_blocks) table[(size_t)threadIdx.x * n_blocks + c0 + c] = h[c][threadIdx.x];
+}
+
+// row scan -- thread t of block d owns the contiguous segment [t K, (t+1) K) of digit d's row (K = ceil(n_blocks /
+// 256)): independent loads, ONE block-wide scan of the 256 segment sums, a second sweep writing the exclusive values;
+// the round-3 kernel walked the row in 256-wide steps with three barriers each (36 dependent steps at 9.3 M keys).
+__global__ void __launch_bounds__(RS_SCAN_THREADS)
+radix_scan_rows_seg_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __restrict__ row_tot) {
+  __shared__ uint32_t wsum[RS_SCAN_THREADS / 64];
+  uint32_t* row = table + (size_t)blockIdx.x * n_blocks;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int K = (n_blocks + RS_SCAN_THREADS - 1) / RS_SCAN_THREADS;
+  const int a = min(n_blocks, (int)threadIdx.x * K), b = min(n_blocks, a + K);
+  uint32_t sum = 0;
+#pragma unroll 8
+  for (int i = a; i < b; ++i) sum += row[i];
+  uint32_t x = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  uint32_t run = woff + x - sum;
+#pragma unroll 8
+  for (int i = a; i < b; ++i) {
+    const uint32_t v = row[i];
+    row[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == RS_SCAN_THREADS - 1) row_tot[blockIdx.x] = run;
+}
+
+template <typename KeyT, typename ValT, int RS_ITEMS, bool SPLIT = false>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in,
                      KeyT* __restrict__ keys_out, ValT* __restrict__ vals_out, int shift,
                      int n_blocks, const uint32_t* __restrict__ table,
                      const uint32_t* __restrict__ row_tot /*[256] keys per digit*/,
-                     const int64_t* __restrict__ n_dev) {
+                     const int64_t* __restrict__ n_dev, int32_t* __restrict__ out_a = nullptr,
+                     int32_t* __restrict__ out_b = nullptr) {
   constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;
   if (n_dev) n = min(n, *n_dev);
   // cnt[round][wave][digit]: first the number of keys of that digit in that (round, wave), then
@@ -189,7 +259,13 @@ radix_scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const ValT* __
       const unsigned digit = (unsigned)((k >> shift) & 0xFF);
       const uint32_t pos = cursor[digit] + (uint32_t)li - dstart[digit];
       keys_out[pos] = k;
-      vals_out[pos] = sval[li];
+      if constexpr (SPLIT) {  // final pass of an (a, b)-pair payload: the two halves go to their own arrays
+        const ValT v = sval[li];
+        out_a[pos] = v.x;
+        out_b[pos] = v.y;
+      } else {
+        vals_out[pos] = sval[li];
+      }
     }
   }
 }
@@ -206,7 +282,8 @@ static inline size_t radix_table_bytes(int64_t n) {
 template <typename KeyT, typename ValT, int ITEMS>
 static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                                  ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
-                                 uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr) {
+                                 uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr,
+                                 int32_t* split_a = nullptr, int32_t* split_b = nullptr, bool round4 = true) {
   constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -222,11 +299,26 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
     const int shift = begin_bit + 8 * p;
     KeyT* kdst = (ksrc == keysA) ? keysB : keysA;
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
-    hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
-                       n_blocks, table, n_dev);
-    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
+    if (round4) {
+      hipLaunchKernelGGL((radix_hist_multi_kernel<KeyT, ITEMS>), dim3((n_blocks + RS_HIST_HB - 1) / RS_HIST_HB),
+                         dim3(RS_THREADS), 0, s, n, ksrc, shift, n_blocks, table, n_dev);
+      hipLaunchKernelGGL(radix_scan_rows_seg_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
+    } else {
+      hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
+                         n_blocks, table, n_dev);
+      hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
+    }
+    if constexpr (sizeof(ValT) == 8) {
+      if (split_a && p == passes - 1) {
+        hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS, true>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc,
+                           vsrc, kdst, (ValT*)nullptr, shift, n_blocks, table, row_tot, n_dev, split_a, split_b);
+        CLMGS_LAUNCH_CHECK();
+        ksrc = kdst;
+        continue;
+      }
+    }
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, vsrc,
-                       kdst, vdst, shift, n_blocks, table, row_tot, n_dev);
+                       kdst, vdst, shift, n_blocks, table, row_tot, n_dev, (int32_t*)nullptr, (int32_t*)nullptr);
     CLMGS_LAUNCH_CHECK();
     ksrc = kdst;
     vsrc = vdst;
@@ -238,9 +330,10 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
 template <typename KeyT, typename ValT = int32_t>
 static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                             ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
-                            uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr) {
+                            uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr, bool round4 = true) {
   return radix_sort_pairs_impl<KeyT, ValT, RS_DEFAULT_ITEMS>(s, n, keysA, keysB, valsA, valsB, vals_final,
-                                                      begin_bit, end_bit, table, keys_sorted, n_dev);
+                                                      begin_bit, end_bit, table, keys_sorted, n_dev, nullptr, nullptr,
+                                                      round4);
 }
 
 // ------------------------------------------------------------- inclusive scan of int64

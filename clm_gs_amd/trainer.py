@@ -227,6 +227,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             gaussians.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
     timer.stop()
+    from . import _lib
+    _lib.check_device_errors()  # the binning chain's look-back kernels never timed out (raises otherwise)
     n_done = ((iterations - 1) // gbsz + 1) * gbsz + 1
     timer.print_time(log_file, n_done)
     log_file.write(memory_line(iteration, gbsz, gaussians, what="final"))

@@ -386,6 +386,14 @@ int clmgs_knn3_mean_dist2(void* stream, int n, const float* pts_sorted, const in
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);
 
+/* Device error word of the single-launch scan / sort-pass kernels of the binning chain (csrc/onesweep.h: workgroups
+ * of one launch hand per-chunk aggregates to each other by decoupled look-back; every poll loop is bounded).
+ * *bits: 1 = a scan look-back, 2 = a sort-pass look-back gave up after its bound -- the lists of that call are
+ * invalid.  Synchronises the device; `reset` clears the word.  No reference counterpart (gsplat.isect_tiles sorts
+ * with cub, strategies/base_engine.py:175-186); callers check it where they synchronise anyway (evaluation, saving,
+ * the end of a benchmark). */
+int clmgs_device_errors(uint32_t* bits, int reset);
+
 /* ---- pinned host memory  (numba.cuda.pinned_array at clm_offload/gaussian_model.py:34-44) */
 void* clmgs_pinned_alloc(size_t bytes);
 int clmgs_pinned_free(void* p);

@@ -707,3 +707,73 @@ def test_device_count_forms_equal_exact_forms(dev, slack):
                                     dptr(c.row_cum), dptr(part2)))
     torch.cuda.synchronize()
     assert torch.equal(part2[:I], part[:I]) and bool((part2[I:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,wh", [(3000, (150, 101)), (180_000, (640, 480))])
+def test_single_launch_binning_equals_legacy_chain(dev, n, wh):
+    """Round 4: the default binning chain (CLMGS_BINNING=fused: scans folded into their producers + one finishing
+    launch, multi-chunk histograms, segment row scans, the last tile-sort pass writing flatten_ids / emit_slot itself) and
+    the look-back chain (CLMGS_BINNING=lookback, csrc/onesweep.h: one launch per radix digit -- measured slower, kept as
+    a tested alternative) == the round-3 chain (CLMGS_BINNING=legacy: three launches per digit and per scan), element for
+    element: depth order, both cumulative counts, boxes / masks, totals, flatten_ids, emit_slot, offsets, isect_ids --
+    exact form, device-count form, with and without exact tile culling; 180 000 rows / ~1 M intersections spread over
+    dozens of look-back tickets per kernel.  Also the visibility selection (its scan is a look-back kernel now)."""
+    import os
+    from clm_gs_amd import _lib, gsplat as G
+    from clm_gs_amd._lib import check, dptr, stream
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    L = _lib.lib()
+    w, h = wh
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    sc = synth_gaussians(n, seed=11, device="cuda")
+    cam = nadir_cameras(1, n, w, h, 0.9, seed=2, device="cuda")[0]
+    vm = cam.world_view_transform.t().contiguous()[None]
+    K = cam.K[None]
+    quats = torch.nn.functional.normalize(sc["rotation"])
+    radii, m2, d, cn, _ = G.fully_fused_projection(sc["xyz"], None, quats, torch.exp(sc["scaling"]), vm, K, w, h)
+    d = d.clone()
+    d[0, : n // 50] = d[0, 0]  # exact depth ties: stability of every pass matters
+    packed = torch.empty((n, 16), device=dev)
+    colors = torch.rand(1, n, 3, device=dev)
+    opac = torch.sigmoid(sc["opacity"]).reshape(1, -1).contiguous()
+    fids0, off0, _ = G.isect_tiles_two_level(m2, radii, d, 16, tw, th)
+    out, al, last = torch.empty((h, w, 3), device=dev), torch.empty((h, w), device=dev), torch.empty((h, w), dtype=torch.int32, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, n, fids0.numel(), dptr(m2), dptr(cn), dptr(colors), dptr(opac), None, w, h, 16, tw,
+                                th, dptr(off0), dptr(fids0), dptr(packed), dptr(out), dptr(al), dptr(last)))  # fills `packed`
+
+    def run(route, pk, cap_slack):
+        os.environ["CLMGS_BINNING"] = route
+        try:
+            c = G.isect2_begin(m2, radii, d, 16, tw, th, want_isect_ids=True, want_slots=True, packed=pk)
+            torch.cuda.synchronize()
+            tot = c.totals.clone()
+            res = [c.order[:n].clone(), c.cum[:n].clone(), c.boxes[:n].clone(), tot, c.row_cum[:n].clone()]
+            cap = None if cap_slack is None else max(1, int(int(tot[0]) * cap_slack))
+            fids, off, ids, (slot, _) = G.isect2_finish(c, capacity=cap)
+            torch.cuda.synchronize()
+            I = int(tot[0])
+            return res + [fids[:I].clone(), off.clone(), ids[:I].clone(), slot[:I].clone()]
+        finally:
+            os.environ.pop("CLMGS_BINNING", None)
+
+    names = ("order", "cum", "boxes", "totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot")
+    for pk in (None, packed):
+        ref = run("legacy", pk, None)
+        assert int(ref[3][0]) > (100_000 if n > 100_000 else 100)
+        for route in ("fused", "lookback"):
+            for slack in (None, 1.0, 1.3):
+                got = run(route, pk, slack)
+                for nm, a, b in zip(names, got, ref):
+                    assert torch.equal(a, b), (route, nm, pk is not None, slack)
+    # visibility selection through the look-back scan == through the three-launch scan
+    cams = nadir_cameras(3, n, w, h, 0.4, seed=5, device="cuda")
+    Ks = torch.stack([c.K for c in cams])
+    vms = torch.stack([c.world_view_transform.t() for c in cams])
+    os.environ["CLMGS_BINNING"] = "lookback"
+    try:
+        f_ref, u_ref = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
+    finally:
+        os.environ.pop("CLMGS_BINNING", None)
+    f_new, u_new = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
+    assert torch.equal(u_new, u_ref) and all(torch.equal(a, b) for a, b in zip(f_new, f_ref))
+    _lib.check_device_errors()
