@@ -42,6 +42,14 @@ __device__ __forceinline__ void lds_barrier() {
 }
 #endif
 
+// Partial-gradient line of the atomic-free rasterize backward: 9 floats (x y ca cb | cc r g b | o) in PART_F4 float4.
+// 4 = one 64 B line per (row, tile) intersection, a fourth float4 of zeros.  Round 4 measured the 48 B form (PART_F4 =
+// 3, 16 B x I_emitted less written and read back): rasterize_bwd 1.76 -> 1.82 ms, preprocess_bwd 0.59 -> 0.61 ms solo --
+// SLOWER: a 48 B line straddles two 64 B memory lines, and because slots are numbered in ROW order the two halves
+// of a memory line are written by different tiles at different times (two partial-line writes instead of one full
+// one).  Kept at 4; the constant is the single place to change it (clmgs_rasterize_partials_bytes reports it).
+constexpr int PART_F4 = 4;
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -5,32 +5,44 @@
 // HBM-bound stencil.  What is fused away compared with "fused_ssim + elementwise torch ops":
 // the u8 -> float ground-truth image (never materialised), the |x - y| / mean passes, the
 // HWC -> CHW transposing copy (the rendered image is read through its strides) and the sign()
-// backward pass.  One 256-thread block owns a 16x16 pixel tile for all three channels; the
-// 26x26x3 halos are fetched in one sweep that is contiguous in memory for HWC images.
+// backward pass.
 #include "common.h"
 
 namespace clmgs {
 
-// Streaming separable 11-tap window, one WAVEFRONT per strip of 64 output columns x LS_ROWS output
-// rows (x one channel in the forward):
-//   * the wave walks down the strip in MACRO steps of 11 input rows.  The 11 x 74 input values of
-//     the NEXT macro step (with the +-5 column halo) are requested while the current 11 rows are
-//     processed (13 loads per lane and array stay in flight for ~11 row times: HBM latency is
-//     covered without relying on occupancy); at the macro boundary they are written to a 16-row LDS
-//     ring;
-//   * per row every lane reads its 11 taps from the ring and forms the HORIZONTAL sums;
-//   * the VERTICAL pass is a sliding window in registers: the last 11 rows of horizontal sums
-//     live in a statically indexed ring (the row loop is unrolled by 11), so a finished output row
-//     costs 11 FMAs per statistic and no LDS at all;
-//   * no workgroup barrier anywhere (wave-scope fences only), ~10 KB of LDS per wave.
-// The tiled version it replaces (32x32 tile, 42 KB of LDS per 256-thread block, five barriers per
-// channel) sat at ~55 % VALU utilisation with 3 waves/SIMD.
+// Streaming separable 11-tap window, one WAVEFRONT per strip of 64 output columns x LS_ROWS output rows x one
+// channel, forward AND backward (round 4; rounds 1-3: forward in macro steps of 11 rows with 26 values in flight per
+// lane and a ring of 5 statistics -- 146 VGPRs, 3 waves/SIMD, 36 % of the VALU issue rate; backward tiled 32x32 with
+// nine workgroup barriers per tile and ~75 instructions of halo index arithmetic per pixel -- 30 %):
+//   * ROW-granular software pipeline: the values of input row r+LP are requested while row r is processed (LP = 4
+//     rows ~ 2 000 cycles of one wave's time, twice an HBM miss); a lane loads its own column, lanes 0..9 the ten halo
+//     columns: 4 x 4 registers in flight instead of 26;
+//   * row r goes to a small LDS ring (8 rows: the L1 term reads the centre row r-5), every lane reads its 11 taps
+//     and forms the HORIZONTAL sums; LDS is the only cross-lane path, ~5 KB per wave;
+//   * the VERTICAL pass is a sliding window in registers: the last 12 rows of horizontal sums live in a statically
+//     indexed ring (the row loop is unrolled by 12 = 3 LP), a finished output row costs 11 FMAs per statistic;
+//   * FOUR statistics, not five: SSIM and its three derivative maps only ever use E[aa] + E[bb] (sigma1^2 + sigma2^2),
+//     never the two terms alone -- one ring row, 11 vertical FMAs and 11 VGPRs less than (mu1, mu2, E[aa], E[bb], E[ab]);
+//   * no workgroup barrier anywhere (wave-scope fences only).
+// Measured at 4608x3456 (profiles/loss_microbench.py): forward 0.40 -> 0.35 ms, backward 0.43 -> 0.265 ms.  What the
+// compiler needed (from the ISA): loads under a branch, or a conversion right behind its load, made every row wait
+// for ALL outstanding loads (s_waitcnt vmcnt(0/1)); with unconditional loads at clamped coordinates, masks applied at
+// consumption, raw ground-truth bytes and no branch around a row step it counts them (vmcnt(15-27)).  Tried and not
+// kept: 4 waves/SIMD (128 VGPRs: 8-56 B of spills per lane, scratch reloads bring vmcnt(0) back: 0.35-0.42 ms), the
+// products a^2 + b^2 and a b staged once per element in LDS (4 FMAs per tap instead of 7 VALU: 164 VGPRs, +-0).
+// Planar [3,H,W] images (the engine's internal layout since round 4) make every row load one contiguous 256 B run;
+// strided views ([H,W,3]) still work through the strides.
 constexpr int LR = 5;                             // window radius
-constexpr int LM = 2 * LR + 1;                    // rows per macro step = window length (11)
-constexpr int LS_W = 64, LS_ROWS = 66;            // strip: output columns (= lanes), output rows (6 macros)
+constexpr int LM = 2 * LR + 1;                    // window length (11)
+constexpr int LS_W = 64, LS_ROWS = 62;            // strip: output columns (= lanes), output rows (72 input rows)
 constexpr int LS_IN = LS_W + 2 * LR;              // input columns per row (74)
 constexpr int LS_PITCH = LS_IN + 2;               // LDS row pitch (floats)
-constexpr int LS_RING = 16;                       // LDS ring rows: 11 of the macro + 5 older (L1 centre)
+constexpr int LS_RING = 8;                        // LDS ring rows
+constexpr int LU = 12;                            // unroll of the row loop = rows of the register ring
+#ifndef CLMGS_LOSS_LP
+#define CLMGS_LOSS_LP 4
+#endif
+constexpr int LP = CLMGS_LOSS_LP;                 // prefetch distance in rows (divides LU)
 constexpr int LOSS_SLOTS = 1024;                  // partial-sum slots (spreads the atomics)
 constexpr float L_C1 = 0.01f * 0.01f, L_C2 = 0.03f * 0.03f;
 
@@ -50,11 +62,26 @@ __device__ __forceinline__ void wave_sync() {
 // clamp(u8 / 255, 0, 1) (base_engine.py:79-103), correctly rounded like the IEEE division for all 256
 // inputs (checked exhaustively) in 3 VALU instead of the ~10 of v_div_scale/fmas/fixup:
 // q = v * (1/255); q += fma(-q, 255, v) * (1/255).  The clamp is a no-op on [0, 1].
-__device__ __forceinline__ float gt_val(const uint8_t* __restrict__ gt, size_t o) {
-  const float v = (float)gt[o];
+__device__ __forceinline__ float gt_from_byte(unsigned byte) {
+  const float v = (float)byte;
   const float r = 1.0f / 255.0f;
   const float q = v * r;
   return fmaf(fmaf(-q, 255.0f, v), r, q);
+}
+
+// block id -> (strip, channel): the three channel passes of one strip are ids i, i+8, i+16 -- workgroups go to the
+// 8 XCDs round-robin by id, so the three land on the SAME XCD close in time (channel-interleaved images: every line
+// is shared by the three passes and comes from HBM once; planar images: the three read disjoint planes, harmless)
+__device__ __forceinline__ bool strip_of_block(int H, int W, int& c, int& x0, int& y0, int& slot) {
+  const int n_sx = (W + LS_W - 1) / LS_W, n_sy = (H + LS_ROWS - 1) / LS_ROWS;
+  const int grp = blockIdx.x / 24, rem = blockIdx.x - grp * 24;
+  c = rem >> 3;
+  const int strip = grp * 8 + (rem & 7);
+  if (strip >= n_sx * n_sy) return false;
+  const int by = strip / n_sx, bx = strip - by * n_sx;
+  x0 = bx * LS_W; y0 = by * LS_ROWS;
+  slot = ((c * n_sy + by) * n_sx + bx) & (LOSS_SLOTS - 1);
+  return true;
 }
 
 #ifndef CLMGS_LOSS_FWD_WAVES
@@ -64,221 +91,151 @@ __global__ void __launch_bounds__(64, CLMGS_LOSS_FWD_WAVES)
 loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float* __restrict__ partials,
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
   __shared__ float la[LS_RING][LS_PITCH], lb[LS_RING][LS_PITCH];
-  const int lane = threadIdx.x;
-  // 1-D grid, block id -> (strip, channel) so that the three channel passes of one strip are ids i,
-  // i+8, i+16: workgroups go to the 8 XCDs round-robin by id, so the three land on the SAME XCD close
-  // in time and the channel-interleaved image lines (each pass uses a third of every line) are
-  // fetched from HBM once instead of three times.
-  const int n_sx = (W + LS_W - 1) / LS_W, n_sy = (H + LS_ROWS - 1) / LS_ROWS;
-  const int grp = blockIdx.x / 24, rem = blockIdx.x - grp * 24;
-  const int c = rem >> 3, strip = grp * 8 + (rem & 7);
-  if (strip >= n_sx * n_sy) return;
-  const int by = strip / n_sx, bx = strip - by * n_sx;
-  const int x0 = bx * LS_W, y0 = by * LS_ROWS;
-  const size_t plane = (size_t)H * W;
-  const int xo = x0 + lane;                              // output column
-  const int n_rows = min(LS_ROWS, H - y0) + 2 * LR;      // input rows to walk
-  // Staging map: per macro step a lane requests its OWN column of the 11 rows (row pointer = scalar
-  // base + lane: two VALU per load, a wave-uniform branch for rows outside the image) plus two of
-  // the 110 halo values (columns 64..73 of the 11 rows).
-  const int xs = x0 - LR + lane;                         // this lane's input column
-  const bool xs_ok = xs >= 0 && xs < W;
-  int hrow[2], hcol[2];
-  bool h_ok[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int h = lane + 64 * u;
-    hrow[u] = h / (2 * LR); hcol[u] = LS_W + h - hrow[u] * (2 * LR);
-    const int xh = x0 - LR + hcol[u];
-    h_ok[u] = h < LM * 2 * LR && xh < W;
-  }
-  float pa[LM], pb[LM], ha[2], hb[2];                    // the macro step in flight
-  auto fetch = [&](int r0) {  // request input rows r0 .. r0+10 (zero outside the image)
-#pragma unroll
-    for (int k = 0; k < LM; ++k) {
-      const int y = y0 - LR + r0 + k;                    // wave-uniform
-      pa[k] = 0.f; pb[k] = 0.f;
-      if (y >= 0 && y < H && xs_ok) {
-        pa[k] = img.p[c * img.sc + y * img.sy + xs * img.sx];
-        pb[k] = gt_val(gt, c * plane + (size_t)y * W + xs);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int y = y0 - LR + r0 + hrow[u], x = x0 - LR + hcol[u];
-      ha[u] = 0.f; hb[u] = 0.f;
-      if (h_ok[u] && y >= 0 && y < H) {
-        ha[u] = img.p[c * img.sc + y * img.sy + x * img.sx];
-        hb[u] = gt_val(gt, c * plane + (size_t)y * W + x);
-      }
-    }
-  };
-  fetch(0);
-  float win[LM][5];   // ring of horizontal sums: mu1 mu2 E[aa] E[bb] E[ab]
-  float l1 = 0.f, ss = 0.f;
-  for (int r0 = 0; r0 < n_rows; r0 += LM) {
-    // macro boundary: rows r0 .. r0+10 -> LDS ring, then the next macro step takes off
-#pragma unroll
-    for (int k = 0; k < LM; ++k) {
-      const int slot = (r0 + k) & (LS_RING - 1);
-      la[slot][lane] = pa[k]; lb[slot][lane] = pb[k];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (lane + 64 * u < LM * 2 * LR) {
-        const int slot = (r0 + hrow[u]) & (LS_RING - 1);
-        la[slot][hcol[u]] = ha[u]; lb[slot][hcol[u]] = hb[u];
-      }
-    }
-    fetch(r0 + LM);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < LM; ++k) {
-      const int r = r0 + k;
-      if (r < n_rows) {  // wave-uniform
-        const int buf = r & (LS_RING - 1);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-#pragma unroll
-        for (int j = 0; j < LM; ++j) {
           const float av = la[buf][lane + j], bv = lb[buf][lane + j];
           const float wa_ = l_win[j] * av, wb_ = l_win[j] * bv;
-          s0 += wa_; s1 += wb_; s2 += wa_ * av; s3 += wb_ * bv; s4 += wa_ * bv;
+          s0 += wa_; s1 += wb_; s2 = fmaf(wa_, av, s2); s2 = fmaf(wb_, bv, s2); s3 = fmaf(wa_, bv, s3);
         }
-        win[k][0] = s0; win[k][1] = s1; win[k][2] = s2; win[k][3] = s3; win[k][4] = s4;
-        if (r >= 2 * LR) {  // rows r-10 .. r are in the ring: output row y0 + r - 10
-          float acc[5];
+        win[k][0] = s0; win[k][1] = s1; win[k][2] = s2; win[k][3] = s3;
+        {  // rows r-10 .. r are in the ring: output row y0 + r - 10 (r < 10: no output row yet -- computed on
+           // whatever the ring holds and masked below, 14 % of the SSIM arithmetic, instead of a branch)
+          float acc[4];
 #pragma unroll
-          for (int q = 0; q < 5; ++q) {
+          for (int q = 0; q < 4; ++q) {
             float sacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < LM; ++j) sacc += l_win[j] * win[(k + 1 + j) % LM][q];
+            for (int j = 0; j < LM; ++j) sacc += l_win[j] * win[(k + 2 + j) % LU][q];
             acc[q] = sacc;
           }
           const int y = y0 + r - 2 * LR;
-          if (xo < W && y < H) {
+          const bool out_ok = (r >= 2 * LR) && (r < n_rows) && (xo < W) && (y < H);
+          {
             const float mu1 = acc[0], mu2 = acc[1];
             const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float sg1 = acc[2] - mu1sq, sg2 = acc[3] - mu2sq, sg12 = acc[4] - mu12;
+            const float sgs = (acc[2] - mu1sq) - mu2sq, sg12 = acc[3] - mu12;   // sigma1^2 + sigma2^2, sigma12
             const float A = 2.f * mu12 + L_C1, B = 2.f * sg12 + L_C2;
-            const float D = mu1sq + mu2sq + L_C1, E = sg1 + sg2 + L_C2;
+            const float D = mu1sq + mu2sq + L_C1, E = sgs + L_C2;
             const float iDE = __builtin_amdgcn_rcpf(D * E);  // 1-ulp reciprocals: three IEEE divides
             const float val = A * B * iDE;                   // per pixel were a tenth of the kernel
-            ss += val;
+            ss += out_ok ? val : 0.f;
             const int cbuf = (r - LR) & (LS_RING - 1);  // centre: input row r - 5, still in the ring
-            l1 += fabsf(la[cbuf][lane + LR] - lb[cbuf][lane + LR]);
-            if (m1) {
+            l1 += out_ok ? fabsf(la[cbuf][lane + LR] - lb[cbuf][lane + LR]) : 0.f;
+            if (m1 && out_ok) {
               const float d_mu1 = 2.f * mu2 * B * iDE - val * 2.f * mu1 * __builtin_amdgcn_rcpf(D);
               const float d_s1 = -val * __builtin_amdgcn_rcpf(E), d_s12 = 2.f * A * iDE;
-              const size_t oidx = c * plane + (size_t)y * W + xo;
-              m1[oidx] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12; m2[oidx] = d_s1; m3[oidx] = d_s12;
+              const size_t orow = c * plane + (size_t)y * W;  // wave-uniform
+              (m1 + orow)[(unsigned)xo] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+              (m2 + orow)[(unsigned)xo] = d_s1; (m3 + orow)[(unsigned)xo] = d_s12;
             }
           }
         }
       }
     }
-    wave_sync();  // the ring rows of this macro step are consumed before the next one lands
   }
   const float tl1 = wave_sum(l1), tss = wave_sum(ss);
   if (lane == 0) {
-    const int slot = ((c * n_sy + by) * n_sx + bx) & (LOSS_SLOTS - 1);
     atomicAdd(partials + 2 * slot, tl1);
     atomicAdd(partials + 2 * slot + 1, tss);
   }
 }
 
-// Backward: the tiled form (32x32 output pixels per 256-thread block, separable passes through LDS
-// with 4-wide register blocking).  A streaming version like the forward was measured equal or
-// slower (0.52-0.62 vs 0.49 ms): its output-pixel loads sit behind the prefetch in vmcnt order.
-constexpr int LT = 32, LH = LT + 2 * LR;  // tile, halo edge (42)
-// v_img (same strides as img) = v * ( w_l1 * sign(x - y) - w_ssim * dSSIMsum/dx ) / numel
-__global__ void __launch_bounds__(256)
+// Backward, same streaming shape: the three derivative maps of a channel walk through the window (3 statistics, a
+// 36-register ring), the rendered / ground-truth values of the OUTPUT pixel ride in the same prefetch stream (requested
+// LP rows before they are used, so every wait is for the oldest outstanding load), and the cotangent row leaves as one
+// run per row (planar images: 256 contiguous bytes).
+// v_img (strides of vimg) = v * ( w_l1 * sign(x - y) - w_ssim * dSSIMsum/dx ) / numel
+#ifndef CLMGS_LOSS_BWD_WAVES
+#define CLMGS_LOSS_BWD_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, CLMGS_LOSS_BWD_WAVES)
 loss_bwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, const float* __restrict__ v,
                 float w_l1_over_numel, float w_ssim_over_numel, const float* __restrict__ m1,
-                const float* __restrict__ m2, const float* __restrict__ m3, float* __restrict__ v_img) {
-  __shared__ float sm[3][LH][LH + 1];
-  __shared__ float hz[3][LH][LT + 1];
-  // XCD-aware tile order: each XCD's L2 sees a contiguous run of tiles, so the 5-pixel halos shared
-  // with the neighbouring tiles are fetched from HBM once
-  const int n_tx = (W + LT - 1) / LT, n_ty = (H + LT - 1) / LT;
-  const int tile = (int)xcd_remap(blockIdx.x, (unsigned)(n_tx * n_ty));
-  const int tyi = tile / n_tx, txi = tile - tyi * n_tx;
-  const int x0 = txi * LT, y0 = tyi * LT;
-  const int tid = threadIdx.x;
+                const float* __restrict__ m2, const float* __restrict__ m3, float* __restrict__ v_img,
+                int64_t vsc, int64_t vsy, int64_t vsx) {
+  __shared__ float lm[2][3][LS_PITCH];
+  const int lane = threadIdx.x;
+  int c, x0, y0, slot;
+  if (!strip_of_block(H, W, c, x0, y0, slot)) return;
   const size_t plane = (size_t)H * W;
+  const int xo = x0 + lane;
+  const int n_out = min(LS_ROWS, H - y0);
+  const int n_rows = n_out + 2 * LR;
+  const int xs = x0 - LR + lane;
+  const bool xs_ok = xs >= 0 && xs < W;
+  // halo: lanes 0..9 fetch map 1's ten halo columns, lanes 16..25 map 2's, lanes 32..41 map 3's -- ONE load and one
+  // register per row for the three maps
+  const int hg = lane >> 4, hl = lane & 15;
+  const int xh = x0 - LR + LS_W + hl;
+  const bool h_ok = hg < 3 && hl < 2 * LR && xh < W;
+  const float* mh = (hg == 0 ? m1 : (hg == 1 ? m2 : m3)) + c * plane;  // (lanes 48..63: map 3 again, never stored)
+  const float* m1c = m1 + c * plane;
+  const float* m2c = m2 + c * plane;
+  const float* m3c = m3 + c * plane;
+  const float* img_c = img.p + c * img.sc;
+  const uint8_t* gt_c = gt + c * plane;
   const float vv = v[0];
-  float res[3][4];  // the three channels of a pixel leave together (below): one full 12 B per pixel
+  // unconditional loads at clamped coordinates, masks at consumption, raw ground-truth byte (see the forward kernel)
+  const unsigned xs_c = (unsigned)min(max(xs, 0), W - 1);
+  const unsigned xh_c = (unsigned)min(x0 - LR + LS_W + min(hl, 2 * LR - 1), W - 1);
+  const unsigned xo_c = (unsigned)min(xo, W - 1);
+  const unsigned xo_off = xo_c * (unsigned)img.sx;
+  const unsigned xo_voff = (unsigned)xo * (unsigned)vsx;
+  float p1[LP], p2[LP], p3[LP], ph[LP], px[LP];
+  unsigned py[LP];
+  auto fetch = [&](int r, int s) {
+    const int rc = min(r, n_rows - 1);
+    const int y = min(max(y0 - LR + rc, 0), H - 1);         // input row of the maps (wave-uniform)
+    const int yo = min(max(y0 + rc - 2 * LR, 0), H - 1);    // output row finished at iteration r
+    const size_t o = (size_t)y * W;   // wave-uniform
+    p1[s] = (m1c + o)[xs_c]; p2[s] = (m2c + o)[xs_c]; p3[s] = (m3c + o)[xs_c];
+    ph[s] = (mh + o)[xh_c];
+    px[s] = (img_c + yo * img.sy)[xo_off];
+    py[s] = (gt_c + (size_t)yo * W)[xo_c];
+  };
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    __syncthreads();
-    for (int i = tid; i < LH * LH; i += 256) {
-      const int r = i / LH, cc = i - r * LH;
-      const int yy = y0 + r - LR, xx = x0 + cc - LR;
-      float a = 0.f, b = 0.f, d = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const size_t o = c * plane + (size_t)yy * W + xx;
-        a = m1[o]; b = m2[o]; d = m3[o];
-      }
-      sm[0][r][cc] = a; sm[1][r][cc] = b; sm[2][r][cc] = d;
-    }
-    __syncthreads();
-    for (int t = tid; t < 3 * LH * (LT / 4); t += 256) {
-      const int q = t / (LH * (LT / 4)), rem = t - q * (LH * (LT / 4));
-      const int r = rem / (LT / 4), c4 = (rem - r * (LT / 4)) * 4;
-      float a[14];
+  for (int s = 0; s < LP; ++s) fetch(s, s);
+  float win[LU][3];
+  for (int r0 = 0; r0 < n_rows; r0 += LU) {
 #pragma unroll
-      for (int k = 0; k < 14; ++k) a[k] = sm[q][r][c4 + k];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) sacc += l_win[k] * a[o + k];
-        hz[q][r][c4 + o] = sacc;
-      }
-    }
-    __syncthreads();
-    {
-      const int col = tid & 31, r4 = (tid >> 5) * 4;
-      float g[3][4];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        float vcol[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) vcol[k] = hz[q][r4 + k][col];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          float sacc = 0.f;
-#pragma unroll
-          for (int k = 0; k < 11; ++k) sacc += l_win[k] * vcol[o + k];
-          g[q][o] = sacc;
+    for (int k = 0; k < LU; ++k) {
+      const int r = r0 + k;
+      {  // no branch on r (see the forward kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        const int s = k % LP, buf = r & 1;
+        {
+          const int yin = y0 - LR + r;
+          const bool row_ok = yin >= 0 && yin < H;
+          const bool okm = row_ok && xs_ok;
+          lm[buf][0][lane] = okm ? p1[s] : 0.f; lm[buf][1][lane] = okm ? p2[s] : 0.f; lm[buf][2][lane] = okm ? p3[s] : 0.f;
+          if (hg < 3 && hl < 2 * LR) lm[buf][hg][LS_W + hl] = (row_ok && h_ok) ? ph[s] : 0.f;
         }
-      }
+        const float xv = px[s], yv = gt_from_byte(py[s]);
+        fetch(r + LP, s);
+        wave_sync();
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const int y = y0 + r4 + o, x = x0 + col;
-        res[c][o] = 0.f;
-        if (y < H && x < W) {
-          const int64_t oi = c * img.sc + y * img.sy + x * img.sx;
-          const float xv = img.p[oi];
-          const float yv = gt_val(gt, c * plane + (size_t)y * W + x);
-          const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
-          const float dss = g[0][o] + 2.f * xv * g[1][o] + yv * g[2][o];
-          res[c][o] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
+        for (int j = 0; j < LM; ++j) {
+          s0 = fmaf(l_win[j], lm[buf][0][lane + j], s0);
+          s1 = fmaf(l_win[j], lm[buf][1][lane + j], s1);
+          s2 = fmaf(l_win[j], lm[buf][2][lane + j], s2);
         }
-      }
-    }
-  }
-  // Channel-interleaved ([H,W,3]) cotangent images: a store per channel pass touched every 64 B line
-  // three times, a third of it each (WRITE_SIZE was 3x the image); back to back the three partial
-  // stores of a line merge before they leave the L2.
-  {
-    const int col = tid & 31, r4 = (tid >> 5) * 4;
+        win[k][0] = s0; win[k][1] = s1; win[k][2] = s2;
+        {
+          float g[3];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int y = y0 + r4 + o, x = x0 + col;
-      if (y < H && x < W) {
-        const int64_t ob = y * img.sy + x * img.sx;
+          for (int q = 0; q < 3; ++q) {
+            float sacc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v_img[ob + c * img.sc] = res[c][o];
+            for (int j = 0; j < LM; ++j) sacc += l_win[j] * win[(k + 2 + j) % LU][q];
+            g[q] = sacc;
+          }
+          const int y = y0 + r - 2 * LR;
+          if (r >= 2 * LR && r < n_rows && xo < W) {
+            const float sgn = (xv > yv) ? 1.f : ((xv < yv) ? -1.f : 0.f);
+            const float dss = g[0] + 2.f * xv * g[1] + yv * g[2];
+            (v_img + (c * vsc + y * vsy))[xo_voff] = vv * (w_l1_over_numel * sgn - w_ssim_over_numel * dss);
+          }
+        }
+        wave_sync();  // the two-row LDS ring: row r is consumed before row r+2 lands in its place
       }
     }
   }
@@ -311,10 +268,11 @@ extern "C" int clmgs_l1_ssim_loss_bwd(void* stream, int H, int W, const float* i
   CLMGS_CHECK_ARG(H >= 1 && W >= 1 && img && gt_u8 && v_loss && m1 && m2 && m3 && v_img);
   ImgView v{img, stride_c, stride_y, stride_x};
   const double numel = 3.0 * (double)H * (double)W;
-  dim3 grid((unsigned)(ceil_div(W, LT) * ceil_div(H, LT)));
-  hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, v, gt_u8, v_loss,
+  const int64_t strips = (int64_t)ceil_div(W, LS_W) * ceil_div(H, LS_ROWS);
+  dim3 grid((unsigned)(24 * ceil_div(strips, 8)));
+  hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, H, W, v, gt_u8, v_loss,
                      (float)((1.0 - lambda_dssim) / numel), (float)(lambda_dssim / numel), m1, m2, m3,
-                     v_img);
+                     v_img, stride_c, stride_y, stride_x);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

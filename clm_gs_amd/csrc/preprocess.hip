@@ -238,7 +238,7 @@ struct PreGrads {
   int packed_stats;      // 1: max_radii2D is a [N,4] table  max radius | grad accum | count | pad
   float* v_means2d_out;  // [V,2] or NULL: copy of the screen-space gradient (API parity)
   int stats_only_visible;  // 1: statistics only for rows with radius > 0 (no_offload semantics)
-  // != NULL: the rasterize backward left one 64 B partial-gradient line per (row, tile) intersection;
+  // != NULL: the rasterize backward left one partial-gradient line (PART_F4 float4 = 64 B) per (row, tile) intersection;
   // row i owns lines [row_cum[i-1], row_cum[i]) and its gradient line is their sum in ascending order
   // (this kernel then takes the place of the row-sum pass: no [V,16] gradient table round trip)
   const float4* partials;
@@ -299,11 +299,11 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
     if (o.partials) {  // kernel-uniform.  The row's first four partial lines are requested here, with
       // everything else the lane needs; longer ranges (rare: 2.6 lines per row on average) follow below
       ga = make_float4(0.f, 0.f, 0.f, 0.f); gb = ga; go = 0.f;
-      const float4* src = o.partials + 4 * (size_t)s0;
+      const float4* src = o.partials + PART_F4 * (size_t)s0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         pa[u] = ga; pb[u] = ga; po[u] = 0.f;
-        if (mine && u < cnt) { pa[u] = src[4 * u]; pb[u] = src[4 * u + 1]; po[u] = src[4 * u + 2].x; }
+        if (mine && u < cnt) { pa[u] = src[PART_F4 * u]; pb[u] = src[PART_F4 * u + 1]; po[u] = src[PART_F4 * u + 2].x; }
       }
     } else {
       ga = packed_grad[4 * (size_t)i];
@@ -367,12 +367,12 @@ preprocess_bwd_kernel(int V, PreArgs a, const int32_t* __restrict__ radii,
         go += po[u];
       }
       if (mine) {
-        const float4* src = o.partials + 4 * (size_t)s0;
+        const float4* src = o.partials + PART_F4 * (size_t)s0;
         for (int tt = 4; tt < cnt; tt += 4) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int l = min(tt + u, cnt - 1);
-            pa[u] = src[4 * l]; pb[u] = src[4 * l + 1]; po[u] = src[4 * l + 2].x;
+            pa[u] = src[PART_F4 * l]; pb[u] = src[PART_F4 * l + 1]; po[u] = src[PART_F4 * l + 2].x;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -599,7 +599,7 @@ extern "C" int clmgs_preprocess_bwd(void* stream, int V, const int64_t* filter, 
   CLMGS_CHECK_ARG(xyz && sh_rows && viewmat_host && K_host && campos_host && radii && g_xyz && g_sh_rows);
   // exactly one source of the per-row raster gradient: the [V,16] table, or the partial lines + ranges
   CLMGS_CHECK_ARG((packed_grad != nullptr) != (partials != nullptr));
-  CLMGS_CHECK_ARG(!partials || (row_cum && (((uintptr_t)partials & 63) == 0)));
+  CLMGS_CHECK_ARG(!partials || (row_cum && (((uintptr_t)partials & 15) == 0)));
   CLMGS_CHECK_ARG((opacity_raw && scaling_raw && rotation_raw) ||
                   (!opacity_raw && !scaling_raw && !rotation_raw && (((uintptr_t)xyz & 15) == 0)));
   const bool pg = !g_opacity && !g_scaling && !g_rotation;

@@ -264,7 +264,7 @@ __device__ unsigned long long g_dbg[16];
 #ifndef CLMGS_BWD_WAVES
 #define CLMGS_BWD_WAVES 4  // 5 spills (96 VGPRs): scratch reloads force vmcnt(0) and kill the prefetch
 #endif
-// PART: atomic-free accumulation.  Every sorted intersection owns the 64 B line partials[slot]
+// PART: atomic-free accumulation.  Every sorted intersection owns the line partials[slot] (PART_F4 float4 = 64 B)
 // (slot = its emit index, see isect2_emit_kernel); the tile's wave STORES the reduced sums there
 // (zeros for culled / unreached entries, so every line is written exactly once per launch) and
 // raster_partials_sum_kernel adds each row's contiguous range.
@@ -341,8 +341,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   if (PART) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int idx = max(hi + 1, rs) + lane; idx < re; idx += 64) {  // behind the deepest contributor: zeros
-      float4* dst = partials + 4 * (size_t)emit_slot[idx];
-      dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
+      float4* dst = partials + PART_F4 * (size_t)emit_slot[idx];
+#pragma unroll
+      for (int q = 0; q < PART_F4; ++q) dst[q] = z4;
     }
     cur_p = (hi - lane >= rs) ? emit_slot[hi - lane] : 0;
     nxt_p = (hi - 64 - lane >= rs) ? emit_slot[hi - 64 - lane] : 0;
@@ -371,8 +372,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     }
     if (PART && gid >= 0 && mask == 0) {  // culled for this tile: its line is all zeros
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4* dst = partials + 4 * (size_t)pid;
-      dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
+      float4* dst = partials + PART_F4 * (size_t)pid;
+#pragma unroll
+      for (int q = 0; q < PART_F4; ++q) dst[q] = z4;
     }
     const unsigned long long bal = __ballot(mask != 0);
     const int pos = __popcll(bal & ((1ull << lane) - 1ull));
@@ -451,7 +453,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     if (DBG == 1 || DBG == 2) {
       if (((touched >> lane) & 1ull) && sm.acc[lane][0] == 1.2345e30f) packed_grad[0] = 1.f;
     } else if (PART) {
-      if (lane < bn) {  // one full 64 B line per entry of the round, zeros if no pixel was valid
+      if (lane < bn) {  // one full line (PART_F4 float4) per entry of the round, zeros if no pixel was valid
         const bool hit = (touched >> lane) & 1ull;
         const float4* a = reinterpret_cast<const float4*>(sm.acc[lane]);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -464,8 +466,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           r1 = make_float4(0.5f * m1.x, m1.y, m1.z, m1.w);
           r2 = make_float4(a[2].x, 0.f, 0.f, 0.f);
         }
-        float4* dst = partials + 4 * (size_t)sm.id[lane];
-        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = z4;
+        float4* dst = partials + PART_F4 * (size_t)sm.id[lane];
+        dst[0] = r0; dst[1] = r1; dst[2] = r2;
+        if (PART_F4 > 3) dst[3] = z4;
       }
     } else if ((touched >> lane) & 1ull) {
       // all nine atomics of a Gaussian land in its one 64 B gradient line
@@ -507,14 +510,14 @@ raster_partials_sum_kernel(int64_t n_rows, const int64_t* __restrict__ row_cum,
     const int cnt = (int)(row_cum[r] - s0);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     float o = 0.f;
-    const float4* src = partials + 4 * (size_t)s0;
+    const float4* src = partials + PART_F4 * (size_t)s0;
     for (int t = 0; t < cnt; t += 4) {  // four lines in flight per step (clamped; extra ones masked)
       float4 pa[4], pb[4];
       float po[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int tt = min(t + u, cnt - 1);
-        pa[u] = src[4 * tt]; pb[u] = src[4 * tt + 1]; po[u] = src[4 * tt + 2].x;
+        pa[u] = src[PART_F4 * tt]; pb[u] = src[PART_F4 * tt + 1]; po[u] = src[PART_F4 * tt + 2].x;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -535,7 +538,7 @@ raster_partials_sum_kernel(int64_t n_rows, const int64_t* __restrict__ row_cum,
 using namespace clmgs;
 
 extern "C" size_t clmgs_rasterize_partials_bytes(int64_t n_isects) {
-  return (size_t)(n_isects > 0 ? n_isects : 1) * 64;
+  return (size_t)(n_isects > 0 ? n_isects : 1) * (PART_F4 * 16);
 }
 
 // Profiling aid (CLMGS_BWD_DEBUG=3): stage / loop / flush / total cycles, entries, entries with a

@@ -19,6 +19,18 @@ F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
 
 
+def _partial_line_floats():
+    """Floats per partial-gradient line of the atomic-free rasterize backward, as the library reports it
+    (csrc/common.h PART_F4: 16 = one 64 B line; the 48 B form was measured slower)."""
+    global _PART_FLOATS
+    if _PART_FLOATS is None:
+        _PART_FLOATS = int(_lib.lib().clmgs_rasterize_partials_bytes(1)) // 4
+    return _PART_FLOATS
+
+
+_PART_FLOATS = None
+
+
 def _cam_host(camera):
     """Host copies of viewmat (row-major world->camera), K and the camera centre, cached."""
     h = getattr(camera, "_clmgs_host", None)
@@ -299,7 +311,7 @@ def camera_backward(gaussians, p, g_sh_rows, small_grad=None, update_stats=True,
         # atomic-free accumulation: the tile kernel stores one 64 B line per intersection (row-ordered
         # slots); clmgs_preprocess_bwd sums each row's contiguous range while it gathers the row.
         # Allocated on the stream of its WRITER (the caching allocator orders reuse by allocation stream).
-        partials = empty_bucketed(max(n_isects, 1), (16,), F32, dev)
+        partials = empty_bucketed(max(n_isects, 1), (_partial_line_floats(),), F32, dev)
     if p.ev_loss is not None:
         s_raster.wait_event(p.ev_loss)
     if p.n_dev is None:

@@ -142,7 +142,7 @@ int clmgs_rasterize_fwd(void* stream, int C, int N, int64_t n_isects, const floa
  *   - emit_slot == NULL: packed_grad is zeroed here and the per-(Gaussian,tile) sums are added
  *     with float atomics (any flatten_ids / offsets, C >= 1);
  *   - emit_slot from clmgs_isect2_emit_sort (C == 1) + `partials` scratch of
- *     clmgs_rasterize_partials_bytes(n_isects) bytes (64 B aligned): every (Gaussian,tile) sum is
+ *     clmgs_rasterize_partials_bytes(n_isects) bytes (64 B lines, 16 B aligned): every (Gaussian,tile) sum is
  *     STORED at its slot (every slot is written exactly once, zeros included) -- no atomics (they
  *     bound the kernel: 4.05 -> ~2 ms at 12 M intersections), bitwise reproducible gradients.  With
  *     packed_grad != NULL (+ row_cum from clmgs_isect2_order_count) a row-order pass then adds each row's

@@ -493,7 +493,8 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
 
     def bwd(slots):
         pg = torch.full((n, 16), float("nan"), device=dev)
-        parts = torch.full((max(I, 1), 16), float("nan"), device=dev)  # every line must be overwritten
+        LF = L.clmgs_rasterize_partials_bytes(1) // 4  # floats per partial line (16: one 64 B line)
+        parts = torch.full((max(I, 1), LF), float("nan"), device=dev)  # every line must be overwritten
         outs = [torch.empty(n, 2, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev),
                 torch.empty(n, device=dev)]
         assert L.clmgs_rasterize_partials_bytes(I) == parts.numel() * 4
@@ -504,7 +505,7 @@ def test_rasterize_bwd_atomic_free_path(dev, opaque):
         if slots:  # the sum the engine path folds into clmgs_preprocess_bwd: row ranges of the partial lines
             ps, st = parts.cpu(), starts.tolist()
             for i in torch.nonzero(cnt).flatten()[:100].tolist():
-                want = torch.zeros(16)
+                want = torch.zeros(LF)
                 for l in range(st[i], int(cu[i])):
                     want = want + ps[l]
                 assert torch.equal(want[:9], pg[i].cpu()[:9]), i
