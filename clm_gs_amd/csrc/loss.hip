@@ -30,8 +30,9 @@ namespace clmgs {
 // consumption, raw ground-truth bytes and no branch around a row step it counts them (vmcnt(15-27)).  Tried and not
 // kept: 4 waves/SIMD (128 VGPRs: 8-56 B of spills per lane, scratch reloads bring vmcnt(0) back: 0.35-0.42 ms), the
 // products a^2 + b^2 and a b staged once per element in LDS (4 FMAs per tap instead of 7 VALU: 164 VGPRs, +-0).
-// Planar [3,H,W] images (the engine's internal layout since round 4) make every row load one contiguous 256 B run;
-// strided views ([H,W,3]) still work through the strides.
+// Images are read through their strides: the renderer's [H,W,3] buffer (the engine's layout) and planar [3,H,W]
+// tensors measure the same in the forward, 5 % apart in the backward (0.281 vs 0.267 ms) -- not worth a second
+// layout in the tile kernels.
 constexpr int LR = 5;                             // window radius
 constexpr int LM = 2 * LR + 1;                    // window length (11)
 constexpr int LS_W = 64, LS_ROWS = 62;            // strip: output columns (= lanes), output rows (72 input rows)
@@ -91,6 +92,62 @@ __global__ void __launch_bounds__(64, CLMGS_LOSS_FWD_WAVES)
 loss_fwd_kernel(int H, int W, ImgView img, const uint8_t* __restrict__ gt, float* __restrict__ partials,
                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ m3) {
   __shared__ float la[LS_RING][LS_PITCH], lb[LS_RING][LS_PITCH];
+  const int lane = threadIdx.x;
+  int c, x0, y0, slot;
+  if (!strip_of_block(H, W, c, x0, y0, slot)) return;
+  const size_t plane = (size_t)H * W;
+  const int xo = x0 + lane;                              // output column
+  const int n_rows = min(LS_ROWS, H - y0) + 2 * LR;      // input rows to walk
+  const int xs = x0 - LR + lane;                         // this lane's input column
+  const bool xs_ok = xs >= 0 && xs < W;
+  const int xh = x0 - LR + LS_W + lane;                  // lanes 0..9: one of the ten halo columns 64..73
+  const bool h_ok = lane < 2 * LR && xh < W;
+  const float* img_c = img.p + c * img.sc;
+  const uint8_t* gt_c = gt + c * plane;
+  // The loads are UNCONDITIONAL (coordinates clamped into the image, the masks are applied when a row is consumed)
+  // and the ground-truth byte stays raw until then: straight-line code lets the compiler count the outstanding
+  // loads exactly (s_waitcnt vmcnt(N) with N = what was issued since), whereas loads under a branch -- or a
+  // conversion right behind its load -- made it wait for ALL outstanding loads at every row (vmcnt(0/1): the
+  // prefetch hid nothing; rounds 1-3 had this in their macro-step fetch too).
+  // (32-bit lane offsets against wave-uniform row pointers)
+  const unsigned xs_c = (unsigned)min(max(xs, 0), W - 1);
+  const unsigned xh_c = (unsigned)min(x0 - LR + LS_W + min(lane, 2 * LR - 1), W - 1);  // lanes >= 10 repeat lane 9's address
+  const unsigned xs_off = xs_c * (unsigned)img.sx, xh_off = xh_c * (unsigned)img.sx;
+  float pa[LP], ha[LP];                                  // rows in flight
+  unsigned pb[LP], hb[LP];                               // (raw ground-truth bytes)
+  auto fetch = [&](int r, int s) {  // request input row r into slot s
+    const int y = min(max(y0 - LR + min(r, n_rows - 1), 0), H - 1);  // wave-uniform
+    const float* ir = img_c + y * img.sy;
+    const uint8_t* gr = gt_c + (size_t)y * W;
+    pa[s] = ir[xs_off]; pb[s] = gr[xs_c];
+    ha[s] = ir[xh_off]; hb[s] = gr[xh_c];
+  };
+#pragma unroll
+  for (int s = 0; s < LP; ++s) fetch(s, s);
+  float win[LU][4];   // ring of horizontal sums: mu1 mu2 E[aa]+E[bb] E[ab]
+  float l1 = 0.f, ss = 0.f;
+  for (int r0 = 0; r0 < n_rows; r0 += LU) {
+#pragma unroll
+    for (int k = 0; k < LU; ++k) {
+      const int r = r0 + k;
+      {  // NO branch on r: rows past the strip's end (bottom strips only) run on clamped data and store nothing --
+         // every branch around a step would make the waitcnt analysis assume the step's loads may not have been issued
+        __builtin_amdgcn_sched_barrier(0);  // one row at a time
+        const int s = k % LP, buf = r & (LS_RING - 1);
+        {
+          const int yin = y0 - LR + r;
+          const bool row_ok = yin >= 0 && yin < H;       // wave-uniform; zero padding outside the image
+          const bool okm = row_ok && xs_ok, okh = row_ok && h_ok;
+          la[buf][lane] = okm ? pa[s] : 0.f; lb[buf][lane] = okm ? gt_from_byte(pb[s]) : 0.f;
+          if (lane < 2 * LR) {
+            la[buf][LS_W + lane] = okh ? ha[s] : 0.f; lb[buf][LS_W + lane] = okh ? gt_from_byte(hb[s]) : 0.f;
+          }
+        }
+        fetch(r + LP, s);
+        wave_sync();
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LM; ++j) {
           const float av = la[buf][lane + j], bv = lb[buf][lane + j];
           const float wa_ = l_win[j] * av, wb_ = l_win[j] * bv;
           s0 += wa_; s1 += wb_; s2 = fmaf(wa_, av, s2); s2 = fmaf(wb_, bv, s2); s3 = fmaf(wa_, bv, s3);
