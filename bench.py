@@ -160,6 +160,11 @@ def parse():
                          "(kept for A/B: costs a transposing copy per camera)")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
                     help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality (Z-ordered rows required)")
+    ap.add_argument("--no-trainer-leg", action="store_true",
+                    help="skip the third leg: clm_gs_amd.trainer.training on the bench scene (densify + opacity reset inside the "
+                         "end-to-end clock) -> trainer_img_s / trainer_peak_gpu_bytes")
+    ap.add_argument("--trainer-images", type=int, default=400)
+    ap.add_argument("--trainer-grad-threshold", type=float, default=0.0002)
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -449,6 +454,90 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
                     "both together (profiles/r02_probe_host_link.json); every touched SH row crosses once per direction per batch"},
            "loss_first": round(sum(vals[:k2]) / k2, 6), "loss_last": round(sum(vals[-k2:]) / k2, 6),
            "gt_images": "pinned host, uploaded per batch (train.py:310-312)"}
+    del g
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
+    """Row f1 at full size: the product's own training loop, `clm_gs_amd.trainer.training`, on the
+    bench scene for `--trainer-images` images -- LR schedule per image, the engine call, ONE densify_and_prune (+ the
+    Z-order re-sort of every table) and ONE opacity reset inside the reference's End2endTimer (utils/timer.py:87-111),
+    the evaluation outside it (train.py:438-447) -- with NONE of bench.py's measurement aids (no priming renders, no
+    allocator reservoir, a fresh model).  Reports the reference's own log figures: `end2end total_time ... it/s` and
+    `Max Memory usage`, plus the host time per phase."""
+    import gc
+    import io
+    import re
+
+    from clm_gs_amd import _lib, trainer, utils
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload
+    from clm_gs_amd.synthetic import synth_gaussians
+    n_img = int(a.trainer_images)
+    gc.collect()
+    torch.cuda.empty_cache()
+    for c in cams:  # the loop takes cameras whose ground truth is on the GPU (trainer.training docstring)
+        if c.original_image is None:
+            c.original_image = c.image_host.to("cuda")
+    args = utils.default_args(bsz=bsz, sh_residency="hbm", iterations=n_img,
+                              densify_from_iter=n_img // 4, densification_interval=n_img // 2,
+                              densify_until_iter=3 * n_img // 4, opacity_reset_interval=3 * n_img // 4,
+                              densify_grad_threshold=float(a.trainer_grad_threshold),
+                              # row tables with 5 % of head room, as a training run sizes them (the reference's
+                              # --prealloc_capacity, train.py:107-115): the densification appends in place instead of
+                              # re-allocating all four tables at 1.5x
+                              prealloc_capacity=int(N * 1.05) // 16 * 16)
+    args.clm_offload = True
+    utils.set_args(args)
+    utils.set_img_size(H, W)
+    scene = synth_gaussians(N, seed=0, device="cuda")
+    g = GaussianModelCLMOffload(3)
+    g.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"],
+                          spatial_lr_scale=lr_extent)
+    del scene
+    g.active_sh_degree = 3
+    g.training_setup(args)  # (training() puts the rows in Z-order itself, as after loading a point cloud)
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+
+    class _Scene:
+        cameras_extent = extent
+    log, phases = io.StringIO(), {}
+    ms0 = torch.cuda.memory_stats()
+    t0 = time.perf_counter()
+    timer = trainer.training(g, _Scene, cams, [], log, iterations=n_img, test_iterations=(n_img,), phase_times=phases)
+    wall = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    text = log.getvalue()
+    m = re.search(r"end2end total_time: ([0-9.]+) s, iterations: (\d+), throughput ([0-9.]+) it/s", text)
+    mem = re.findall(r"Max Memory usage: ([0-9.]+) GB", text)
+    dens = re.findall(r"iteration\[(\d+),(\d+)\) densify_and_prune\. Now num of 3dgs: (\d+)", text)
+    psnr = re.findall(r"Evaluating train: L1 ([0-9.eE+-]+) PSNR ([0-9.eE+-]+)", text)
+    first = re.search(r"iteration\[1,\d+\) loss: ([0-9. ]+) image", text)
+    last = re.findall(r"iteration\[\d+,\d+\) loss: ([0-9. ]+) image", text)
+    n_after = int(g.get_xyz.shape[0])
+    out = {"images": n_img, "end2end_total_time_s": float(m.group(1)) if m else None,
+           "iterations_logged": int(m.group(2)) if m else None,
+           "trainer_img_s": float(m.group(3)) if m else None,
+           "trainer_peak_gpu_bytes": int(torch.cuda.max_memory_allocated()),
+           "max_memory_usage_GB_logged": float(mem[-1]) if mem else None,
+           "wall_s_incl_eval": round(wall, 3),
+           "n_gaussians_before_after": [N, n_after],
+           "densify_lines": [[int(x) for x in d] for d in dens],
+           "eval_train_l1_psnr": [float(x) for x in psnr[-1]] if psnr else None,
+           "loss_first_last_batch": [[float(x) for x in first.group(1).split()] if first else None,
+                                     [float(x) for x in last[-1].split()] if last else None],
+           "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items()},
+           "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+           "schedule": {"densify_at_image": n_img // 2, "opacity_reset_at_image": 3 * n_img // 4,
+                        "densify_grad_threshold": float(a.trainer_grad_threshold)},
+           "what": "clm_gs_amd.trainer.training on a fresh model of the bench scene: shuffled epochs over the run's cameras, "
+                   "LR schedule, engine call per batch, one densify_and_prune + Z-order re-sort and one opacity reset INSIDE the "
+                   "End2endTimer, evaluation outside it; no priming, no allocator reservoir; loss lines written one batch late "
+                   "(defer_loss_log) so the host never drains the device between batches"}
     del g
     gc.collect()
     torch.cuda.empty_cache()
@@ -915,6 +1004,17 @@ def main():
             out["host_resident"] = host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
         except Exception as e:  # reported, never fatal for the headline
             out["host_resident"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if (not a.no_trainer_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+            and a.config in ("rubble28m", "rubble10m", "small")):
+        try:
+            gaussians = None
+            out["trainer"] = trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent)
+            out["trainer_img_s"] = out["trainer"]["trainer_img_s"]
+            out["trainer_peak_gpu_bytes"] = out["trainer"]["trainer_peak_gpu_bytes"]
+            if out["trainer_img_s"]:
+                out["trainer_vs_value"] = round(out["trainer_img_s"] / value, 4)
+        except Exception as e:  # reported, never fatal for the headline
+            out["trainer"] = {"trainer_img_s": None, "error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
     sys.stdout.flush()
     if not train_ok:

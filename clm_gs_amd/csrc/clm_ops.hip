@@ -5,6 +5,8 @@
 //
 // All of these are HBM- (or host-link-) bound row/byte movers: a 48-float row is
 // 12 lanes x 16 B, so 64 lanes move 5 1/3 rows per instruction fully coalesced.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace clmgs {
@@ -288,6 +290,95 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
   }
 }
 
+// The [N,48] form of the same kernel (the SH-row tables; what the engine calls every batch): a thread walks
+// float4 column k of rows r, r + S, r + 2S ... -- the grid is a multiple of 3 blocks, so the stride is a multiple of
+// the 12 float4 of a row and neither k nor the learning rates change: no 64-bit division per element (the generic
+// kernel's i / cv), the learning rates are loaded once; the next row id is requested a whole iteration ahead, and
+// the row's stamps, p, m, v and its gradient row are all requested together (the generic form waits for the stamp
+// before it asks for the data: three dependent HBM latencies per element instead of two).
+template <typename IdxT>
+__global__ void __launch_bounds__(256)
+adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                       const int32_t* __restrict__ last_step, const void* __restrict__ rows,
+                       unsigned n_rows, const float* __restrict__ col_lr, float beta1,
+                       float beta2, float eps, int to_step, int bias_correction, int max_replay,
+                       float* __restrict__ g, const int32_t* __restrict__ g_step, float grad_scale,
+                       float ob1, float ob2, int keep_grad) {
+  constexpr int VEC = 4;
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned r_stride = gridDim.x * 256u / 12u;  // (grid is a multiple of 3)
+  unsigned r = t0 / 12u;
+  const int k = (int)(t0 - r * 12u) * VEC;
+  if (r >= n_rows) return;
+  float lr[VEC];
+  vload<VEC>(col_lr + k, lr);
+  int64_t row_next = row_of<IdxT>(rows, (int64_t)r);
+  for (; r < n_rows; r += r_stride) {
+    const int64_t row = row_next;
+    if (r + r_stride < n_rows) row_next = row_of<IdxT>(rows, (int64_t)(r + r_stride));
+    const int64_t o = row * 48 + k;
+    float mm[VEC], vv[VEC], pp[VEC], gg[VEC];
+    int a = last_step[row];
+    const int gs = g_step ? g_step[row] : 0;
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp);
+    if (g) vload<VEC>(g + o, gg);
+    const bool pending = gs > a && gs <= to_step;
+    if (to_step - a <= 0) continue;
+    if (!pending) {
+      bool any_state = false;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) any_state |= (mm[c] != 0.f) | (vv[c] != 0.f);
+      if (!any_state) continue;
+    }
+    auto replay = [&](int from, int to) {
+      const int missed = to - from;
+      if (missed <= 0) return;
+      const int n = min(missed, max_replay);
+      float pw1 = powf(beta1, (float)(from + 1)), pw2 = powf(beta2, (float)(from + 1));
+      for (int j = 0; j < n; ++j) {
+        float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+        if (bias_correction) {
+          inv_bc1 = 1.f / (1.f - pw1);
+          inv_sqrt_bc2 = 1.f / sqrtf(1.f - pw2);
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          mm[c] *= beta1;
+          vv[c] *= beta2;
+          pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
+        }
+        pw1 *= beta1; pw2 *= beta2;
+      }
+      if (missed > n) {
+        const int d = missed - n;
+        const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
+      }
+    };
+    if (pending) {
+      replay(a, gs - 1);
+      float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
+      if (bias_correction) {
+        inv_bc1 = 1.f / (1.f - powf(beta1, (float)gs));
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(beta2, (float)gs));
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const float gsc = gg[c] * grad_scale;
+        mm[c] = beta1 * mm[c] + ob1 * gsc;
+        vv[c] = beta2 * vv[c] + ob2 * gsc * gsc;
+        pp[c] -= (lr[c] * inv_bc1) * adam_ratio(mm[c], vv[c], inv_sqrt_bc2, eps);
+        gg[c] = 0.f;
+      }
+      if (!keep_grad) vstore<VEC>(g + o, gg);
+      a = gs;
+    }
+    replay(a, to_step);
+    vstore<VEC>(m + o, mm); vstore<VEC>(v + o, vv); vstore<VEC>(p + o, pp);
+  }
+}
+
 // Dense Adam of the 11 GPU-resident attributes when the engine keeps the packed [N,12] mirror
 // (xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad) and accumulates their gradients in a packed
 // [N,12] table: one pass reads the gradient row, updates p / m / v of the four parameter tensors
@@ -528,6 +619,19 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
   CLMGS_CHECK_ARG(p && m && v && last_step && col_lr && ((g != nullptr) == (g_step != nullptr)));
   const bool v4 = (cols % 4 == 0) &&
                   (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)col_lr | (uintptr_t)g) & 15) == 0;
+  if (v4 && cols == 48 && n_rows < ((int64_t)1 << 27) && !getenv("CLMGS_CATCH_UP_GENERIC")) {  // (12 n < 2^32)
+    int grid48 = (int)min(ceil_div(n_rows * 12, 256), (int64_t)4095);
+    grid48 = (grid48 + 2) / 3 * 3;
+#define CLMGS_CATCH_UP48(I)                                                                          \
+  hipLaunchKernelGGL((adam_catch_up48_kernel<I>), dim3(grid48), dim3(256), 0, (hipStream_t)stream, p, m, v, \
+                     last_step, rows, (unsigned)n_rows, col_lr, (float)beta1, (float)beta2, (float)eps, to_step, \
+                     bias_correction, max_replay, g, g_step, grad_scale, (float)(1.0 - beta1),        \
+                     (float)(1.0 - beta2), keep_grad)
+    if (idx_is_64) CLMGS_CATCH_UP48(int64_t); else CLMGS_CATCH_UP48(int32_t);
+#undef CLMGS_CATCH_UP48
+    CLMGS_LAUNCH_CHECK();
+    return 0;
+  }
   const int grid = (int)min(ceil_div(n_rows * (cols / (v4 ? 4 : 1)), 256), (int64_t)256 * 16);
 #define CLMGS_CATCH_UP(I, VEC)                                                                     \
   hipLaunchKernelGGL((adam_catch_up_kernel<I, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \

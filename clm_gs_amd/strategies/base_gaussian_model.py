@@ -183,7 +183,12 @@ class BaseGaussianModel(ABC):
                                    utils.select_rows(self._opacity.detach(), sel), utils.select_rows(self._scaling.detach(), sel),
                                    utils.select_rows(self._rotation.detach(), sel))
 
-    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, defer_prune=False):
+        """defer_prune=True: the split originals are NOT pruned here; their mask (over the rows after the append) is
+        returned so that densify_and_prune can remove them together with the low-opacity rows in ONE compaction of the
+        row tables (the reference prunes twice, clm/gaussian_model.py:687-692 and base_gaussian_model.py:364-388; both
+        prunes keep the row order and the second mask only looks at values of rows the first one keeps, so one prune
+        with the OR of the two masks leaves exactly the same rows in the same order)."""
         n_init = self.get_xyz.shape[0]
         padded = torch.zeros((n_init,), device="cuda")
         padded[: grads.shape[0]] = grads.squeeze()
@@ -199,7 +204,10 @@ class BaseGaussianModel(ABC):
                                    utils.select_rows(self._opacity.detach(), sel).repeat(N, 1), new_scaling,
                                    utils.select_rows(self._rotation.detach(), sel).repeat(N, 1))
         prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device="cuda", dtype=torch.bool)))
+        if defer_prune:
+            return prune
         self.prune_points(prune)
+        return None
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
         """base_gaussian_model.py:364-388.  The screen-size prune is provably inert upstream
@@ -208,13 +216,13 @@ class BaseGaussianModel(ABC):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent)
+        split_mask = self.densify_and_split(grads, max_grad, extent, defer_prune=True)
         prune_mask = (self.get_opacity < min_opacity).squeeze()
         if max_screen_size:
             assert torch.all(self.max_radii2D == 0)
             big_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
             prune_mask = torch.logical_or(prune_mask, big_ws)
-        self.prune_points(prune_mask)
+        self.prune_points(torch.logical_or(prune_mask, split_mask))  # one compaction instead of two
 
     # ----------------------------------------------------------- storage order
     def permute_rows(self, order):

@@ -85,9 +85,62 @@ def evaluate(name, iteration, cameras, render_fn, log_file, max_images=10 ** 9):
     return l1, p
 
 
+class _LossLog:
+    """The `iteration[a,b) loss: ...` line of a batch needs the batch's loss VALUES on the host.  The reference reads
+    them right after the batch (train.py: torch.stack(losses).cpu()), which drains the device before the next batch is
+    enqueued; here the values travel on a side stream behind an event recorded after the batch, and the line is written
+    when the NEXT batch has been enqueued (same text, same order): the host never waits for a device that has nothing
+    queued behind it.  `defer_loss_log=False` in the args restores the immediate read."""
+
+    def __init__(self, log_file, defer):
+        self.log_file, self.defer, self.pending, self.stream = log_file, defer, None, None
+        self.hosts, self.turn = {}, 0  # two pinned buffers per batch size, used alternately (no allocation per batch)
+
+    def _write(self, head, host_vals, tail):
+        self.log_file.write(head + " ".join("%.6f" % l for l in host_vals.tolist()) + tail)
+
+    def push(self, head, losses, tail):
+        if not self.defer:
+            self._write(head, torch.stack(losses).cpu(), tail)
+            return
+        prev = self.pending
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        stacked = torch.stack(losses)  # enqueued on the current stream, right behind the batch
+        ev2 = torch.cuda.Event()
+        ev2.record(torch.cuda.current_stream())
+        self.turn ^= 1
+        key = (tuple(stacked.shape), self.turn)
+        host = self.hosts.get(key)
+        if host is None:
+            host = self.hosts[key] = torch.empty(stacked.shape, dtype=stacked.dtype, pin_memory=True)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev2)
+            host.copy_(stacked, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        stacked.record_stream(self.stream)
+        self.pending = (head, host, tail, done)
+        if prev is not None:
+            self._flush(prev)
+
+    def _flush(self, item):
+        head, host, tail, done = item
+        done.synchronize()
+        self._write(head, host, tail)
+
+    def flush(self):
+        if self.pending is not None:
+            self._flush(self.pending)
+            self.pending = None
+
+
 def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations=None,
-             test_iterations=(), background=None, shuffle_seed=0):
+             test_iterations=(), background=None, shuffle_seed=0, phase_times=None):
     """Runs `iterations` images of training; returns the End2endTimer.
+    `phase_times` (optional dict): host wall time per phase inside the end-to-end clock is accumulated into it
+    ("engine" = enqueueing the batches, "densify" = gsplat_densification incl. the device work it waits for,
+    "resort" = the Z-order re-sort after a densification, "log" = waiting for loss values, "final_sync").
 
     Camera-DP: when a process group is up every rank runs this same loop over the
     same shuffled order, takes cameras rank::ranks of each GLOBAL batch (bsz x ranks images), and
@@ -155,6 +208,12 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     if locality:
         assert spatial, "dp_locality needs the Z-ordered row tables (spatial_row_order)"
         deal()
+    defer = bool(getattr(args, "defer_loss_log", True))
+    loss_log = _LossLog(log_file, defer)
+    pt = phase_times if phase_times is not None else {}
+
+    def _acc(key, t_start):
+        pt[key] = pt.get(key, 0.0) + time.perf_counter() - t_start
     timer = End2endTimer()
     timer.start()
     next_batch = None
@@ -180,6 +239,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         if clm and getattr(args, "sh_residency", "hbm") == "host":
             from .strategies.clm_offload.engine import hint_next_batch
             hint_next_batch(gaussians, next_batch)
+        _t = time.perf_counter()
         if naive:
             losses, visibility = naive_offload_train_one_batch(gaussians, scene, batch, background,
                                                                sparse_adam=args.sparse_adam)
@@ -193,11 +253,14 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             losses, visibility = baseline_accumGrads_impl(gaussians, scene, batch, background,
                                                           sparse_adam=args.sparse_adam)
             names, sparsity = [c.image_name for c in batch], None
-        batched_loss = torch.stack(losses).cpu().tolist()
-        log_file.write("iteration[{},{}) loss: {} image: {}".format(
-            iteration, iteration + gbsz, " ".join("%.6f" % l for l in batched_loss), names))
-        log_file.write((" sparsity: " + " ".join("%.4f" % s for s in sparsity) + "\n") if sparsity else "\n")
+        _acc("engine", _t)
+        _t = time.perf_counter()
+        loss_log.push("iteration[{},{}) loss: ".format(iteration, iteration + gbsz), losses,
+                      " image: {}".format(names) + ((" sparsity: " + " ".join("%.4f" % s for s in sparsity) + "\n")
+                                                   if sparsity else "\n"))
+        _acc("log", _t)
         if any(iteration <= t < iteration + gbsz for t in test_iterations):
+            loss_log.flush()
             timer.stop()  # evaluation is excluded from the throughput figure
             if hasattr(gaussians, "flush_lazy_rows"):  # deferred row steps (and, owner-computes DP, the exchange)
                 gaussians.flush_lazy_rows()
@@ -206,14 +269,19 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
                 evaluate("test", iteration, test_cameras, render_fn, log_file)
             timer.start()
         n_before = gaussians.get_xyz.shape[0]
+        _t = time.perf_counter()
         gsplat_densification(iteration, scene, gaussians, None)
+        _acc("densify", _t)
         if spatial and gaussians.get_xyz.shape[0] != n_before:
+            _t = time.perf_counter()
             gaussians.spatial_sort()  # clones / splits were appended at the end of the tables
+            _acc("resort", _t)
             if locality and abs(gaussians.get_xyz.shape[0] - dealt_at) > 0.1 * dealt_at:
                 deal()
                 next_batch = None  # drawn from the old pool
         if gaussians.get_xyz.shape[0] != n_before or utils.check_update_at_this_iter(
                 iteration, gbsz, args.densification_interval, 0):
+            loss_log.flush()  # keep the reference's line order: the batch's loss line, then the memory line
             log_file.write(memory_line(iteration, gbsz, gaussians))
         if not clm and not naive:  # train.py:533-578
             if args.lr_scale_mode != "accumu":
@@ -225,8 +293,12 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             else:
                 gaussians.optimizer.step()
             gaussians.optimizer.zero_grad(set_to_none=True)
-        torch.cuda.synchronize()
+        if not defer:
+            torch.cuda.synchronize()
+    _t = time.perf_counter()
+    loss_log.flush()
     timer.stop()
+    _acc("final_sync", _t)
     from . import _lib
     _lib.check_device_errors()  # the binning chain's look-back kernels never timed out (raises otherwise)
     n_done = ((iterations - 1) // gbsz + 1) * gbsz + 1
