@@ -160,6 +160,10 @@ def parse():
                          "(kept for A/B: costs a transposing copy per camera)")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "allreduce", "owner", "locality"],
                     help="camera-DP exchange for --gpus > 1 (clm_gs_amd/dp.py); auto = locality (Z-ordered rows required)")
+    ap.add_argument("--scene", default="slab", choices=["slab", "heavy"],
+                    help="scale distribution of the synthetic Gaussians (clm_gs_amd/synthetic.py SCENE_KINDS): slab = SURVEY "
+                         "8d's generator (I/V = 3.8 at 4K); heavy = heavy-tailed scales with a measured I/V of ~10 (long "
+                         "per-tile lists), same N, same image size")
     ap.add_argument("--no-trainer-leg", action="store_true",
                     help="skip the third leg: clm_gs_amd.trainer.training on the bench scene (densify + opacity reset inside the "
                          "end-to-end clock) -> trainer_img_s / trainer_peak_gpu_bytes")
@@ -377,7 +381,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(H, W)
-    scene = synth_gaussians(N, seed=0, device="cuda")
+    scene = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
     if a.row_order == "morton":
         order = utils.morton_order(scene["xyz"])
         for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
@@ -491,7 +495,7 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(H, W)
-    scene = synth_gaussians(N, seed=0, device="cuda")
+    scene = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
     g = GaussianModelCLMOffload(3)
     g.create_from_tensors(scene["xyz"], scene["shs48"], scene["scaling"], scene["rotation"], scene["opacity"],
                           spatial_lr_scale=lr_extent)
@@ -597,7 +601,7 @@ def main():
     utils.set_img_size(H, W)
     torch.manual_seed(0)
 
-    scene = synth_gaussians(N, seed=0, device="cuda")
+    scene = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
     if a.row_order == "morton":
         order = utils.morton_order(scene["xyz"])
         for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
@@ -954,7 +958,7 @@ def main():
                    "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
                    "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
                    "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
-                   "camera_order": a.camera_order, "row_order": a.row_order,
+                   "camera_order": a.camera_order, "row_order": a.row_order, "scene": a.scene,
                    "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb,
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,

@@ -35,17 +35,25 @@ def perturbed_copy(scene, seed=99, xyz_sigma=0.05, opacity_shift=0.8, log_scale_
     return out
 
 
-def synth_gaussians(n, seed=0, device="cuda", thickness=0.1):
+# Scale distributions of the synthetic scenes: (median scale in units of the nearest-neighbour spacing, sigma of the
+# log-scale).  "slab" is SURVEY 8d's generator (I / V = 3.8 tile intersections per visible Gaussian at 4K); "heavy" is
+# a heavy-tailed one chosen so that the MEASURED I / V is ~10, the figure SURVEY 8d's own Rubble-4K illustration uses
+# (I = 30 M at V = 3 M): long per-tile lists, multi-round staging and deep early termination in the tile kernels.
+SCENE_KINDS = {"slab": (0.7, 0.4), "heavy": (1.2, 0.75)}
+
+
+def synth_gaussians(n, seed=0, device="cuda", thickness=0.1, kind="slab"):
     """xyz ~ U([-L,L]^2 x [0, thickness*L]) with L s.t. areal density = 1 / unit^2; log-scales
-    ~ N(log 0.7, 0.4^2); quats ~ N(0,I) un-normalised; opacity logit ~ N(0,1.5^2);
-    SH dc ~ N(0,1), rest ~ N(0,0.1^2)."""
+    ~ N(log s, sigma^2) with (s, sigma) = SCENE_KINDS[kind] ((0.7, 0.4) for the default slab); quats ~ N(0,I)
+    un-normalised; opacity logit ~ N(0,1.5^2); SH dc ~ N(0,1), rest ~ N(0,0.1^2)."""
+    s_med, s_sig = SCENE_KINDS[kind]
     g = torch.Generator(device=device).manual_seed(seed)
     L = 0.5 * math.sqrt(n)
     xyz = torch.rand((n, 3), generator=g, device=device)
     xyz[:, 0] = (xyz[:, 0] * 2 - 1) * L
     xyz[:, 1] = (xyz[:, 1] * 2 - 1) * L
     xyz[:, 2] = xyz[:, 2] * thickness * L
-    scaling = torch.randn((n, 3), generator=g, device=device) * 0.4 + math.log(0.7)
+    scaling = torch.randn((n, 3), generator=g, device=device) * s_sig + math.log(s_med)
     rotation = torch.randn((n, 4), generator=g, device=device)
     opacity = torch.randn((n, 1), generator=g, device=device) * 1.5
     shs = torch.randn((n, 16, 3), generator=g, device=device) * 0.1
