@@ -69,6 +69,7 @@ SIGNATURES = {
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_knn3_mean_dist2": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
+    "clmgs_publish_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_device_errors": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),

@@ -86,6 +86,26 @@ static int rows_move(void* stream, float* dst, const float* src, const void* dst
   return 0;
 }
 
+// Message of the camera-DP locality exchange, step F (clm_gs_amd/dp.py publish_rows): [chunk, cols] rows then chunk row
+// ids.  rows[i] = stamp[own[i]] == step ? table[own[i]] : 0 (a row whose line is an earlier step's travels as zeros),
+// ids[i] = bits of int32(own[i] - lo).  One pass instead of gather + stamp gather + mask + id conversion + copy.
+__global__ void __launch_bounds__(256)
+publish_pack_kernel(float* __restrict__ msg, const float* __restrict__ table, const int64_t* __restrict__ own,
+                    const int32_t* __restrict__ stamp, int step, int64_t lo, int64_t n, int64_t chunk, int f4_per_row) {
+  const int64_t total = n * f4_per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / f4_per_row;
+    const int k = (int)(i - r * f4_per_row);
+    const int64_t row = own[r];
+    const bool live = !stamp || stamp[row] == step;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) v = reinterpret_cast<const float4*>(table)[row * f4_per_row + k];
+    reinterpret_cast<float4*>(msg)[i] = v;
+    if (k == 0) reinterpret_cast<int32_t*>(msg)[chunk * f4_per_row * 4 + r] = (int32_t)(row - lo);
+  }
+}
+
 // ------------------------------------------------------------------ bitmaps
 template <typename T>
 __global__ void scatter_to_bit_kernel(T* __restrict__ bitmap, const int64_t* __restrict__ filter,
@@ -518,6 +538,19 @@ extern "C" int clmgs_rows_gather(void* stream, float* dst, const float* src, con
                                  const void* src_idx, int idx_is_64, int64_t n_rows, int cols,
                                  int grid_blocks) {
   return rows_move<false>(stream, dst, src, dst_idx, src_idx, idx_is_64, n_rows, cols, grid_blocks);
+}
+
+extern "C" int clmgs_publish_pack(void* stream, float* msg, const float* table, const int64_t* own_rows,
+                                  const int32_t* stamp, int step, int64_t lo, int64_t n_rows, int64_t chunk,
+                                  int cols) {
+  CLMGS_CHECK_ARG(n_rows >= 0 && chunk >= n_rows && cols > 0 && cols % 4 == 0);
+  if (n_rows == 0) return 0;
+  CLMGS_CHECK_ARG(msg && table && own_rows && (((uintptr_t)msg | (uintptr_t)table) & 15) == 0);
+  const int64_t total = n_rows * (cols / 4);
+  hipLaunchKernelGGL(publish_pack_kernel, dim3(min(ceil_div(total, 256), 256 * 8)), dim3(256), 0, (hipStream_t)stream,
+                     msg, table, own_rows, stamp, step, lo, n_rows, chunk, cols / 4);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int clmgs_rows_scatter_add(void* stream, float* dst, const float* src,

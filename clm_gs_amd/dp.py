@@ -295,31 +295,127 @@ def owner_gather_dense(tables, n_total):
 # Nothing else travels: a row deep inside a rank's region costs 52 B per peer (step F) instead of 240 B x 2 (G-1)/G.
 class BorderPlan:
     __slots__ = ("n_ranks", "rank", "lo", "hi", "n_total", "mine", "border", "need", "serve", "serve_rows",
-                 "own_rows", "own_counts")
+                 "own_rows", "own_counts", "parts")
 
 
-def border_plan(touched_rows, n_total):
-    """touched_rows: ascending int64 ids this rank's cameras touch.  Two small collectives, ONE host read."""
+class _Part:
+    """One slice of the border rows for an exchange issued on its own: split sizes per peer + the positions of the
+    slice inside `border` (requester side) and inside `serve_rows` (owner side), both grouped by peer."""
+    __slots__ = ("need", "serve", "border_idx", "serve_idx")
+
+
+def _segments(starts, lens, dev):
+    """Concatenation of arange(starts[q], starts[q] + lens[q]) over the peers (host lists -> one device tensor)."""
+    segs = [torch.arange(a, a + n, device=dev) for a, n in zip(starts, lens) if n]
+    return torch.cat(segs) if segs else torch.empty((0,), dtype=torch.int64, device=dev)
+
+
+def _isin_sorted(values, sorted_set):
+    """values[i] in sorted_set (ascending, unique) -> bool, by binary search (no set materialised)."""
+    if sorted_set is None or sorted_set.numel() == 0 or values.numel() == 0:
+        return torch.zeros(values.shape, dtype=torch.bool, device=values.device)
+    pos = torch.searchsorted(sorted_set, values).clamp_(max=sorted_set.numel() - 1)
+    return sorted_set[pos] == values
+
+
+def border_plan(touched_rows, n_total, first_rows=None, last_rows=None):
+    """touched_rows: ascending int64 ids this rank's cameras touch.  Two small collectives + the count all-gather; two
+    host reads (the owner boundaries, before any collective; the split sizes).
+
+    first_rows / last_rows (ascending ids of the FIRST / LAST camera's filter, optional) split the exchange so that
+    it can hide behind rendering (engine: clm_offload/engine.py):
+      * B is issued in two parts: `params0` = the border rows the first camera renders from, `params1` = the rest --
+        camera 0 starts as soon as its own part has landed, the larger rest travels while camera 0 renders;
+      * D likewise: `grads0` = the border rows the LAST camera does not touch (their gradient lines are final once the
+        second-to-last backward has run: they travel under the last camera's backward), `grads1` = the rest.
+    Within every peer's segment the border list is ordered (first-camera rows, then the others), ascending inside each
+    group; the in-last flag travels in bit 62 of the ids, so both sides derive the same D lists.  Without first_rows /
+    last_rows there is one part each (`params0` / `grads0` empty), the exchange is what it was."""
     G, r = world_size(), rank()
     dev = touched_rows.device
     cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
-    b = torch.searchsorted(touched_rows, cuts)
-    need = b[1:] - b[:-1]
-    need[r] = 0
-    serve = torch.empty_like(need)
-    dist.all_to_all_single(serve, need)
-    host = torch.cat((b, need, serve)).tolist()
-    bl, need_l, serve_l = host[:G + 1], host[G + 1:2 * G + 1], host[2 * G + 1:]
-    bl[0], bl[-1] = 0, int(touched_rows.numel())
+    # host read 1: the owner boundaries inside the sorted touched list (no collective behind it: the caller has just
+    # read the filter sizes of the same selection, the device has nothing queued)
+    bl = torch.searchsorted(touched_rows, cuts).tolist()
+    n_t = int(touched_rows.numel())
+    bl[0], bl[-1] = 0, n_t
+    need_l = [bl[q + 1] - bl[q] for q in range(G)]
+    need_l[r] = 0
+    nb_start = [sum(need_l[:q]) for q in range(G)]
+    n_b = sum(need_l)
     pl = BorderPlan()
     pl.n_ranks, pl.rank, pl.n_total = G, r, n_total
     pl.lo, pl.hi = owner_range(n_total, r, G)
     pl.mine = touched_rows[bl[r]:bl[r + 1]]
-    pl.border = torch.cat((touched_rows[:bl[r]], touched_rows[bl[r + 1]:]))
+    border = torch.cat((touched_rows[:bl[r]], touched_rows[bl[r + 1]:]))     # ascending = grouped by owner
+    i64 = dict(dtype=torch.int64, device=dev)
+    starts_d = torch.tensor(nb_start, **i64)
+    ends_d = torch.tensor([a + n for a, n in zip(nb_start, need_l)], **i64)
+    if n_b:
+        # everything below works on the BORDER rows only (none on one rank, a fifth of the touched rows on two) with
+        # scans and scatters -- no sort, no atomics
+        in_first = _isin_sorted(border, first_rows)
+        in_last = _isin_sorted(border, last_rows) if last_rows is not None else torch.ones_like(in_first)
+        cf = torch.cat((torch.zeros(1, **i64), torch.cumsum(in_first.to(torch.int64), 0)))      # exclusive counts
+        cl = torch.cat((torch.zeros(1, **i64), torch.cumsum((~in_last).to(torch.int64), 0)))
+        need0 = cf[ends_d] - cf[starts_d]
+        need_d0 = cl[ends_d] - cl[starts_d]
+    else:
+        in_first = in_last = torch.zeros((0,), dtype=torch.bool, device=dev)
+        need0 = need_d0 = torch.zeros((G,), **i64)
+    need3 = torch.stack((torch.tensor(need_l, **i64), need0, need_d0), dim=1).contiguous()      # [G,3]
+    serve3 = torch.empty_like(need3)
+    dist.all_to_all_single(serve3.view(-1), need3.view(-1))
+    host = torch.cat((need3.view(-1), serve3.view(-1))).tolist()              # host read 2: the split sizes
+    n3, s3 = host[:3 * G], host[3 * G:]
+    need0_l, need_d0_l = n3[1::3], n3[2::3]
+    serve_l, serve0_l, serve_d0_l = s3[0::3], s3[1::3], s3[2::3]
+    if n_b:
+        # stable partition of every owner's segment into (first-camera rows, the others): destination by rank
+        seg = torch.repeat_interleave(torch.arange(G, device=dev), torch.tensor(need_l, **i64), output_size=n_b)
+        pos = torch.arange(n_b, device=dev)
+        rank_first = cf[:-1] - cf[starts_d][seg]                 # first-camera rows before me in my segment
+        rank_rest = (pos - starts_d[seg]) - rank_first
+        dest = starts_d[seg] + torch.where(in_first, rank_first, need0[seg] + rank_rest)
+        pl.border = torch.empty_like(border)
+        pl.border[dest] = border
+        border_last = torch.empty_like(in_last)
+        border_last[dest] = in_last
+    else:
+        pl.border, border_last = border, in_last
     pl.need, pl.serve = need_l, serve_l
     pl.serve_rows = torch.empty((sum(serve_l),), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(pl.serve_rows, pl.border, output_split_sizes=serve_l, input_split_sizes=need_l)
-    _count("all_to_all_ids", 8 * (G + pl.border.numel()))
+    tagged = pl.border | (border_last.to(torch.int64) << 62)
+    dist.all_to_all_single(pl.serve_rows, tagged, output_split_sizes=serve_l, input_split_sizes=need_l)
+    serve_last = ((pl.serve_rows >> 62) & 1).to(torch.bool)
+    pl.serve_rows = pl.serve_rows & ((1 << 62) - 1)
+    _count("all_to_all_ids", 8 * (3 * G + pl.border.numel()))
+    # ---- the parts
+    sv_start = [sum(serve_l[:q]) for q in range(G)]
+    parts = {}
+    p0, p1 = _Part(), _Part()
+    p0.need, p0.serve = need0_l, serve0_l
+    p1.need, p1.serve = [a - c for a, c in zip(need_l, need0_l)], [a - c for a, c in zip(serve_l, serve0_l)]
+    p0.border_idx = _segments(nb_start, need0_l, dev)
+    p1.border_idx = _segments([a + c for a, c in zip(nb_start, need0_l)], p1.need, dev)
+    p0.serve_idx = _segments(sv_start, serve0_l, dev)
+    p1.serve_idx = _segments([a + c for a, c in zip(sv_start, serve0_l)], p1.serve, dev)
+    parts["params0"], parts["params1"] = p0, p1
+    # D parts: the rows with in_last == 0 (part 0) / == 1 (part 1); ascending positions ARE grouped by peer, and their
+    # counts are known on the host (nonzero_static: no readback)
+    def by_flag(flags, n_zero):
+        n = int(flags.numel())
+        if n == 0:
+            e = torch.empty((0,), **i64)
+            return e, e
+        return (torch.nonzero_static(~flags, size=n_zero).flatten(), torch.nonzero_static(flags, size=n - n_zero).flatten())
+    g0, g1 = _Part(), _Part()
+    g0.need, g0.serve = need_d0_l, serve_d0_l
+    g1.need, g1.serve = [a - c for a, c in zip(need_l, need_d0_l)], [a - c for a, c in zip(serve_l, serve_d0_l)]
+    g0.border_idx, g1.border_idx = by_flag(border_last, sum(need_d0_l))
+    g0.serve_idx, g1.serve_idx = by_flag(serve_last, sum(serve_d0_l))
+    parts["grads0"], parts["grads1"] = g0, g1
+    pl.parts = parts
     # the rows of this rank's range anybody touches this batch, and how many every rank has: known NOW, so the
     # end-of-batch publication of the small-gradient sums (step F) needs no size readback of its own
     pl.own_rows = border_own_rows(pl)
@@ -334,6 +430,8 @@ def border_plan(touched_rows, n_total):
 def border_own_rows(pl):
     """Rows of this rank's range that anybody touches this batch (own cameras or served), ascending."""
     dev = pl.mine.device
+    if pl.serve_rows.numel() == 0:
+        return pl.mine  # nobody asked for anything (always so on one rank): the own touched rows, already ascending
     mark = torch.zeros((max(1, pl.hi - pl.lo),), dtype=torch.bool, device=dev)
     if pl.mine.numel():
         utils.fill_rows(mark, pl.mine - pl.lo, True)
@@ -342,45 +440,70 @@ def border_own_rows(pl):
     return torch.nonzero(mark).flatten() + pl.lo
 
 
-def border_params_out(table, pl):
-    """B: table[border] <- the owners' rows."""
+def border_params_out(table, pl, part=None):
+    """B: table[border] <- the owners' rows.  part: None = all border rows in one exchange; "params0" / "params1" = the
+    two slices of border_plan (the first camera's rows, the rest), each an exchange of its own."""
     W = table.shape[1]
-    send = _take(table, pl.serve_rows) if pl.serve_rows.numel() else table.new_empty((0, W))
-    recv = table.new_empty((pl.border.numel(), W))
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=pl.need, input_split_sizes=pl.serve)
+    if part is None:
+        need, serve, b_rows, s_rows = pl.need, pl.serve, pl.border, pl.serve_rows
+    else:
+        pt = pl.parts[part]
+        need, serve = pt.need, pt.serve
+        b_rows = pl.border[pt.border_idx] if pt.border_idx.numel() else pl.border[:0]
+        s_rows = pl.serve_rows[pt.serve_idx] if pt.serve_idx.numel() else pl.serve_rows[:0]
+    send = _take(table, s_rows) if s_rows.numel() else table.new_empty((0, W))
+    recv = table.new_empty((b_rows.numel(), W))
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=need, input_split_sizes=serve)
     _count("all_to_all_params", send.numel() * send.element_size())
-    if pl.border.numel():
-        _put(table, pl.border, recv)
+    if b_rows.numel():
+        _put(table, b_rows, recv)
 
 
-def border_grads_home(tables, stamp, step, pl):
-    """D: the gradient rows of this rank's border rows go to their owners, which accumulate them.
-    tables: gradient tables [N, w_i] sharing `stamp` (int32 [N]: the step a row's gradient lines belong to;
-    first-touch policy).  stamp None: clearing policy (rows without a gradient hold zeros) -- the owner simply
-    adds, and the sender's border rows are zeroed once handed over."""
+def border_grads_send(tables, stamp, step, pl, part=None):
+    """D, first half: the gradient lines of this rank's border rows (all, or the slice "grads0" / "grads1" of
+    border_plan) travel to their owners.  -> the received lines [n_served, sum of widths] (+ the served row ids), to be
+    handed to border_grads_apply once nothing on this rank writes the gradient tables any more.  Only READS the
+    tables (rows of this slice), so it may run on a side stream under the last camera's backward when the slice holds
+    no row that camera touches ("grads0")."""
     widths = [t.shape[1] for t in tables]
     Wt = sum(widths)
     t0 = tables[0]
-    if pl.border.numel():
-        send = torch.cat([_take(t, pl.border) for t in tables], dim=1)
+    if part is None:
+        need, serve, b_rows, s_rows = pl.need, pl.serve, pl.border, pl.serve_rows
+    else:
+        pt = pl.parts[part]
+        need, serve = pt.need, pt.serve
+        b_rows = pl.border[pt.border_idx] if pt.border_idx.numel() else pl.border[:0]
+        s_rows = pl.serve_rows[pt.serve_idx] if pt.serve_idx.numel() else pl.serve_rows[:0]
+    if b_rows.numel():
+        send = torch.cat([_take(t, b_rows) for t in tables], dim=1)
         if stamp is not None:
             # The plan lists every border row of the FILTERS; the backward stores (and stamps) only rows that were drawn
             # (radius > 0).  A filtered row the exact projection did not draw (fast-accept vs exact tie, a camera redone
             # over capacity) keeps the gradient lines of an EARLIER step under first-touch stores: it travels as zeros,
             # never as that stale content (the owner then adds / stores nothing for it).
-            live = (utils.take_rows(stamp, pl.border) == step)[:, None]
+            live = (utils.take_rows(stamp, b_rows) == step)[:, None]
             send = torch.where(live, send, torch.zeros((), dtype=send.dtype, device=send.device))
     else:
         send = t0.new_empty((0, Wt))
-    recv = t0.new_empty((pl.serve_rows.numel(), Wt))
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=pl.serve, input_split_sizes=pl.need)
+    recv = t0.new_empty((s_rows.numel(), Wt))
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=serve, input_split_sizes=need)
     _count("all_to_all_grads", send.numel() * send.element_size())
+    return recv, s_rows, serve, b_rows
+
+
+def border_grads_apply(tables, stamp, step, pl, received):
+    """D, second half (owner side): add the received lines, requester by requester in rank order (ids are unique
+    within a requester's segment -> no atomics, a fixed summation order), storing instead of adding -- and stamping
+    -- where the row had no gradient this step yet (first-touch policy; stamp None: clearing policy, plain add)."""
+    recv, s_rows, serve, b_rows = received
+    widths = [t.shape[1] for t in tables]
     off = 0
-    for q in range(pl.n_ranks):  # requester by requester: ids are unique within a segment -> no atomics,
-        k = pl.serve[q]          # and a fixed summation order
+    for q in range(pl.n_ranks):
+        k = serve[q]
         if not k:
             continue
-        ids, seg = pl.serve_rows[off:off + k], recv[off:off + k]
+        ids, seg = s_rows[off:off + k], recv[off:off + k]
         c = 0
         if stamp is None:
             for t, w in zip(tables, widths):
@@ -393,16 +516,25 @@ def border_grads_home(tables, stamp, step, pl):
                 c += w
             utils.fill_rows(stamp, ids, step)
         off += k
-    if stamp is None and pl.border.numel():
+    if stamp is None and b_rows.numel():
         for t in tables:
-            utils.fill_rows(t, pl.border, 0.0)
+            utils.fill_rows(t, b_rows, 0.0)
 
 
-def publish_rows(tables, own_rows, n_total, counts=None, live=None):
+def border_grads_home(tables, stamp, step, pl):
+    """D in one go (send + apply of all border rows): the gradient rows of this rank's border rows go to their owners,
+    which accumulate them.  tables: gradient tables [N, w_i] sharing `stamp` (int32 [N]: the step a row's gradient
+    lines belong to; first-touch policy).  stamp None: clearing policy (rows without a gradient hold zeros) -- the
+    owner simply adds, and the sender's border rows are zeroed once handed over."""
+    border_grads_apply(tables, stamp, step, pl, border_grads_send(tables, stamp, step, pl))
+
+
+def publish_rows(tables, own_rows, n_total, counts=None, live=None, stamp=None, step=0):
     """F, general form: every owner all-gathers (row id, its summed rows of `tables`, side by side) for `own_rows`
     (ascending absolute ids inside its range); the receivers store the rows.  `counts`: len(own_rows) of every rank
     if the caller exchanged them already (border_plan does) -- no host read here then.
-    `live` (bool per own row, optional): rows whose line is not of this step are sent as zeros (sizes stay the plan's).
+    `stamp` + `step` (or `live`, a bool per own row): rows whose line is not of this step are sent as zeros (the sizes
+    stay the plan's).
     -> (counts per rank, list of the absolute id tensors received from every other rank)."""
     G, r = world_size(), rank()
     lo, _ = owner_range(n_total, r, G)
@@ -421,7 +553,17 @@ def publish_rows(tables, own_rows, n_total, counts=None, live=None):
     send = t0.new_empty((chunk * (W + 1),))
     rows_blk, ids_blk = send[:chunk * W].view(chunk, W), send[chunk * W:]
     n_own = own_rows.numel()
-    if n_own:
+    t_ = tables[0]
+    if n_own and len(tables) == 1 and t_.dim() == 2 and t_.is_cuda and t_.dtype == torch.float32 and W % 4 == 0 \
+            and t_.is_contiguous() and live is None:
+        # one library pass: rows (zeros for lines that are not of `step`, if a stamp table is given) + the id block
+        from . import _lib
+        from ._lib import check, dptr, stream
+        check(_lib.lib().clmgs_publish_pack(stream(), dptr(send), dptr(t_), dptr(own_rows.contiguous(), torch.int64),
+                                            dptr(stamp, torch.int32, True), int(step), int(lo), int(n_own), int(chunk), int(W)))
+    elif n_own:
+        if stamp is not None and live is None:
+            live = utils.take_rows(stamp, own_rows) == step
         if len(tables) == 1 and tables[0].dim() == 2:
             _take_into(rows_blk[:n_own], tables[0], own_rows)
         else:
@@ -462,9 +604,7 @@ def publish_small(small_g, stamp, step, n_total, pl=None):
         # own rows no camera drew after all (see border_grads_home) hold an earlier step's line: published as zeros
         # -- the sizes of the exchange stay the plan's (known before rendering, no readback), its CONTENT follows the
         # stamps; a zero line stamped `step` is what the replicated small-attribute Adam reads for an unstamped row
-        own = pl.own_rows
-        live = (utils.take_rows(stamp, own) == step) if own.numel() else None
-        counts, got = publish_rows([small_g], own, n_total, counts=pl.own_counts, live=live)
+        counts, got = publish_rows([small_g], pl.own_rows, n_total, counts=pl.own_counts, stamp=stamp, step=step)
     else:
         lo, hi = owner_range(n_total)
         own = torch.nonzero(stamp[lo:hi] == step).flatten() + lo
@@ -555,7 +695,7 @@ def exchange_bytes(touched_per_rank, n_total):
     for r in range(G):
         border = sum(per[r][q] for q in range(G) if q != r)
         serve = sum(per[p][r] for p in range(G) if p != r)
-        locality.append(8.0 * (G + border) + 192.0 * serve + 240.0 * border + (G - 1) * 52.0 * chunk + 8.0 * (G - 1))
+        locality.append(8.0 * (3 * G + border) + 192.0 * serve + 240.0 * border + (G - 1) * 52.0 * chunk + 8.0 * (G - 1))
     return {"allreduce": allreduce, "owner": owner, "locality": locality, "union": U, "n_ranks": G,
             "touched": [int(t.numel()) for t in touched_per_rank],
             "border": [sum(per[r][q] for q in range(G) if q != r) for r in range(G)],

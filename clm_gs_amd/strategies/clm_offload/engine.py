@@ -306,16 +306,39 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     # `_row_g_step` itself and stores instead of accumulating on a row's first touch of this step
     ft_stamp = gaussians._row_g_step if (lazy and fused and gaussians.first_touch_grads) else None
     owner = border = None  # owner-computes camera-DP (dp.py): rows owned by index range
+    dp_ev_b0 = dp_ev_b1 = dp_comm = None
+    dp_split = False
     if locality:
         # A + B of the locality exchange: who needs which of my rows; bring every own row anybody renders from
-        # up to date (waiting gradient step + replays); parameter rows out to the ranks that asked for them
+        # up to date (waiting gradient step + replays); parameter rows out to the ranks that asked for them.
+        # OVERLAP (round 4, dp_overlap): under the camera pipeline the exchange is split (dp.border_plan parts) --
+        #   B  parameters of the FIRST camera's border rows travel first, the (larger) rest while camera 0 renders:
+        #      both on a side stream, the front stream waits for an event per part;
+        #   D  gradient lines of the border rows the LAST camera does not touch leave right after the second-to-last
+        #      backward, i.e. under the last camera's backward (side stream, read-only on rows nobody writes any more);
+        #      the rest, the owner-side accumulation and F (the owners' published sums) stay at the tail.
+        dp_split = bool(pipelined and bsz >= 2 and getattr(args, "dp_overlap", True))
         with _lib.host_region("dp_border_plan"):
-            border = dp.border_plan(touched_rows.long(), N)
+            border = dp.border_plan(touched_rows.long(), N, first_rows=filters[0] if dp_split else None,
+                                    last_rows=filters[bsz - 1] if dp_split else None)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
         own_rows = border.own_rows
         if own_rows.numel():
             gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
-        dp.border_params_out(params.data, border)
+        if dp_split:
+            dp_comm = getattr(gaussians, "_dp_comm_stream", None)
+            if dp_comm is None:
+                dp_comm = gaussians._dp_comm_stream = torch.cuda.Stream()
+            dp_comm.wait_stream(default_stream)  # the owners' rows are current
+            with torch.cuda.stream(dp_comm):
+                dp.border_params_out(params.data, border, "params0")
+                dp_ev_b0 = torch.cuda.Event()
+                dp_ev_b0.record(dp_comm)
+                dp.border_params_out(params.data, border, "params1")
+                dp_ev_b1 = torch.cuda.Event()
+                dp_ev_b1.record(dp_comm)
+        else:
+            dp.border_params_out(params.data, border)
     elif locality_sparse:
         with _lib.host_region("dp_border_plan"):
             border = dp.border_plan(touched_rows.long(), N)
@@ -415,7 +438,21 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             ahead = bool(getattr(args, "front_ahead", False))
             fronts = (s_front, sts["front2"]) if ahead else (s_front, s_front)
 
+            dp_recv0 = [None]
+
+            def _after_backward(k):
+                # camera-DP, locality exchange: the gradient lines of the border rows the last camera does not touch are
+                # final once camera bsz-2's backward is enqueued -- they travel now, under the last camera's backward
+                if dp_split and k == bsz - 2:
+                    ev = torch.cuda.Event()
+                    ev.record(s_mem)
+                    dp_comm.wait_event(ev)
+                    with torch.cuda.stream(dp_comm):
+                        dp_recv0[0] = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads0")
+
             def _front(k):
+                if dp_split:  # parameters of this camera's border rows have landed (part 0: camera 0, part 1: the rest)
+                    fronts[k % 2].wait_event(dp_ev_b0 if k == 0 else dp_ev_b1)
                 with _lib.host_region("camera_front"):
                     return camera_front(
                         gaussians, batched_cameras[k], filters[k], params.data, 1, background,
@@ -434,10 +471,15 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                     with _lib.host_region("camera_backward"):
                         camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
                                         stats_delta=stats_d, sh_stamp=ft_stamp, cur_step=step, release=True)
+                    _after_backward(micro_idx - depth)
             for k in range(max(0, bsz - depth), bsz):
                 with _lib.host_region("camera_backward"):
                     camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d,
                                     sh_stamp=ft_stamp, cur_step=step, release=True)
+                _after_backward(k)
+            if dp_split:
+                default_stream.wait_stream(dp_comm)
+                gaussians._dp_recv0 = dp_recv0[0]
             default_stream.wait_stream(fronts[1])
             for st_ in (s_front, s_mem, s_raster):
                 default_stream.wait_stream(st_)
@@ -501,7 +543,17 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         elif border is not None:
             # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
             # their owners; the owners publish the summed small-attribute gradients of their touched rows
-            dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
+            if dp_split:
+                r0 = gaussians._dp_recv0
+                gaussians._dp_recv0 = None
+                for t_ in (r0[0], r0[1], r0[3]):  # allocated on the side stream, consumed here
+                    if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                        t_.record_stream(default_stream)
+                r1 = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads1")
+                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r0)
+                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
+            else:
+                dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
             dp.publish_small(small_gk, ft_stamp, step, N, border)
         elif owner is not None:
             # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the

@@ -383,6 +383,13 @@ int clmgs_knn3_mean_dist2(void* stream, int n, const float* pts_sorted, const in
                           float ox, float oy, float oz, float h, int gx, int gy, int gz,
                           int max_ring, float* mean_d2_sorted);
 
+/* Camera-DP, locality exchange, step F (clm_gs_amd/dp.py publish_rows; net-new, the reference is single GPU): packs
+ * the message an owner all-gathers -- msg[0 .. chunk*cols) = the rows table[own_rows[i]] (zeros where stamp != NULL and
+ * stamp[row] != step: the row's gradient line is not of this step), msg[chunk*cols + i] = the bits of
+ * int32(own_rows[i] - lo).  cols % 4 == 0, msg / table 16 B aligned, chunk >= n_rows. */
+int clmgs_publish_pack(void* stream, float* msg, const float* table, const int64_t* own_rows, const int32_t* stamp,
+                       int step, int64_t lo, int64_t n_rows, int64_t chunk, int cols);
+
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);
 

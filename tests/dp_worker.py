@@ -17,6 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 W, H, N, BSZ, STEPS = 96, 64, 4000, 4, 3
+VIS = 0.35
+if os.environ.get("CLMGS_DPW_SIZE"):  # "W,H,N,BSZ,STEPS,VIS": the full-size run of tests/test_gpu_dp.py
+    _w, _h, _n, _b, _s, _v = os.environ["CLMGS_DPW_SIZE"].split(",")
+    W, H, N, BSZ, STEPS, VIS = int(_w), int(_h), int(_n), int(_b), int(_s), float(_v)
 
 
 class _Scene:
@@ -111,7 +115,7 @@ def main():
     utils.set_args(args)
     utils.set_img_size(H, W)
     sc = synth_gaussians(N, seed=0, device="cuda")
-    cams = nadir_cameras(STEPS * BSZ * world, N, W, H, 0.35, seed=0, device="cuda")
+    cams = nadir_cameras(STEPS * BSZ * world, N, W, H, VIS, seed=0, device="cuda")
     g = torch.Generator().manual_seed(5)
     for c in cams:
         c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()

@@ -136,7 +136,9 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     if mode == "foreign" and rank == world - 1:
         pick[lo:hi] = False
     T = torch.nonzero(pick).flatten()
-    pl = dp.border_plan(T, N)
+    split = mode == "parts"
+    first_rows, last_rows = (T[::3].clone(), T[1::2].clone()) if split else (None, None)
+    pl = dp.border_plan(T, N, first_rows=first_rows, last_rows=last_rows)
     fails = []
     if not (torch.equal(torch.sort(torch.cat((pl.mine, pl.border))).values, T)):
         fails.append(1)
@@ -152,7 +154,21 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     truth = (owner_of * 1000 + torch.arange(N) % 97).float()[:, None].repeat(1, 48)
     params = torch.full((N, 48), -1.0)
     params[lo:hi] = truth[lo:hi]
-    dp.border_params_out(params, pl)
+    if split:
+        # the exchange in two parts: after part 0 exactly the first camera's border rows are current
+        dp.border_params_out(params, pl, "params0")
+        isb = (T < lo) | (T >= hi)
+        in_first = torch.isin(T, first_rows)
+        if not (torch.equal(params[T[isb & in_first]], truth[T[isb & in_first]])
+                and bool((params[T[isb & ~in_first]] == -1.0).all())):
+            fails.append(16)
+        g0 = pl.border[pl.parts["grads0"].border_idx]
+        if not (not bool(torch.isin(g0, last_rows).any())
+                and g0.numel() + pl.parts["grads1"].border_idx.numel() == pl.border.numel()):
+            fails.append(17)  # grads0 = the border rows the LAST camera does not touch
+        dp.border_params_out(params, pl, "params1")
+    else:
+        dp.border_params_out(params, pl)
     if not (torch.equal(params[T], truth[T])):  # everything I render from is current
         fails.append(4)
     untouched_foreign = torch.ones(N, dtype=torch.bool)
@@ -173,7 +189,13 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
         dead = T[::7]
         g_sh[dead], g_small[dead], stamp[dead] = 9.0, 9.0, 3
         dense_sh[dead], dense_small[dead] = 0.0, 0.0
-    dp.border_grads_home([g_sh, g_small], stamp, step, pl)
+    if split:  # both slices travel first (the early one under the last camera's backward), then both are applied
+        r0 = dp.border_grads_send([g_sh, g_small], stamp, step, pl, "grads0")
+        r1 = dp.border_grads_send([g_sh, g_small], stamp, step, pl, "grads1")
+        dp.border_grads_apply([g_sh, g_small], stamp, step, pl, r0)
+        dp.border_grads_apply([g_sh, g_small], stamp, step, pl, r1)
+    else:
+        dp.border_grads_home([g_sh, g_small], stamp, step, pl)
     own_touched = dp.border_own_rows(pl)
     dp.publish_small(g_small, stamp, step, N, pl)
     gathered = [None] * world
@@ -244,6 +266,15 @@ def test_dp_locality_exchange_edge_shapes_gloo():
     _run_world(_locality_worker, 2, "idle")
     _run_world(_locality_worker, 3, "foreign")
     _run_world(_locality_worker, 4, "disjoint")
+
+
+def test_dp_locality_exchange_in_parts_gloo():
+    """Round 4: the exchange split so that it can hide behind rendering -- parameters of the first camera's border rows
+    first (params0), the rest while it renders (params1); gradient lines of the border rows the last camera does not
+    touch early (grads0), the rest after its backward (grads1) -- leaves every table exactly where the one-piece
+    exchange leaves it (world 2 and 3, incl. the wire-byte account)."""
+    _run_world(_locality_worker, 2, "parts")
+    _run_world(_locality_worker, 3, "parts")
 
 
 def test_dp_locality_exchange_ignores_rows_the_backward_did_not_draw():

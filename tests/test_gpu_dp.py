@@ -96,6 +96,23 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev):
     assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
 
 
+def test_locality_exchange_at_28m_two_ranks_share_the_gpu(dev):
+    """config 4's camera-DP half at FULL SIZE as far as one GPU allows -- 28 M Gaussians, 4608x3456, two
+    ranks of bsz 4 sharing the device (gloo; 2 x 37 GB of replicas), the locality exchange with the cameras dealt by row
+    ownership: after two global batches and flush_lazy_rows() the replicas are bit-identical and equal the
+    single-rank run on the global batches (bsz 8); border rows and published sums really travelled."""
+    env = dict(os.environ, CLMGS_DPW_SIZE="4608,3456,28000000,4,2,0.10")
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "tests", "dp_worker.py"), "locality"], timeout=1500, env=env)
+    line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
+    res = json.loads(line[len("DPRESULT "):])
+    assert res["replicas_equal"] is True, res
+    assert max(res["rel_l2_vs_single"]) < 2e-4, res
+    assert res["wire"]["all_to_all_params"] > 1e8 and res["wire"]["all_to_all_grads"] > 1e8, res  # > 100 MB of border rows
+    assert res["wire"]["all_gather_small"] > 1e7, res
+
+
 def test_locality_exchange_sparse_adam_equals_single_rank(dev):
     """dp_locality with sparse_adam (BigCity as the reference scripts it, bigcity.sh:54-85: SelectiveAdam for the
     small attributes, the SH rows of visible Gaussians only): border rows by all_to_all, clearing-policy gradient
