@@ -69,6 +69,8 @@ SIGNATURES = {
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_knn3_mean_dist2": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
+    "clmgs_host_groups_temp_bytes": (_sz, [_i64]),
+    "clmgs_host_groups": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_publish_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_device_errors": (_i, [_vp, _i]),
@@ -113,7 +115,7 @@ class _Namespace:
 
 
 _NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
-              "clmgs_isect_sort_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_usable_cpus", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
+              "clmgs_isect_sort_temp_bytes", "clmgs_host_groups_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_usable_cpus", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters", "clmgs_device_errors"}
 
 

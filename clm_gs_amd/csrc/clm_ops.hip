@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "radix.h"
 
 namespace clmgs {
 
@@ -104,6 +105,45 @@ publish_pack_kernel(float* __restrict__ msg, const float* __restrict__ table, co
     reinterpret_cast<float4*>(msg)[i] = v;
     if (k == 0) reinterpret_cast<int32_t*>(msg)[chunk * f4_per_row * 4 + r] = (int32_t)(row - lo);
   }
+}
+
+// ------------------------------------------------------------------ row groups of the host-resident batch
+// For every row a batch touches: the FIRST and the LAST camera of the batch that uses it, from the visibility bitmap
+// (bit bsz-1-i = camera i, as the reference encodes it, clm_offload/engine.py:137-153).  Keys for two stable one-digit
+// radix sorts: kf = first camera (255 = the row is already staged, not "late"), kl = last camera.
+template <typename T>
+__global__ void __launch_bounds__(256)
+host_group_keys_kernel(int64_t n, const int64_t* __restrict__ touched, const T* __restrict__ bitmap, int bsz,
+                       const uint8_t* __restrict__ staged, uint32_t* __restrict__ kf, uint32_t* __restrict__ kl,
+                       int32_t* __restrict__ rows32) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = touched[j];
+    unsigned long long bm = (unsigned long long)(typename std::make_unsigned<T>::type)bitmap[row];
+    if (bsz < 64) bm &= (1ull << bsz) - 1ull;
+    int first = 254, last = 254;  // a touched row is in at least one filter; 254 only for an inconsistent input
+    if (bm) {
+      first = (bsz - 1) - (63 - __clzll((long long)bm));
+      last = (bsz - 1) - (__ffsll((long long)bm) - 1);
+    }
+    kf[j] = (staged && staged[row]) ? 255u : (uint32_t)first;
+    kl[j] = (uint32_t)last;
+    rows32[j] = (int32_t)row;
+  }
+}
+
+// counts[0..bsz) = late rows per first camera, counts[bsz..2 bsz) = rows per last camera, counts[2 bsz] = late rows;
+// slot_of[late_sorted[k]] = slot0 + k
+__global__ void __launch_bounds__(256)
+host_group_finish_kernel(int64_t n, int bsz, const uint32_t* __restrict__ tot_first, const uint32_t* __restrict__ tot_last,
+                         const int32_t* __restrict__ late_sorted, int slot0, int32_t* __restrict__ slot_of,
+                         int64_t* __restrict__ counts) {
+  const int64_t n_late = n - (int64_t)tot_first[255];
+  if (blockIdx.x == 0 && threadIdx.x <= 2 * bsz) {
+    const int t = threadIdx.x;
+    counts[t] = t < bsz ? (int64_t)tot_first[t] : (t < 2 * bsz ? (int64_t)tot_last[t - bsz] : n_late);
+  }
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_late; k += (int64_t)gridDim.x * blockDim.x)
+    slot_of[late_sorted[k]] = slot0 + (int32_t)k;
 }
 
 // ------------------------------------------------------------------ bitmaps
@@ -576,6 +616,50 @@ extern "C" int clmgs_scatter_to_bit(void* stream, void* bitmap, int elem_bytes,
   const int grid = min(ceil_div(n, 256), 256 * 8);
   DISPATCH_ELEM(elem_bytes, hipLaunchKernelGGL(scatter_to_bit_kernel<T>, dim3(grid), dim3(256), 0,
                                                (hipStream_t)stream, (T*)bitmap, filter, n, bit));
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t clmgs_host_groups_temp_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return 4 * align_up((size_t)n * 4, 256) + 2 * align_up((size_t)n * 4, 256) + 2 * radix_table_bytes(n) + 256;
+}
+
+extern "C" int clmgs_host_groups(void* stream, int64_t n, const int64_t* touched, const void* bitmap, int elem_bytes,
+                                 int bsz, const uint8_t* staged, int slot0, int32_t* late_sorted,
+                                 int32_t* rows_by_last, int32_t* slot_of, int64_t* counts, void* temp,
+                                 size_t temp_bytes) {
+  CLMGS_CHECK_ARG(n >= 0 && bsz >= 1 && bsz <= 64 && bsz <= elem_bytes * 8);
+  CLMGS_CHECK_ARG(counts);
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    CLMGS_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (2 * bsz + 1), s));
+    return 0;
+  }
+  CLMGS_CHECK_ARG(n < ((int64_t)1 << 31) && touched && bitmap && late_sorted && rows_by_last && slot_of && temp);
+  CLMGS_CHECK_ARG(temp_bytes >= clmgs_host_groups_temp_bytes(n));
+  char* base = (char*)temp;
+  const size_t a4 = align_up((size_t)n * 4, 256);
+  uint32_t* kf = (uint32_t*)base; base += a4;
+  uint32_t* kl = (uint32_t*)base; base += a4;
+  uint32_t* kb = (uint32_t*)base; base += a4;   // second key buffer of the sorts
+  int32_t* rows32 = (int32_t*)base; base += a4;
+  int32_t* vb = (int32_t*)base; base += a4;
+  int32_t* vc = (int32_t*)base; base += a4;     // (unused by one-pass sorts; kept for the sorter's interface)
+  uint32_t* table1 = (uint32_t*)base; base += radix_table_bytes(n);
+  uint32_t* table2 = (uint32_t*)base;
+  const int grid = min(ceil_div(n, 256), 256 * 8);
+  DISPATCH_ELEM(elem_bytes, hipLaunchKernelGGL(host_group_keys_kernel<T>, dim3(grid), dim3(256), 0, s, n, touched,
+                                               (const T*)bitmap, bsz, staged, kf, kl, rows32));
+  CLMGS_LAUNCH_CHECK();
+  uint32_t* sorted = nullptr;
+  int rc = radix_sort_pairs<uint32_t, int32_t>(s, n, kf, kb, rows32, vb, late_sorted, 0, 8, table1, &sorted);
+  if (rc) return rc;
+  rc = radix_sort_pairs<uint32_t, int32_t>(s, n, kl, kb, rows32, vc, rows_by_last, 0, 8, table2, &sorted);
+  if (rc) return rc;
+  const int nb = (int)((n + RS_MIN_CHUNK - 1) / RS_MIN_CHUNK);
+  hipLaunchKernelGGL(host_group_finish_kernel, dim3(grid), dim3(256), 0, s, n, bsz, table1 + (size_t)nb * 256,
+                     table2 + (size_t)nb * 256, late_sorted, slot0, slot_of, counts);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -52,7 +52,7 @@ radix_hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int n_blo
 // kernels, whose one-wave blocks refill every freed wave slot, a 1024-thread block (16 slots on ONE
 // CU at once) was not dispatched until the tile kernel had drained -- 1.5 ms instead of 5 us.
 constexpr int RS_SCAN_THREADS = 256;
-__global__ void __launch_bounds__(RS_SCAN_THREADS)
+static __global__ void __launch_bounds__(RS_SCAN_THREADS)
 radix_scan_rows_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __restrict__ row_tot) {
   __shared__ uint32_t wsum[RS_SCAN_THREADS / 64];
   __shared__ uint32_t carry_s;
@@ -121,7 +121,7 @@ radix_hist_multi_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, int
 // row scan -- thread t of block d owns the contiguous segment [t K, (t+1) K) of digit d's row (K = ceil(n_blocks /
 // 256)): independent loads, ONE block-wide scan of the 256 segment sums, a second sweep writing the exclusive values;
 // the round-3 kernel walked the row in 256-wide steps with three barriers each (36 dependent steps at 9.3 M keys).
-__global__ void __launch_bounds__(RS_SCAN_THREADS)
+static __global__ void __launch_bounds__(RS_SCAN_THREADS)
 radix_scan_rows_seg_kernel(int n_blocks, uint32_t* __restrict__ table, uint32_t* __restrict__ row_tot) {
   __shared__ uint32_t wsum[RS_SCAN_THREADS / 64];
   uint32_t* row = table + (size_t)blockIdx.x * n_blocks;
@@ -351,7 +351,7 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, int lane) {
 }
 
 // pass 1: per-block inclusive scan in place + block totals
-__global__ void __launch_bounds__(SC_THREADS)
+static __global__ void __launch_bounds__(SC_THREADS)
 scan_i64_blocks_kernel(int64_t n, int64_t* __restrict__ data, int64_t* __restrict__ block_tot) {
   __shared__ int64_t wsum[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -376,7 +376,7 @@ scan_i64_blocks_kernel(int64_t n, int64_t* __restrict__ data, int64_t* __restric
 }
 
 // pass 2: exclusive scan of the block totals, one block (256 threads, see radix_scan_rows_kernel)
-__global__ void __launch_bounds__(SC_THREADS)
+static __global__ void __launch_bounds__(SC_THREADS)
 scan_i64_totals_kernel(int nb, int64_t* __restrict__ tot) {
   __shared__ int64_t wsum[SC_THREADS / 64];
   __shared__ int64_t carry_s;
@@ -400,7 +400,7 @@ scan_i64_totals_kernel(int nb, int64_t* __restrict__ tot) {
 }
 
 // pass 3: add the block offsets; last_out (optional) receives the grand total data[n-1]
-__global__ void __launch_bounds__(SC_THREADS)
+static __global__ void __launch_bounds__(SC_THREADS)
 scan_i64_add_kernel(int64_t n, int64_t* __restrict__ data, const int64_t* __restrict__ tot,
                     int64_t* __restrict__ last_out) {
   const int64_t off = tot[blockIdx.x];

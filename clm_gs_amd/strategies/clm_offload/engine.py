@@ -763,63 +763,59 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
             mark.zero_()
             utils.fill_rows(mark, touched_rows, True)          # rows this batch touches
             wasted = touched_rows[:0]
-            late_rows = touched_rows
+            staged_mask = None
             if spec is not None and n_p:
                 P = spec["rows"]                                 # staged rows, slot k = P[k]
                 wasted = P[~mark[P]]                             # staged but not touched: no gradient will land
                 in_spec.zero_()
                 utils.fill_rows(in_spec, P, True)
-                late_rows = touched_rows[~in_spec[touched_rows]]
-            n_late = int(late_rows.shape[0])                     # (shape of a boolean selection: one host read)
+                staged_mask = in_spec
+            # ---- ONE library call (clmgs_host_groups) groups the rows: the rows still to be staged ("late": not in
+            # the speculative block) by the camera that uses them FIRST (slot order), all touched rows by the camera
+            # that uses them LAST (hand-back order), slot_of[] of the late rows, and the 2 bsz + 1 group sizes on the
+            # device -- two stable one-digit radix sorts.  Rounds 2-3 did this with ~60 torch index ops (float64 log2 of
+            # the bitmap words, two 64-bit sorts, bincounts, boolean selections): 24 ms of a 114 ms batch during which
+            # the GPU did little else.
+            bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
+            late_all = torch.empty((T,), dtype=torch.int32, device=dev)
+            rows_by_last32 = torch.empty((T,), dtype=torch.int32, device=dev)
+            counts = torch.empty((2 * bsz + 1,), dtype=torch.int64, device=dev)
+            tb = L.clmgs_host_groups_temp_bytes(T)
+            tmp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+            _t0 = time.perf_counter()
+            # (slot_of of the late rows needs slot0 = n_p, which is only final once the staging tables are known not to
+            #  have been re-allocated: n_p is re-checked below and the call repeated in that rare case)
+            def group(slot0, staged):
+                _lib.check(L.clmgs_host_groups(_lib.stream(), T, _lib.dptr(touched_rows, torch.int64), _lib.dptr(bitmap),
+                                               bitmap.element_size(), bsz, _lib.dptr(staged.view(torch.uint8), None, True)
+                                               if staged is not None else None, int(slot0), _lib.dptr(late_all),
+                                               _lib.dptr(rows_by_last32), _lib.dptr(slot_of), _lib.dptr(counts),
+                                               _lib.dptr(tmp), tb))
+            group(n_p, staged_mask)
+            cl = counts.tolist()                                          # one host read: the group sizes
+            _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
+            n_late = int(cl[2 * bsz])
             hb = _host_buffers(gaussians, n_p + n_late, dev)
             if spec is not None and spec["gen"] != hb["gen"]:
                 # the staging tables had to grow: what was staged went with the old ones -- everything is late
                 # (re-preparing a current row is the identity; the stamps of the touched rows stay right)
-                late_rows, n_late, n_p, spec = touched_rows, T, 0, None
+                n_p, spec = 0, None
+                group(0, None)
+                cl = counts.tolist()
+                n_late = int(cl[2 * bsz])
             if spec is not None and n_p:
                 slot_of[spec["rows"]] = torch.arange(n_p, dtype=torch.int32, device=dev)
             sh_stage = hb["sh_stage"][hb["cur"]]
             T_slots = n_p + n_late
             _lib.STATS.setdefault("host_late_rows", []).append(n_late)
             g_stage = hb["g_stage"][:T_slots]
-            # ---- group the LATE rows by first use (slot order); all touched rows by last use (hand-back order)
-            bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
-
-            def first_last(rows):
-                if bsz < 32:
-                    bm = bitmap[rows].to(torch.int32) & ((1 << bsz) - 1)
-                    # float64 holds every bitmap word below 2^53 exactly: floor(log2) is the index of the top bit
-                    first = (bsz - 1) - torch.floor(torch.log2(bm.to(torch.float64))).to(torch.int64)   # earliest camera
-                    low = bm & (-bm)
-                    last = (bsz - 1) - torch.round(torch.log2(low.to(torch.float64))).to(torch.int64)   # latest camera
-                    return first, last
-                # bsz 32 / 64: per-camera membership instead of log2 on wide words
-                n_r = rows.shape[0]
-                first = torch.full((n_r,), bsz, dtype=torch.int64, device=dev)
-                last = torch.zeros((n_r,), dtype=torch.int64, device=dev)
-                pos = torch.full((N,), -1, dtype=torch.int64, device=dev)
-                pos[rows] = torch.arange(n_r, device=dev)
-                for i, f in enumerate(filters):
-                    pf = pos[f]
-                    pf = pf[pf >= 0]
-                    first[pf] = torch.minimum(first[pf], torch.full_like(pf, i))
-                    last[pf] = i
-                return first, last
-
-            first_l, _ = first_last(late_rows)
-            ord_first = torch.sort(first_l, stable=True).indices
-            late_sorted = late_rows[ord_first]                          # slot n_p + k holds row late_sorted[k]
-            rows32 = late_sorted.to(torch.int32)
-            _, last_all = first_last(touched_rows)
-            # a staged row's camera can start once the staged block has landed: first-use groups of the late rows only
-            counts = torch.cat((torch.bincount(first_l, minlength=bsz), torch.bincount(last_all, minlength=bsz)))
+            rows32 = late_all[:n_late]                                   # slot n_p + k holds row rows32[k]
+            late_sorted = rows32
             rows_h, stage_h = hb["rows_h"][:n_late], hb["stage_h"][:n_late]
             if n_late:
                 _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), n_late * 4, 2))
-                slot_of[late_sorted] = torch.arange(n_p, n_p + n_late, dtype=torch.int32, device=dev)
             sh_index = [slot_of[f] for f in filters]
-            ord_last = torch.sort(last_all, stable=True).indices
-            rows_by_last = touched_rows[ord_last]
+            rows_by_last = rows_by_last32.to(torch.int64)
             slots_by_last = slot_of[rows_by_last]
             # ---- the NEXT batch's rows on the positions current now; what this batch touches cannot be staged early
             spec_rows = None
@@ -841,10 +837,9 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
                 else:
                     spec_rows = None
             _t0 = time.perf_counter()
-            cl = counts.tolist()                                          # one host read: 2*bsz group sizes
             wasted_h = wasted.cpu() if wasted.numel() else None
             _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
-        n_first, n_last = cl[:bsz], cl[bsz:]
+        n_first, n_last = cl[:bsz], cl[bsz:2 * bsz]
         if wasted_h is not None:  # staged for this batch but not touched by it: they expect no gradient after all
             gaussians._host_g_step[wasted_h] = 0
         prev = gaussians._host_grads_event

@@ -383,6 +383,18 @@ int clmgs_knn3_mean_dist2(void* stream, int n, const float* pts_sorted, const in
                           float ox, float oy, float oz, float h, int gx, int gy, int gz,
                           int max_ring, float* mean_d2_sorted);
 
+/* Host-resident batch (sh_residency="host"): the rows a batch touches, grouped by the camera that uses them FIRST (slot
+ * order of the rows that still have to be staged) and LAST (hand-back order of the gradient rows) -- what the reference
+ * derives from its bitmap with ffs / sort / tolist (clm_offload/engine.py:137-260), as two stable one-digit radix sorts.
+ * touched[n] ascending row ids; bitmap[N] of elem_bytes-wide words, bit bsz-1-i = camera i; staged (u8[N], optional):
+ * rows already staged for this batch (not "late").  Out: late_sorted[<= n] (late rows by first camera), rows_by_last[n],
+ * slot_of[row] = slot0 + position in late_sorted, counts[2*bsz+1] (device) = late rows per first camera | rows per
+ * last camera | number of late rows. */
+size_t clmgs_host_groups_temp_bytes(int64_t n);
+int clmgs_host_groups(void* stream, int64_t n, const int64_t* touched, const void* bitmap, int elem_bytes, int bsz,
+                      const uint8_t* staged, int slot0, int32_t* late_sorted, int32_t* rows_by_last, int32_t* slot_of,
+                      int64_t* counts, void* temp, size_t temp_bytes);
+
 /* Camera-DP, locality exchange, step F (clm_gs_amd/dp.py publish_rows; net-new, the reference is single GPU): packs
  * the message an owner all-gathers -- msg[0 .. chunk*cols) = the rows table[own_rows[i]] (zeros where stamp != NULL and
  * stamp[row] != step: the row's gradient line is not of this step), msg[chunk*cols + i] = the bits of
