@@ -267,6 +267,7 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
                         P_(radii), P_(m2), P_(dep), P_(con))
     t_cull = (time.perf_counter() - tc0) * N / float(n_s)
     n_a = min(N, 1_000_000)
+    torch_threads_before = torch.get_num_threads()
     torch.set_num_threads(usable)
     g_ = torch.Generator().manual_seed(0)
     pa, ga = torch.randn(n_a, 59, generator=g_), torch.randn(n_a, 59, generator=g_)
@@ -275,6 +276,7 @@ def cpu_baseline(gaussians, cam, width, height, budget_s):
     ta0 = time.perf_counter()
     O.adam_rows(pa, ga, ma, va, None, torch.full((59,), 1e-3), 0.9, 0.999, 1e-15, 2, 0.25)
     t_adam = (time.perf_counter() - ta0) * N / float(n_a)
+    torch.set_num_threads(torch_threads_before)  # the legs after this one keep their own CPU budget (the host pool)
     t_cam = t / frac2
     batch_s = bsz * (t_cam + t_cull) + t_adam
     return {
@@ -326,7 +328,14 @@ class GtFeeder:
         slot = key % self.DEPTH
         bufs = self.ring.get(slot)
         if bufs is None or len(bufs) != len(batch) or bufs[0].shape != batch[0].image_host.shape:
+            # NEW buffers: the caching allocator hands out blocks that the current (default) stream has freed but
+            # whose last readers may still be QUEUED there (stream-ordered reuse is only safe on the freeing
+            # stream).  The upload below runs on the feeder stream, so it must first wait for everything the default
+            # stream has enqueued so far -- otherwise it overwrites e.g. the previous batch's intersection lists under
+            # the kernels still reading them (round 4: GPU memory fault in the second, streamed pass of
+            # `--strategy no_offload` / `overlap_cameras=false`, present since round 2; the pipelined default never hit it).
             bufs = self.ring[slot] = [torch.empty(tuple(c.image_host.shape), dtype=torch.uint8, device="cuda") for c in batch]
+            self.stream.wait_stream(torch.cuda.current_stream())
         ev_free = self.freed.pop(slot, None)
         with torch.cuda.stream(self.stream):
             if ev_free is not None:
@@ -356,6 +365,9 @@ def upload_gt(batch, stream):
     with torch.cuda.stream(stream):
         for c in batch:
             c.original_image = c.image_host.to("cuda", non_blocking=True)
+            # allocated on the side stream, read by kernels of the current one: the allocator must not hand the block to the
+            # NEXT batch's upload (side stream again) while those kernels are still queued
+            c.original_image.record_stream(cur)
     cur.wait_stream(stream)
 
 
@@ -421,6 +433,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     torch.cuda.reset_peak_memory_stats()
     _lib.STATS.setdefault("touched_rows", []).clear()
     _lib.HOST_REGIONS = {}
+    _lib.REGION_TRACE = {} if os.environ.get("CLMGS_REGION_TRACE") == "1" else None
     _lib.STATS["host_prepare_s"] = 0.0
     t0 = time.perf_counter()
     for b in range(a.host_warmup, n_b):
@@ -453,6 +466,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
                              "copy, 1 536 B of host memory traffic per touched row) was working: near 1.0 the leg is bound by the "
                              "CPUs the container grants, not by the link or the GPU",
            "host_ms_per_step": {k: round(v / host_steps * 1e3, 2) for k, v in regions.items()},
+           **({"host_ms_trace": _lib.REGION_TRACE} if _lib.REGION_TRACE else {}),
            "link": {"bytes_per_batch": round(link_bytes, 1), "achieved_GBps": round(link_bytes * host_steps / dt / 1e9, 2),
                     "peak_GBps": 57.0, "note": "peak = hipMemcpyAsync pinned<->HBM measured on this node type, EITHER direction or "
                     "both together (profiles/r02_probe_host_link.json); every touched SH row crosses once per direction per batch"},

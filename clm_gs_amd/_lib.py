@@ -164,6 +164,7 @@ def check_device_errors():
 
 
 HOST_REGIONS = None  # set to {} to accumulate host wall time per engine region (diagnostics)
+REGION_TRACE = None  # set to {} (with HOST_REGIONS) to keep every occurrence's time as well
 _ROCTX = None        # libroctx64 handle when CLMGS_ROCTX=1 (ranges show up in `rocprofv3 --marker-trace`)
 
 
@@ -204,7 +205,10 @@ class host_region:
 
     def __exit__(self, *exc):
         if HOST_REGIONS is not None:
-            HOST_REGIONS[self.name] = HOST_REGIONS.get(self.name, 0.0) + time.perf_counter() - self.t0
+            dt = time.perf_counter() - self.t0
+            HOST_REGIONS[self.name] = HOST_REGIONS.get(self.name, 0.0) + dt
+            if REGION_TRACE is not None:  # per-occurrence times (diagnostics: which batch paid)
+                REGION_TRACE.setdefault(self.name, []).append(round(dt * 1e3, 2))
         if self.rx:
             self.rx.roctxRangePop()
         return False

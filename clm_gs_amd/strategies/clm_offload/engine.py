@@ -639,20 +639,31 @@ def _host_buffers(gaussians, T, dev):
     hb = getattr(gaussians, "_host_bufs", None)
     N = gaussians._xyz.shape[0]
     if hb is None or hb["cap"] < T or hb["N"] != N:
-        cap = bucket_size(max(int(T * 1.06), 1))  # staged-but-unused rows of a hinted batch ride along: a few percent
+        # Two capacities.  DEVICE tables (they count against the GPU peak of the offloading mode): 8 % over the need,
+        # grown when a batch exceeds them.  PINNED host twins: 50 % over the need -- host memory is cheap, and a new
+        # pinned table is a hipHostMalloc of 2 GB at 28 M (300+ ms: ONE such re-allocation inside a 20-batch run was
+        # 21 of the 24 ms of average "host_groups" time rounds 2-3 reported); they are kept when only the device tables
+        # grow.  The union of a batch's filters varies by several percent from batch to batch (shuffled cameras), and
+        # staged-but-unused rows of a hinted batch ride along.
+        cap = bucket_size(max(int(T * 1.08), 1))
         gen = hb["gen"] + 1 if hb else 0
+        keep_pinned = None
         if hb is not None:
             # The staging tables are written by hipMemcpyAsync issued through ctypes on the side streams (speculative
             # prefetch, feeder): the caching allocator knows nothing of that use, and a dropped speculation is only
-            # JOINED (its last copy may still be in flight).  Growing the tables is rare (bucketed capacity): drain the
-            # device before the old blocks go back to the allocator, so no late copy can land in a recycled block.
+            # JOINED (its last copy may still be in flight).  Growing the tables is rare: drain the device before the
+            # old blocks go back to the allocator, so no late copy can land in a recycled block.
             torch.cuda.synchronize()
+            if hb["N"] == N and hb["rows_h"].shape[0] >= cap:
+                keep_pinned = (hb["rows_h"], hb["stage_h"], hb["spec_rows_h"], hb["spec_stage_h"])
             hb.clear()  # the old tables go back to the allocator BEFORE the new ones are requested
         gaussians._host_bufs = None
+        if keep_pinned is None:
+            cap_h = bucket_size(max(int(T * 1.5), cap))
+            keep_pinned = (pinned_empty((cap_h,), dtype=torch.int32), pinned_empty((cap_h, 48)), None, None)
         hb = gaussians._host_bufs = dict(
             cap=cap, N=N, cur=0, gen=gen,
-            rows_h=pinned_empty((cap,), dtype=torch.int32), stage_h=pinned_empty((cap, 48)),
-            spec_rows_h=None, spec_stage_h=None,
+            rows_h=keep_pinned[0], stage_h=keep_pinned[1], spec_rows_h=keep_pinned[2], spec_stage_h=keep_pinned[3],
             sh_stage=[torch.empty((cap, 48), device=dev), None],
             g_stage=torch.empty((cap, 48), device=dev))
     return hb
@@ -662,10 +673,11 @@ def _host_spec_buffers(hb, dev):
     """The second staging table + its pinned twin: allocated when the first hint arrives (a caller that never
     hints pays nothing for the speculative prefetch)."""
     if hb["sh_stage"][1] is None:
-        cap = hb["cap"]
-        hb["sh_stage"][1] = torch.empty((cap, 48), device=dev)
-        hb["spec_rows_h"] = pinned_empty((cap,), dtype=torch.int32)
-        hb["spec_stage_h"] = pinned_empty((cap, 48))
+        hb["sh_stage"][1] = torch.empty((hb["cap"], 48), device=dev)
+    if hb["spec_rows_h"] is None:
+        cap_h = hb["rows_h"].shape[0]
+        hb["spec_rows_h"] = pinned_empty((cap_h,), dtype=torch.int32)
+        hb["spec_stage_h"] = pinned_empty((cap_h, 48))
 
 
 def hint_next_batch(gaussians, cameras):
