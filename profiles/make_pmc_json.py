@@ -16,7 +16,7 @@ GROUPS = {
     "clmgs_preprocess_fwd": ["preprocess_fwd_kernel"],
     "clmgs_preprocess_bwd": ["preprocess_bwd_kernel"],
     "clmgs_adam_rows": ["adam_rows_kernel"],
-    "clmgs_adam_catch_up": ["adam_catch_up_kernel"],
+    "clmgs_adam_catch_up": ["adam_catch_up"],
 }
 
 
