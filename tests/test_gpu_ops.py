@@ -778,3 +778,59 @@ def test_single_launch_binning_equals_legacy_chain(dev, n, wh):
     f_new, u_new = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
     assert torch.equal(u_new, u_ref) and all(torch.equal(a, b) for a, b in zip(f_new, f_ref))
     _lib.check_device_errors()
+
+
+@pytest.mark.parametrize("bsz", [4, 8, 32, 64])
+def test_host_groups_equals_index_arithmetic(dev, bsz):
+    """clmgs_host_groups (host-resident batch: rows grouped by the camera that uses them first / last, slot table, group
+    sizes) == plain index arithmetic on the same visibility bitmap, for every bitmap word width, with and without a
+    set of already-staged rows."""
+    from clm_gs_amd import _lib
+    from clm_gs_amd._lib import check, dptr, stream
+    from clm_gs_amd.strategies.clm_offload.engine import _encode_bitmap
+    L = _lib.lib()
+    N = 50_000
+    g = torch.Generator().manual_seed(bsz)
+    filters = []
+    for i in range(bsz):
+        k = int(torch.randint(N // 50, N // 6, (1,), generator=g))
+        filters.append(torch.sort(torch.randperm(N, generator=g)[:k]).values.to(dev))
+    seen = torch.zeros(N, dtype=torch.bool, device=dev)
+    for f in filters:
+        seen[f] = True
+    touched = torch.nonzero(seen).flatten()
+    T = touched.numel()
+    bitmap = _encode_bitmap(filters, N, bsz)
+    first = torch.full((N,), bsz, dtype=torch.int64, device=dev)
+    last = torch.full((N,), -1, dtype=torch.int64, device=dev)
+    for i, f in enumerate(filters):
+        first[f] = torch.minimum(first[f], torch.full_like(f, i))
+        last[f] = i
+    for staged_frac in (0.0, 0.4):
+        staged = torch.zeros(N, dtype=torch.bool, device=dev)
+        if staged_frac:
+            staged[touched[torch.rand(T, generator=g).to(dev) < staged_frac]] = True
+        late = touched[~staged[touched]]
+        want_late = late[torch.sort(first[late], stable=True).indices]
+        want_last = touched[torch.sort(last[touched], stable=True).indices]
+        slot0 = 7
+        late_sorted = torch.full((T,), -1, dtype=torch.int32, device=dev)
+        rows_by_last = torch.empty((T,), dtype=torch.int32, device=dev)
+        slot_of = torch.full((N,), -5, dtype=torch.int32, device=dev)
+        counts = torch.empty((2 * bsz + 1,), dtype=torch.int64, device=dev)
+        tb = L.clmgs_host_groups_temp_bytes(T)
+        tmp = torch.empty((tb,), dtype=torch.uint8, device=dev)
+        check(L.clmgs_host_groups(stream(), T, dptr(touched, torch.int64), dptr(bitmap), bitmap.element_size(), bsz,
+                                  dptr(staged.view(torch.uint8)) if staged_frac else None, slot0, dptr(late_sorted),
+                                  dptr(rows_by_last), dptr(slot_of), dptr(counts), dptr(tmp), tb))
+        torch.cuda.synchronize()
+        cl = counts.tolist()
+        n_late = cl[2 * bsz]
+        assert n_late == late.numel()
+        assert torch.equal(late_sorted[:n_late].long(), want_late) and torch.equal(rows_by_last.long(), want_last)
+        assert cl[:bsz] == torch.bincount(first[late], minlength=bsz).tolist()
+        assert cl[bsz:2 * bsz] == torch.bincount(last[touched], minlength=bsz).tolist()
+        assert torch.equal(slot_of[want_late].long(), torch.arange(slot0, slot0 + n_late, device=dev))
+        untouched = torch.ones(N, dtype=torch.bool, device=dev)
+        untouched[want_late] = False
+        assert bool((slot_of[untouched] == -5).all())
