@@ -171,7 +171,10 @@ static int lb_inclusive_scan_i64(hipStream_t s, int64_t n, int64_t* data, void* 
 // SPLIT: ValT == int2 and this is the final pass: .x goes to out_a, .y to out_b (flatten_ids / emit_slot).
 constexpr int OS_ROUND_ITEMS = 4;                      // keys per thread and ranking round (1024 per round)
 constexpr int OS_ROUND = 256 * OS_ROUND_ITEMS;
-constexpr int OS_WINDOW = 4;                           // look-back words in flight per thread
+#ifndef CLMGS_OS_WINDOW
+#define CLMGS_OS_WINDOW 4
+#endif
+constexpr int OS_WINDOW = CLMGS_OS_WINDOW;                           // look-back words in flight per thread
 
 static inline int os_blocks(int64_t n, int rounds) { return (int)((n + (int64_t)OS_ROUND * rounds - 1) / ((int64_t)OS_ROUND * rounds)); }
 // (sized for the thinnest block shape, 1 round: the shape is a run-time choice)
