@@ -96,13 +96,18 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev):
     assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
 
 
-def test_locality_exchange_at_28m_two_ranks_share_the_gpu(dev):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_locality_exchange_at_28m_two_ranks_share_the_gpu(dev, ranks):
     """config 4's camera-DP half at FULL SIZE as far as one GPU allows -- 28 M Gaussians, 4608x3456, two
-    ranks of bsz 4 sharing the device (gloo; 2 x 37 GB of replicas), the locality exchange with the cameras dealt by row
-    ownership: after two global batches and flush_lazy_rows() the replicas are bit-identical and equal the
-    single-rank run on the global batches (bsz 8); border rows and published sums really travelled."""
+    (and four) ranks of bsz 4 sharing the device (gloo; 2-4 x 37 GB of replicas), the locality exchange with the cameras
+    dealt by row ownership and the exchange in parts behind the first / last camera: after two global batches and
+    flush_lazy_rows() the replicas are bit-identical and equal the single-rank run on the global batches (bsz 8 / 16);
+    border rows and published sums really travelled."""
+    import torch
+    if ranks * 40e9 + 45e9 > torch.cuda.get_device_properties(0).total_memory:
+        pytest.skip("needs %d replicas of 37 GB + the single-rank run on one device" % ranks)
     env = dict(os.environ, CLMGS_DPW_SIZE="4608,3456,28000000,4,2,0.10")
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                 os.path.join(ROOT, "tests", "dp_worker.py"), "locality"], timeout=1500, env=env)
     line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
