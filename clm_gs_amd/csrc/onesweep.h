@@ -1,11 +1,15 @@
 // Single-launch primitives of the tile-binning stage for gfx950 (isect.hip): an inclusive int64 scan and one
 // radix-sort pass per launch, both by decoupled look-back between workgroups of ONE launch.
 //
-// Why (profiles/r03_kernel_stats.csv): the binning chain of a camera was ~30 launches of 6-60 us each -- three
-// kernels per 8-bit digit (block histograms, a scan of the [256][blocks] table, the scatter) and three per scan --
-// i.e. bound by launch boundaries and by the load -> LDS -> store latency chain of many tiny grids, not by bytes.
+// Why it was built (profiles/r03_kernel_stats.csv): the binning chain of a camera was ~30 launches of 6-60 us each --
+// three kernels per 8-bit digit (block histograms, a scan of the [256][blocks] table, the scatter) and three per scan.
 // Here a sort pass is ONE launch (digit counts of ALL passes are taken up front, by the kernel that produces the
 // keys) and a scan is folded into the kernel that produces its input.
+// What was MEASURED (round 4): slower than the three-launch form on MI355X -- 60-79 us per pass
+// over 3.3 M keys against 30 + 11 + 11, 155-205 us over 9.3 M keys against 106 + 34 + 34, for every block shape
+// (1 / 2 / 4 / 8 rounds of 1024 keys per workgroup) and every look-back window (2-16 words per thread and step); the
+// single-word scan 40 us for 2.2 M elements against 37 us.  The route is selected with CLMGS_BINNING=lookback (the
+// default is `fused`, isect.hip) and kept as a tested alternative: element-for-element equal lists.
 //
 // Inter-workgroup protocol (MI355X guide, Guideline 16, form R2 "the data IS the flag"): a workgroup takes a TICKET
 // from a device counter -- its chunk of the input is the ticket, so every lower chunk belongs to a workgroup that is
@@ -14,18 +18,17 @@
 // past the non-coherent per-XCD L2s); successors poll those words with relaxed agent-scope atomic loads.  No payload
 // travels separately from its flag, hence no fences.  Every polled word is zeroed by ONE hipMemsetAsync of the
 // call's control block before the first kernel of the call; every spin is bounded (a timeout raises the library's
-// device error word, checked by clmgs_device_errors(), and the kernel still terminates).
+// device error word, read by clmgs_device_errors(), and the kernel still terminates).
 //
-// Sort blocks are FAT (8192 keys per 256-thread workgroup): a look-back step reads a 1 KB row of 256 per-digit
-// words, and with everything dispatched at once the PREFIX frontier grows quadratically in the number of steps, so
-// a workgroup of the first wave reads ~sqrt(2 k W) rows (k = its ticket, W = 4 words in flight per thread): ~50-100
-// rows = its own payload again at 8192 keys, but 8x its payload at 1024 keys.
+// A look-back step of a sort pass reads a 1 KB row of 256 per-digit words; with everything dispatched at once the
+// PREFIX frontier grows quadratically in the number of steps, so a workgroup of the first wave reads ~sqrt(2 k W)
+// rows (k = its ticket, W = words in flight per thread).
 #pragma once
 #include "common.h"
 
 namespace clmgs {
 
-uint32_t* device_error_word();  // host_ops.cpp: one zero-initialised device word per process (lazy)
+uint32_t* device_error_word();  // isect.hip: the address of the library's zero-initialised device error word
 
 constexpr uint32_t LB_AGG = 1u, LB_PREFIX = 2u;
 constexpr unsigned LB_SPIN_LIMIT = 1u << 22;  // polls (~1 us each): seconds -- only a lost workgroup gets there
