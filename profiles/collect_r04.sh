@@ -5,7 +5,7 @@ set -x
 R=$(pwd)
 O=$R/gpurun_out/r04
 mkdir -p $O
-git -C $R rev-parse --short HEAD > $O/commit.txt 2>/dev/null
+# .git does not travel to the GPU box: the label passed to make_pmc_json.py names the tree
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_28m_final.log 2> $O/bench_28m_final.err
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --opt overlap_cameras=false --no-host-leg --no-trainer-leg > $O/bench_28m_no_overlap.log 2>&1
 CLMGS_BINNING=legacy timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-trainer-leg > $O/bench_28m_binning_legacy.log 2>&1
