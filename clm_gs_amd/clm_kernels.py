@@ -234,13 +234,21 @@ def adam_rows(p, g, m, v, rows, col_lr, beta1, beta2, eps, step, bias_correction
 
 
 def adam_catch_up(p, m, v, last_step, rows, col_lr, beta1, beta2, eps, to_step, bias_correction=True,
-                  max_replay=256, g=None, g_step=None, grad_scale=1.0, keep_grad=False):
+                  max_replay=256, g=None, g_step=None, grad_scale=1.0, keep_grad=False, moment_row0=0):
     """Replay the deferred zero-gradient Adam steps of `rows` (None = all) up to `to_step` and
     stamp them; with g / g_step also apply the gradient step that is waiting for a row, at its own
-    step (see clmgs_adam_catch_up)."""
+    step (see clmgs_adam_catch_up).  moment_row0 > 0: m / v are a SHARD of the moment tables whose first row is
+    global row `moment_row0` (camera-DP, moments held by the owner of a row range only); the explicit row list
+    must then stay inside the shard -- the library indexes every table by global row id from the base pointer it
+    is given (include/clmgs.h), so the shard travels as a base moved back by moment_row0 rows."""
     L = _lib.lib()
     n_rows = rows.numel() if rows is not None else p.shape[0]
-    check(L.clmgs_adam_catch_up(stream(), dptr(p, F32), dptr(m, F32), dptr(v, F32), dptr(last_step, I32),
+    m_ptr, v_ptr = dptr(m, F32), dptr(v, F32)
+    if moment_row0:
+        assert rows is not None, "a moment shard needs an explicit row list"
+        back = int(moment_row0) * int(p.shape[-1]) * 4
+        m_ptr, v_ptr = ctypes.c_void_p(m_ptr.value - back), ctypes.c_void_p(v_ptr.value - back)
+    check(L.clmgs_adam_catch_up(stream(), dptr(p, F32), m_ptr, v_ptr, dptr(last_step, I32),
                                 dptr(rows, None, True), _idx64(rows), int(n_rows), int(p.shape[-1]),
                                 dptr(col_lr, F32), float(beta1), float(beta2), float(eps), int(to_step),
                                 int(bool(bias_correction)), int(max_replay), dptr(g, F32, True),

@@ -271,8 +271,13 @@ class BaseGaussianModel(ABC):
         if hasattr(self, "flush_lazy_rows"):  # deferred row optimizers (HBM lazy rows / host rows)
             self.flush_lazy_rows()
         opt = {}
+        # camera-DP with sharded row moments (clm_offload/gaussian_model.py): the full tables are assembled by a
+        # collective, so capture() is then called on ALL ranks (as flush_lazy_rows above already requires)
+        full = self.row_moments_full() if getattr(self, "moments_sharded", False) else None
         for g in self.optimizer.param_groups:
             st = self._opt_state(g["params"][0])
+            if full is not None and g["name"] == "parameters":
+                st = dict(st, exp_avg=full[0], exp_avg_sq=full[1])
             opt[g["name"]] = {
                 "lr": g["lr"],
                 "exp_avg": st["exp_avg"].detach().cpu().clone() if "exp_avg" in st else None,
@@ -303,8 +308,11 @@ class BaseGaussianModel(ABC):
                 continue
             st = self._opt_state(p)
             if "exp_avg" in st:  # row optimizer: state lives in the model's capacity buffers
-                st["exp_avg"].copy_(saved["exp_avg"])
-                st["exp_avg_sq"].copy_(saved["exp_avg_sq"])
+                a, b = 0, saved["exp_avg"].shape[0]
+                if getattr(self, "moments_sharded", False) and g["name"] == "parameters":
+                    a, b = self._mom_lo, self._mom_lo + st["exp_avg"].shape[0]  # this rank's shard of the saved tables
+                st["exp_avg"].copy_(saved["exp_avg"][a:b])
+                st["exp_avg_sq"].copy_(saved["exp_avg_sq"][a:b])
                 st["step"] = int(saved["step"])
             else:              # torch Adam creates its state lazily
                 st["step"] = torch.tensor(saved["step"], dtype=torch.float32, device=p.device)

@@ -1011,7 +1011,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
             a_ = utils.get_args()
             if dp.active() and (getattr(a_, "dp_owner_computes", False) or getattr(a_, "dp_locality", False)):
                 gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
-            gaussians.catch_up_rows(f.to(torch.int32))
+            if not getattr(gaussians, "moments_sharded", False):  # (sharded moments: the flush left every row current)
+                gaussians.catch_up_rows(f.to(torch.int32))
         if getattr(gaussians, "deferred_host_rows", False):  # host rows: apply what is waiting for them
             gaussians.host_rows_prepare(f.to(torch.int32).cpu().contiguous(), None)
         xyz = gaussians._xyz.detach()[f]

@@ -23,6 +23,11 @@ from ..base_gaussian_model import BaseGaussianModel
 _ROW_BUFFERS = ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer")
 
 
+def dp_range(n):
+    from ... import dp
+    return dp.owner_range(n)
+
+
 class GaussianModelCLMOffload(BaseGaussianModel):
     _GPU_GROUPS = (("xyz", "_xyz"), ("opacity", "_opacity"), ("scaling", "_scaling"),
                    ("rotation", "_rotation"))
@@ -88,12 +93,23 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             {"params": [self._parameters], "lr": training_args.feature_lr, "name": "parameters"},
         ]
         cap = self.parameters_buffer.shape[0]
-        self._exp_avg_buffer = self._alloc_rows(cap).zero_()
-        self._exp_avg_sq_buffer = self._alloc_rows(cap).zero_()
+        # camera-DP, locality exchange: only the OWNER of a row ever steps it (engine.py: catch_up_rows(own rows)), so
+        # the two moment tables are held for the owned row range only -- 2 x 192 B x N / ranks instead of 2 x 192 B x N
+        from ... import dp
+        self._mom_sharded = bool((not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True)
+                                 and dp.active() and getattr(a, "dp_locality", False)
+                                 and getattr(a, "dp_shard_moments", True))
+        self._mom_lo, self._mom_n = 0, n
+        m_cap, m_n = cap, n
+        if self._mom_sharded:
+            lo, hi = dp.owner_range(n)
+            self._mom_lo, m_n, m_cap = lo, hi - lo, self._moment_capacity(cap)
+        self._exp_avg_buffer = self._alloc_rows(m_cap).zero_()
+        self._exp_avg_sq_buffer = self._alloc_rows(m_cap).zero_()
         self.optimizer = UnifiedAdam(
             l, [3, 45], [training_args.feature_lr, training_args.feature_lr / 20.0], lr=0.0,
             bias_correction=True, betas=(0.9, 0.999), eps=1e-15, fused=True, sparse=a.sparse_adam,
-            state_tensors=(self._exp_avg_buffer[:n], self._exp_avg_sq_buffer[:n]))
+            state_tensors=(self._exp_avg_buffer[:m_n], self._exp_avg_sq_buffer[:m_n]))
         lr_scale = self._scale_groups_for_bsz(training_args)
         if training_args.lr_scale_mode in ("linear", "sqrt"):
             self.optimizer.columns_lr *= lr_scale
@@ -196,10 +212,27 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         return bool(self.lazy_rows and getattr(a, "fused_front_end", True) and getattr(a, "first_touch_grads", True)
                     and dp_ok and not self.deferred_host_rows)
 
+    @property
+    def moments_sharded(self):
+        """Row moments held for the owned row range only (camera-DP locality exchange, training_setup)."""
+        return bool(getattr(self, "_mom_sharded", False))
+
+    @staticmethod
+    def _moment_capacity(cap):
+        from ... import dp
+        return -(-int(cap) // dp.world_size()) + 1  # the largest owner range of any n <= cap
+
     def catch_up_rows(self, rows=None, to_step=None):
-        """Bring `rows` (None = all) up to date with the zero-gradient Adam steps they skipped."""
+        """Bring `rows` (None = all; with sharded moments: all OWNED rows -- the rest are replicas that their owners
+        keep current) up to date with the zero-gradient Adam steps they skipped."""
         if not self.lazy_rows:
             return
+        if self.moments_sharded and rows is None:
+            lo = self._mom_lo
+            hi = lo + self.optimizer.cpu_adam.state[self._parameters]["exp_avg"].shape[0]
+            if hi <= lo:
+                return
+            rows = torch.arange(lo, hi, dtype=torch.int32, device=self._xyz.device)
         from ...clm_kernels import adam_catch_up
         opt = self.optimizer.cpu_adam
         g = opt.param_groups[0]
@@ -213,7 +246,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         adam_catch_up(p.data, st["exp_avg"], st["exp_avg_sq"], self._row_last_step, rows, col_lr,
                       g["betas"][0], g["betas"][1], g["eps"], to_step, g["bias_correction"],
                       g=self.parameters_grad_buffer[:p.shape[0]], g_step=self._row_g_step,
-                      grad_scale=1.0 / (self.args.bsz * dp.world_size()), keep_grad=self.first_touch_grads)
+                      grad_scale=1.0 / (self.args.bsz * dp.world_size()), keep_grad=self.first_touch_grads,
+                      moment_row0=self._mom_lo if self.moments_sharded else 0)
 
     def flush_lazy_rows(self, exchange=True):
         """Apply every deferred row step that is still waiting.  exchange=False (owner-computes / locality
@@ -250,8 +284,12 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                 return
             self._owner_dirty = False
             st = self.optimizer.cpu_adam.state[self._parameters]
-            dp.owner_gather_dense([self._parameters.data, st["exp_avg"], st["exp_avg_sq"],
-                                   self.parameters_grad_buffer[:n]], n)
+            tables = [self._parameters.data]
+            if not self.moments_sharded:  # sharded: a row's moments never leave its owner
+                tables += [st["exp_avg"], st["exp_avg_sq"]]
+            if not self.first_touch_grads:  # clearing policy: the owners' consumed (zeroed) rows replace the partial sums
+                tables.append(self.parameters_grad_buffer[:n])
+            dp.owner_gather_dense(tables, n)
             self._row_last_step[:n] = self.optimizer.cpu_adam.global_step
             self._row_g_step[:n] = 0
             return
@@ -320,8 +358,12 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         opt.param_groups[0]["params"][0] = self._parameters
         if st is None:
             st = {"step": opt.global_step}
-        st["exp_avg"] = self._exp_avg_buffer[:n]
-        st["exp_avg_sq"] = self._exp_avg_sq_buffer[:n]
+        m_n = n
+        if self.moments_sharded:
+            assert self._mom_n == n, "sharded moments were not redistributed for the new row count"
+            m_n = dp_range(n)[1] - self._mom_lo
+        st["exp_avg"] = self._exp_avg_buffer[:m_n]
+        st["exp_avg_sq"] = self._exp_avg_sq_buffer[:m_n]
         opt.state[self._parameters] = st
         self.optimizer.state = self.optimizer.gpu_adam.state | self.optimizer.cpu_adam.state
 
@@ -344,19 +386,82 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             return
         raise KeyError(name)
 
+    def _full_row_buffers(self):
+        """The [capacity,48] tables indexed by global row id on this rank."""
+        return _ROW_BUFFERS[:2] if self.moments_sharded else _ROW_BUFFERS
+
+    def _redistribute_moments(self, idx, n_new):
+        """Sharded row moments after a structural change: new row j <- old row idx[j] (int64 on the GPU, the same on
+        every rank; -1 = a new row, zero moments).  Owner ranges are index ranges of the CURRENT row count, so an
+        append / prune / re-sort moves range borders: every rank sends the rows of its old shard that landed in
+        another rank's new range (one all_to_all of [rows, 96] lines; the bulk stays local) and rebuilds its shard."""
+        import torch.distributed as dist
+        from ... import dp
+        G, r = dp.world_size(), dp.rank()
+        n_old = self._mom_n
+        dev = self._exp_avg_buffer.device
+        old_cuts = [(q * n_old) // G for q in range(G + 1)]
+        new_cuts = [(q * n_new) // G for q in range(G + 1)]
+        lo, hi = old_cuts[r], old_cuts[r + 1]
+        lo2, hi2 = new_cuts[r], new_cuts[r + 1]
+        idx = idx.to(dev)
+        assert idx.numel() == n_new and idx.dtype == torch.int64
+        send_rows = []
+        for d in range(G):  # in d's new-row order: the receiver lists its positions in the same order
+            sel = idx[new_cuts[d]:new_cuts[d + 1]]
+            send_rows.append(sel[(sel >= lo) & (sel < hi)] - lo)
+        mine = idx[lo2:hi2]
+        recv_pos = [torch.nonzero((mine >= old_cuts[q]) & (mine < old_cuts[q + 1])).flatten() for q in range(G)]
+        send_n = [int(t.numel()) for t in send_rows]
+        recv_n = [int(t.numel()) for t in recv_pos]
+        rows = torch.cat(send_rows)
+        send = torch.cat((self._exp_avg_buffer[rows], self._exp_avg_sq_buffer[rows]), dim=1)
+        recv = torch.empty((sum(recv_n), 96), dtype=torch.float32, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_n, input_split_sizes=send_n)
+        dp._count("moments_all_to_all", (send.shape[0] - send_n[r]) * 96 * 4)
+        m_cap = max(self._exp_avg_buffer.shape[0], self._moment_capacity(self.parameters_buffer.shape[0]))
+        del send
+        self._exp_avg_buffer = self._exp_avg_sq_buffer = None
+        new_m = torch.zeros((m_cap, 48), dtype=torch.float32, device=dev)
+        new_v = torch.zeros((m_cap, 48), dtype=torch.float32, device=dev)
+        pos = torch.cat(recv_pos)
+        if pos.numel():
+            new_m[pos] = recv[:, :48]
+            new_v[pos] = recv[:, 48:]
+        self._exp_avg_buffer, self._exp_avg_sq_buffer = new_m, new_v
+        self._mom_lo, self._mom_n = lo2, n_new
+
+    def row_moments_full(self):
+        """(exp_avg, exp_avg_sq) of ALL rows on this rank -- with sharded moments a COLLECTIVE (all ranks call it:
+        capture()), otherwise the optimizer's own tensors."""
+        st = self.optimizer.cpu_adam.state[self._parameters]
+        if not self.moments_sharded:
+            return st["exp_avg"], st["exp_avg_sq"]
+        from ... import dp
+        n = self._parameters.shape[0]
+        lo, hi = dp.owner_range(n)
+        out = []
+        for t in (st["exp_avg"], st["exp_avg_sq"]):
+            full = torch.zeros((n, 48), dtype=torch.float32, device=t.device)
+            full[lo:hi] = t
+            dp.owner_gather_dense([full], n)
+            out.append(full)
+        return out[0], out[1]
+
     def _grow(self, need):
         cap = self.parameters_buffer.shape[0]
         if need <= cap:
             return
         new_cap = max(need, int(cap * 1.5))
         n = self._parameters.shape[0]
-        for attr in _ROW_BUFFERS:
+        for attr in self._full_row_buffers():
             old = getattr(self, attr)
             new = self._alloc_rows(new_cap)
             new[:n].copy_(old[:n])
             if attr != "parameters_buffer":
                 new[n:].zero_()
             setattr(self, attr, new)
+        # (sharded moment tables are re-made at their new size by _redistribute_moments)
 
     def _append_rows(self, new):
         k = new["xyz"].shape[0]
@@ -382,8 +487,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             self._row_last_step[n:n + k] = self.optimizer.cpu_adam.global_step
         self.parameters_buffer[n:n + k].copy_(new["shs48"])
         self.parameters_grad_buffer[n:n + k].zero_()
-        self._exp_avg_buffer[n:n + k].zero_()
-        self._exp_avg_sq_buffer[n:n + k].zero_()
+        if self.moments_sharded:
+            dev = self.parameters_buffer.device
+            self._redistribute_moments(torch.cat((torch.arange(n, dtype=torch.int64, device=dev),
+                                                  torch.full((k,), -1, dtype=torch.int64, device=dev))), n + k)
+        else:
+            self._exp_avg_buffer[n:n + k].zero_()
+            self._exp_avg_sq_buffer[n:n + k].zero_()
         ext = {"xyz": new["xyz"], "opacity": new["opacity"], "scaling": new["scaling"],
                "rotation": new["rotation"]}
         for name, attr in self._GPU_GROUPS:
@@ -406,13 +516,15 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if scr is None or scr.shape[0] != cap:
             scr = torch.empty((cap, 48), dtype=torch.float32, device=self.parameters_buffer.device)
         idx = idx.contiguous()
-        for attr in _ROW_BUFFERS:
+        for attr in self._full_row_buffers():
             buf = getattr(self, attr)
             if m:
                 clm_kernels._rows("clmgs_rows_gather", scr[:m], buf, None, idx, 0)
             setattr(self, attr, scr)
             scr = buf
         self._row_scratch = scr
+        if self.moments_sharded:
+            self._redistribute_moments(idx[:m], m)
 
     def drop_row_scratch(self):
         """Hand the scratch table of _regather_row_tables back to the allocator (one table of the model's capacity)."""

@@ -52,6 +52,7 @@ def default_args(**over):
         pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         dp_overlap=True,        # camera-DP locality exchange: split B / D so that they hide behind the first / last camera
+        dp_shard_moments=True,  # camera-DP locality exchange (dense deferred row optimizer): m / v of the SH row table only for the owned row range
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)

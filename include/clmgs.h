@@ -312,7 +312,10 @@ int clmgs_adam_rows(void* stream, float* p, float* g, float* m, float* v, const 
  * with grad_scale, between the replays before and after it, and the gradient row is zeroed: the same
  * operations in the same order as the eager update at the end of that batch (optimizer.py:130-144 /
  * clm_offload/engine.py:316-328), in one pass over the row instead of two.  keep_grad = 1: the consumed
- * row is not cleared (producers that STORE on first touch: clmgs_preprocess_bwd with sh_stamp). */
+ * row is not cleared (producers that STORE on first touch: clmgs_preprocess_bwd with sh_stamp).
+ * With an explicit row list every table is addressed as base + row * cols and ONLY the listed rows are touched: m / v
+ * may therefore be bases moved back by row0 rows in front of a shard that holds rows row0.. only (camera-DP: the moments
+ * of a row live at its owner, clm_gs_amd/strategies/clm_offload/gaussian_model.py moments_sharded). */
 /* The packed [N,12] mirror of the four GPU-resident parameter tensors, and their dense Adam when the
  * engine accumulates gradients in a packed [N,12] table: params / exp_avg / exp_avg_sq are HOST
  * arrays of 4 device pointers (xyz [N,3], opacity [N,1], scaling [N,3], rotation [N,4]), lr4 a

@@ -50,6 +50,10 @@ def _train(m, batches, args, world=1):
         it += len(batch) * world  # the image counter strides by the global batch
     m.flush_lazy_rows()
     torch.cuda.synchronize()
+    # row moments: sharded by owner range under the locality exchange; row_moments_full() assembles them (collective)
+    _train.info = {"moments_sharded": bool(getattr(m, "moments_sharded", False)),
+                   "moment_rows_held": int(m._exp_avg_buffer.shape[0]), "n": int(m._parameters.shape[0])}
+    _train.moments = [t.clone() for t in m.row_moments_full()]
     return [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
             m._rotation.detach().clone(), m._parameters.detach().clone()]
 
@@ -75,6 +79,25 @@ def trainer_mode(rank, world, owner=False, locality=False):
     m = _model(sc, args)
     log = io.StringIO()
     trainer.training(m, _Scene, cams, [], log, iterations=64)
+    shard_same = None
+    if locality:
+        # sharded row moments (the default) against the replicated tables: the same arithmetic on the same rows, so
+        # the two runs must agree bit for bit through clone / split / prune / re-sort (shards rebuilt every time)
+        assert m.moments_sharded and m._exp_avg_buffer.shape[0] <= m.parameters_buffer.shape[0] // world + 2
+        m.flush_lazy_rows()
+        args.dp_shard_moments = False
+        m2 = _model(sc, args)
+        assert not m2.moments_sharded
+        trainer.training(m2, _Scene, cams, [], io.StringIO(), iterations=64)
+        m2.flush_lazy_rows()
+        shard_same = m2.get_xyz.shape[0] == m.get_xyz.shape[0] and all(
+            bool(torch.equal(a.detach(), b.detach())) for a, b in
+            zip((m._xyz, m._opacity, m._scaling, m._rotation, m._parameters),
+                (m2._xyz, m2._opacity, m2._scaling, m2._rotation, m2._parameters)))
+        full = m.row_moments_full()
+        st2 = m2.optimizer.cpu_adam.state[m2._parameters]
+        shard_same = bool(shard_same and torch.equal(full[0], st2["exp_avg"]) and torch.equal(full[1], st2["exp_avg_sq"]))
+        del m2
     n = torch.tensor([m.get_xyz.shape[0]], device="cuda")
     n0t = n.clone()
     dist.broadcast(n0t, src=0)
@@ -93,7 +116,7 @@ def trainer_mode(rank, world, owner=False, locality=False):
         print("DPRESULT " + json.dumps({
             "replicas_equal": all(flags), "n_before": n0, "n_after": int(n.item()),
             "global_stride": "iteration[1,9)" in text and "iteration[9,17)" in text,
-            "split": "Number of split gaussians" in text}))
+            "split": "Number of split gaussians" in text, "sharded_equals_replicated_moments": shard_same}))
     dist.destroy_process_group()
 
 
@@ -142,6 +165,7 @@ def main():
         dp.reset_wire()
         mine = _train(_model(sc, args), per_rank[rank], args, world)
         wire = dp.wire_bytes()
+        mine_info, mine_moments = _train.info, _train.moments
         local_share = float(sum(int(shares[c, q]) for c, q in enumerate(ranks_of)) / max(1, int(shares.sum())))
     else:
         mine = _train(_model(sc, args), [gb[rank::world] for gb in global_batches], args, world)
@@ -171,7 +195,9 @@ def main():
         err.append(float((a - b).norm() / b.norm().clamp_min(1e-12)))
     res = {"replicas_equal": all(flags), "rel_l2_vs_single": err}
     if wire is not None:
-        res.update(wire=wire, local_share=local_share)
+        res.update(wire=wire, local_share=local_share, **mine_info)
+        res["moments_rel_l2_vs_single"] = [float((a - b).norm() / b.norm().clamp_min(1e-30))
+                                           for a, b in zip(mine_moments, _train.moments)]
     print("DPRESULT " + json.dumps(res))
 
 

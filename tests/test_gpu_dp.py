@@ -94,6 +94,10 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev):
     assert max(res["rel_l2_vs_single"]) < 2e-4, res
     assert res["local_share"] > 0.5, res                      # the deal keeps most touched rows at home
     assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
+    # row moments live at the owner of a row range only: half the table per rank at 2 ranks, and
+    # the assembled tables equal the single-rank run's
+    assert res["moments_sharded"] is True and res["moment_rows_held"] <= res["n"] // 2 + 2, res
+    assert max(res["moments_rel_l2_vs_single"]) < 1e-3, res
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
@@ -140,6 +144,9 @@ def test_trainer_locality_densify_keeps_replicas_identical(dev):
     res = json.loads(line[len("DPRESULT "):])
     assert res["replicas_equal"] is True, res
     assert res["n_after"] != res["n_before"] and res["split"], res
+    # row moments sharded by owner range (default) == the replicated tables, bit for bit, through clone / split /
+    # prune / re-sort (the shards are rebuilt by an all_to_all at every structural change)
+    assert res["sharded_equals_replicated_moments"] is True, res
 
 
 def test_trainer_two_ranks_densify_keeps_replicas_identical(dev):
