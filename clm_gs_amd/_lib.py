@@ -72,6 +72,9 @@ SIGNATURES = {
     "clmgs_host_groups_temp_bytes": (_sz, [_i64]),
     "clmgs_host_groups": (_i, [_vp, _i64, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_publish_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i]),
+    "clmgs_visibility_candidates": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _vp]),
+    "clmgs_small_rows_scatter": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "clmgs_adam_small_packed_range": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f, _vp, _i]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_device_errors": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),

@@ -457,24 +457,31 @@ constexpr int SA_ROWS = 256;
 __device__ __forceinline__ float adam_elem(float& m, float& v, float p, float g, float lr_bc, float beta1,
                                            float beta2, float ob1, float ob2, float eps,
                                            float inv_sqrt_bc2) {
-  m = beta1 * m + ob1 * g;
-  v = beta2 * v + ob2 * g * g;
-  return p - lr_bc * adam_ratio(m, v, inv_sqrt_bc2, eps);
+  // explicit roundings (no contraction left to the compiler): the <false> and <true> forms of the kernel below, and
+  // any future caller, produce the same bits from the same inputs
+  m = __builtin_fmaf(beta1, m, __fmul_rn(ob1, g));
+  v = __builtin_fmaf(beta2, v, __fmul_rn(__fmul_rn(ob2, g), g));
+  const float ratio = __fmul_rn(m, __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_sqrtf(v), inv_sqrt_bc2, eps)));
+  return __builtin_fmaf(-lr_bc, ratio, p);
 }
 
 // g_stamp != NULL (first-touch producers, clmgs_preprocess_bwd with sh_stamp): row r carries a gradient of
 // THIS step only if g_stamp[r] == cur_step; other rows hold consumed leftovers, are not read (their
 // gradient is zero) and nothing is cleared.
+// RANGE (camera-DP, the small attributes computed by the owner of a row range): only rows row_begin <= r < row_end
+// are stepped; the blocks that straddle the range borders pass the other rows through unchanged (same values written
+// back, mirror row rewritten from the tensors).
+template <bool RANGE>
 __global__ void __launch_bounds__(SA_ROWS)
-adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
+adam_small_packed_kernel(int64_t n, int64_t row_begin, int64_t row_end, SmallAdam t, float4* __restrict__ packed_p,
                          float4* __restrict__ packed_g, float beta1, float beta2, float ob1,
                          float ob2, float eps, float inv_bc1, float inv_sqrt_bc2, float grad_scale,
                          const int32_t* __restrict__ g_stamp, int cur_step) {
   __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
   __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
   const int tid = threadIdx.x;
-  const int64_t n_blocks = (n + SA_ROWS - 1) / SA_ROWS;
-  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+  const int64_t n_blocks = RANGE ? (row_end + SA_ROWS - 1) / SA_ROWS : (n + SA_ROWS - 1) / SA_ROWS;
+  for (int64_t blk = (RANGE ? row_begin / SA_ROWS : 0) + blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const int64_t row0 = blk * SA_ROWS;
     const int rows = (int)min((int64_t)SA_ROWS, n - row0);
     __syncthreads();
@@ -508,8 +515,13 @@ adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int idx = i + k, row = idx / w, e = idx - row * w;
-            pp[k] = adam_elem(mm[k], vv[k], pp[k], sg[row * 12 + co + e] * grad_scale, lr_bc, beta1, beta2,
-                              ob1, ob2, eps, inv_sqrt_bc2);
+            // (RANGE: the same arithmetic, then a select -- a branch around it changes how the compiler contracts the
+            // moment updates, and the two forms of the kernel must agree bit for bit)
+            float m2 = mm[k], v2 = vv[k];
+            const float pn = adam_elem(m2, v2, pp[k], sg[row * 12 + co + e] * grad_scale, lr_bc, beta1, beta2,
+                                       ob1, ob2, eps, inv_sqrt_bc2);
+            const bool act = !RANGE || (row0 + row >= row_begin && row0 + row < row_end);
+            pp[k] = act ? pn : pp[k]; mm[k] = act ? m2 : mm[k]; vv[k] = act ? v2 : vv[k];
             sp[row * 12 + co + e] = pp[k];
           }
           *reinterpret_cast<float4*>(P + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -519,10 +531,12 @@ adam_small_packed_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p,
           for (int idx = i; idx < n_el; ++idx) {  // ragged tail of the last block
             const int row = idx / w, e = idx - row * w;
             float mm = M[idx], vv = V[idx];
-            const float pn = adam_elem(mm, vv, P[idx], sg[row * 12 + co + e] * grad_scale, lr_bc, beta1,
-                                       beta2, ob1, ob2, eps, inv_sqrt_bc2);
-            P[idx] = pn; M[idx] = mm; V[idx] = vv;
-            sp[row * 12 + co + e] = pn;
+            const float p0 = P[idx];
+            const float pn = adam_elem(mm, vv, p0, sg[row * 12 + co + e] * grad_scale, lr_bc, beta1, beta2, ob1, ob2,
+                                       eps, inv_sqrt_bc2);
+            const bool act = !RANGE || (row0 + row >= row_begin && row0 + row < row_end);
+            if (act) { P[idx] = pn; M[idx] = mm; V[idx] = vv; }
+            sp[row * 12 + co + e] = act ? pn : p0;
           }
         }
       }
@@ -549,6 +563,24 @@ pack_small_kernel(int64_t n, const float* __restrict__ xyz, const float* __restr
     packed_p[3 * r] = make_float4(xyz[3 * r], xyz[3 * r + 1], xyz[3 * r + 2], opa[r]);
     packed_p[3 * r + 1] = make_float4(sca[3 * r], sca[3 * r + 1], sca[3 * r + 2], q.x);
     packed_p[3 * r + 2] = make_float4(q.y, q.z, q.w, 0.f);
+  }
+}
+
+// Camera-DP step S (dp.small_fetch): packed [n_rows,12] lines received from the owners -> the four parameter tensors
+// and the packed mirror at `rows` (unique ids)
+__global__ void __launch_bounds__(256)
+small_rows_scatter_kernel(int64_t n_rows, const int64_t* __restrict__ rows, const float4* __restrict__ src,
+                          float* __restrict__ xyz, float* __restrict__ opa, float* __restrict__ sca,
+                          float* __restrict__ rot, float4* __restrict__ packed_p) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows[i];
+    const float4 a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
+    xyz[3 * r] = a.x; xyz[3 * r + 1] = a.y; xyz[3 * r + 2] = a.z;
+    opa[r] = a.w;
+    sca[3 * r] = b.x; sca[3 * r + 1] = b.y; sca[3 * r + 2] = b.z;
+    *reinterpret_cast<float4*>(rot + 4 * r) = make_float4(b.w, c.x, c.y, c.z);
+    packed_p[3 * r] = a; packed_p[3 * r + 1] = b; packed_p[3 * r + 2] = make_float4(c.x, c.y, c.z, 0.f);
   }
 }
 
@@ -773,14 +805,48 @@ extern "C" int clmgs_pack_small(void* stream, int64_t n, const float* xyz, const
   return 0;
 }
 
+extern "C" int clmgs_small_rows_scatter(void* stream, int64_t n_rows, const int64_t* rows, const void* lines,
+                                        float* xyz, float* opacity, float* scaling, float* rotation,
+                                        void* packed_p) {
+  CLMGS_CHECK_ARG(n_rows >= 0);
+  if (n_rows == 0) return 0;
+  CLMGS_CHECK_ARG(rows && lines && xyz && opacity && scaling && rotation && packed_p &&
+                  (((uintptr_t)packed_p | (uintptr_t)lines | (uintptr_t)rotation) & 15) == 0);
+  hipLaunchKernelGGL(small_rows_scatter_kernel, dim3(min(ceil_div(n_rows, 256), 256 * 16)), dim3(256), 0,
+                     (hipStream_t)stream, n_rows, rows, (const float4*)lines, xyz, opacity, scaling, rotation,
+                     (float4*)packed_p);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t row_begin, int64_t row_end,
+                                             float* const* params, float* const* exp_avg,
+                                             float* const* exp_avg_sq, const double* lr4, void* packed_p,
+                                             void* packed_g, double beta1, double beta2, double eps, int step,
+                                             int bias_correction, float grad_scale, const int32_t* g_stamp,
+                                             int cur_step);
+
 extern "C" int clmgs_adam_small_packed(void* stream, int64_t n, float* const* params,
                                        float* const* exp_avg, float* const* exp_avg_sq,
                                        const double* lr4, void* packed_p, void* packed_g,
                                        double beta1, double beta2, double eps, int step,
                                        int bias_correction, float grad_scale, const int32_t* g_stamp,
                                        int cur_step) {
+  return clmgs_adam_small_packed_range(stream, n, 0, -1, params, exp_avg, exp_avg_sq, lr4, packed_p, packed_g, beta1,
+                                       beta2, eps, step, bias_correction, grad_scale, g_stamp, cur_step);
+}
+
+// row_end < 0: all n rows (the kernel without the per-row range test); otherwise only rows row_begin <= r < row_end
+extern "C" int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t row_begin, int64_t row_end,
+                                             float* const* params, float* const* exp_avg,
+                                             float* const* exp_avg_sq, const double* lr4, void* packed_p,
+                                             void* packed_g, double beta1, double beta2, double eps, int step,
+                                             int bias_correction, float grad_scale, const int32_t* g_stamp,
+                                             int cur_step) {
   CLMGS_CHECK_ARG(n >= 0 && step >= 1);
-  if (n == 0) return 0;
+  const bool ranged = row_end >= 0;
+  if (ranged) CLMGS_CHECK_ARG(row_begin >= 0 && row_begin <= row_end && row_end <= n);
+  if (n == 0 || (ranged && row_end == row_begin)) return 0;
   CLMGS_CHECK_ARG(params && exp_avg && exp_avg_sq && lr4 && packed_p && packed_g &&
                   (((uintptr_t)packed_p | (uintptr_t)packed_g) & 15) == 0);
   SmallAdam t;
@@ -794,9 +860,17 @@ extern "C" int clmgs_adam_small_packed(void* stream, int64_t n, float* const* pa
     inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
   }
   const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
-  hipLaunchKernelGGL(adam_small_packed_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
-                     (hipStream_t)stream, n, t, (float4*)packed_p, (float4*)packed_g, (float)beta1,
-                     (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, g_stamp, cur_step);
+  if (ranged) {
+    const int64_t blocks = (row_end + SA_ROWS - 1) / SA_ROWS - row_begin / SA_ROWS;
+    hipLaunchKernelGGL(adam_small_packed_kernel<true>, dim3(min(blocks, (int64_t)256 * 16)), dim3(SA_ROWS), 0,
+                       (hipStream_t)stream, n, row_begin, row_end, t, (float4*)packed_p, (float4*)packed_g,
+                       (float)beta1, (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, g_stamp,
+                       cur_step);
+  } else {
+    hipLaunchKernelGGL(adam_small_packed_kernel<false>, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
+                       (hipStream_t)stream, n, (int64_t)0, n, t, (float4*)packed_p, (float4*)packed_g, (float)beta1,
+                       (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, g_stamp, cur_step);
+  }
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

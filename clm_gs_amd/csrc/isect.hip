@@ -11,7 +11,6 @@
 #include "onesweep.h"
 
 namespace clmgs {
-
 // Device error word of the look-back primitives (onesweep.h): bit 0 = scan look-back timed out, bit 1 = sort
 // look-back timed out.  Read (and cleared) by clmgs_device_errors().
 __device__ uint32_t g_dev_err;
@@ -1087,6 +1086,70 @@ visibility_bits_kernel(int C, int N, int W64, const float* __restrict__ means,
   }
 }
 
+// Camera-DP with the small attributes computed by their owners (clm_gs_amd/dp.py, step S): between two refreshes a
+// rank's copy of a row it does not own is STALE -- the owner has moved the mean by at most `pos_margin` (Euclidean:
+// every camera-space coordinate moves by no more than that, the view rotation is orthonormal) and multiplied the
+// largest scale by at most `scale_gain` (bounds from Adam's step bound, gaussian_model.py small_after_step).  A row is
+// a CANDIDATE if vis_classify could return non-zero for ANY state inside those bounds: depth interval against the
+// planes, the extreme values of x'/z' and y'/z' over the box, the radius bound B at the closest admissible depth.
+// Superset of every row the exact cull keeps, so after the candidates' current values have been fetched from their
+// owners the exact pass over the whole table selects exactly what it selects on one rank: rows that are not
+// candidates fail it with their stale values too (margins >= 0) and fail it with their true ones (superset).
+// NaNs fail every cull comparison -> candidate.  One extra pixel and 0.1 % on the radius cover the rounding of this
+// evaluation against vis_classify's.
+__device__ __forceinline__ bool vis_candidate(const Cam& c, float kc, const float m[3], float smax2g, float d,
+                                              float W, float H, float eps2d, float near_m, float far_m) {
+  const float x = c.R[0] * m[0] + c.R[1] * m[1] + c.R[2] * m[2] + c.t[0];
+  const float y = c.R[3] * m[0] + c.R[4] * m[1] + c.R[5] * m[2] + c.t[1];
+  const float z = c.R[6] * m[0] + c.R[7] * m[1] + c.R[8] * m[2] + c.t[2];
+  const float zl = z - d, zh = z + d;
+  if (zh < near_m || zl > far_m) return false;
+  const float zc = fmaxf(fmaxf(zl, near_m), 1e-12f), zf = fmaxf(fminf(zh, far_m), zc);
+  const float rzc = 1.f / zc, rzf = 1.f / zf;
+  const float xh = x + d, xl = x - d, yh = y + d, yl = y - d;
+  const float tx_max = xh > 0.f ? xh * rzc : xh * rzf, tx_min = xl < 0.f ? xl * rzc : xl * rzf;
+  const float ty_max = yh > 0.f ? yh * rzc : yh * rzf, ty_min = yl < 0.f ? yl * rzc : yl * rzf;
+  const float B = smax2g * rzc * rzc * kc + eps2d;
+  const float Rb = 1.001f * (3.03f * sqrtf(2.f * B + 0.1f) + 2.f) + 1.f;
+  const float mx_max = c.fx * tx_max + c.cx, mx_min = c.fx * tx_min + c.cx;
+  const float my_max = c.fy * ty_max + c.cy, my_min = c.fy * ty_min + c.cy;
+  return !(mx_max + Rb <= 0.f || mx_min - Rb >= W || my_max + Rb <= 0.f || my_min - Rb >= H);
+}
+
+__global__ void __launch_bounds__(256)
+visibility_candidates_kernel(int C, int N, int own_lo, int own_hi, const float* __restrict__ means,
+                             const float* __restrict__ log_scales, const float* __restrict__ viewmats,
+                             const float* __restrict__ Ks, float W, float H, float eps2d, float near_plane,
+                             float far_plane, float pos_margin, float scale_gain, uint8_t* __restrict__ mask) {
+  __shared__ float cam_s[VB_MAX_CAMS][VB_CAM_F];
+  const int tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    const Cam cam = load_cam(viewmats + 16 * c, Ks + 9 * c);
+    float* f = cam_s[c];
+    for (int i = 0; i < 9; ++i) f[i] = cam.R[i];
+    f[9] = cam.t[0]; f[10] = cam.t[1]; f[11] = cam.t[2];
+    f[12] = cam.fx; f[13] = cam.fy; f[14] = cam.cx; f[15] = cam.cy;
+    f[16] = vis_cam_kc(cam, W, H);
+  }
+  __syncthreads();
+  const float near_m = near_plane - (fabsf(near_plane) * 1e-5f + 1e-6f);
+  const float far_m = far_plane + fabsf(far_plane) * 1e-5f;
+  for (int n = blockIdx.x * 256 + tid; n < N; n += gridDim.x * 256) {
+    if (n >= own_lo && n < own_hi) {  // own rows are current: nothing to fetch
+      mask[n] = 0;
+      continue;
+    }
+    const float m[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    const float lmax = fmaxf(log_scales[3 * n], fmaxf(log_scales[3 * n + 1], log_scales[3 * n + 2]));
+    const float sg = __expf(lmax) * scale_gain;
+    const float smax2g = sg * sg;
+    bool any = !(smax2g < 1e30f);  // NaN / overflowing scales: let the exact pass decide
+    for (int c = 0; c < C && !any; ++c)
+      any = vis_candidate(lds_cam(cam_s[c]), cam_s[c][16], m, smax2g, pos_margin, W, H, eps2d, near_m, far_m);
+    mask[n] = any ? 1 : 0;
+  }
+}
+
 // B: after the inclusive scan of the (C+1) x W64 counts: every set bit writes its index at its rank.
 __global__ void __launch_bounds__(256)
 visibility_emit_kernel(int C, int N, int W64, const unsigned long long* __restrict__ bits,
@@ -1158,6 +1221,23 @@ extern "C" int clmgs_visibility_select_emit(void* stream, int C, int N, const vo
   const int64_t* scan = (const int64_t*)base;
   hipLaunchKernelGGL(visibility_emit_kernel, dim3(min(ceil_div((int64_t)words * 64, 256), 256 * 32)),
                      dim3(256), 0, (hipStream_t)stream, C, N, W64, bits, scan, out);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// Rows outside [own_lo, own_hi) that may be visible in any of the C cameras when their stored mean is off by up to
+// pos_margin and their largest scale by a factor up to scale_gain: mask[N] (u8).  See vis_candidate.
+extern "C" int clmgs_visibility_candidates(void* stream, int C, int N, int own_lo, int own_hi, const float* means,
+                                           const float* log_scales, const float* viewmats, const float* Ks,
+                                           int width, int height, float eps2d, float near_plane, float far_plane,
+                                           float pos_margin, float scale_gain, uint8_t* mask) {
+  CLMGS_CHECK_ARG(C >= 1 && C <= 64 && N >= 1 && width > 0 && height > 0);
+  CLMGS_CHECK_ARG(means && log_scales && viewmats && Ks && mask);
+  CLMGS_CHECK_ARG(pos_margin >= 0.f && scale_gain >= 1.f && own_lo >= 0 && own_hi >= own_lo);
+  hipLaunchKernelGGL(visibility_candidates_kernel, dim3(min(ceil_div((int64_t)N, 256), 256 * 16)), dim3(256), 0,
+                     (hipStream_t)stream, C, N, own_lo, own_hi, means, log_scales, viewmats, Ks, (float)width,
+                     (float)height, eps2d, near_plane, far_plane, pos_margin, scale_gain, mask);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -614,6 +614,49 @@ def publish_small(small_g, stamp, step, n_total, pl=None):
     return counts
 
 
+def small_fetch(rows, n_total, packed):
+    """S (dp_small_owner): the CURRENT packed small-attribute lines ([., 12]: xyz 3 | opacity 1 | scaling 3 |
+    rotation 4 | pad) of the rows `rows` (ascending int64 ids outside this rank's range: the candidates of this
+    batch's visibility pass) from their owners, whose mirror `packed` is current for their own range.
+    -> recv [len(rows), 12] in the order of `rows`.  Two host reads (owner boundaries, split sizes), three
+    all_to_alls (counts, ids, lines).  Every rank calls it every batch, also with nothing to ask for."""
+    G, r = world_size(), rank()
+    dev = rows.device
+    cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
+    bl = torch.searchsorted(rows, cuts).tolist()
+    n_r = int(rows.numel())
+    bl[0], bl[-1] = 0, n_r
+    need = [bl[q + 1] - bl[q] for q in range(G)]
+    assert need[r] == 0, "small_fetch: own rows are current, only foreign rows are fetched"
+    need_t = torch.tensor(need, dtype=torch.int64).to(dev)
+    serve_t = torch.empty_like(need_t)
+    dist.all_to_all_single(serve_t, need_t)
+    serve = serve_t.tolist()
+    serve_rows = torch.empty((sum(serve),), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(serve_rows, rows.contiguous(), output_split_sizes=serve, input_split_sizes=need)
+    send = _take(packed, serve_rows) if serve_rows.numel() else packed.new_empty((0, packed.shape[1]))
+    recv = packed.new_empty((n_r, packed.shape[1]))
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=need, input_split_sizes=serve)
+    _count("all_to_all_small_ids", 8 * (G + n_r))
+    _count("all_to_all_small", send.numel() * send.element_size())
+    return recv
+
+
+def small_scatter(rows, lines, packed, tensors):
+    """rows' packed lines -> the mirror and the four parameter tensors (xyz, opacity, scaling, rotation)."""
+    if rows.numel() == 0:
+        return
+    xyz, opa, sca, rot = tensors
+    if packed.is_cuda:
+        from . import _lib
+        _lib.check(_lib.lib().clmgs_small_rows_scatter(
+            _lib.stream(), int(rows.numel()), _lib.dptr(rows.contiguous(), torch.int64), _lib.dptr(lines.contiguous()),
+            _lib.dptr(xyz), _lib.dptr(opa), _lib.dptr(sca), _lib.dptr(rot), _lib.dptr(packed)))
+        return
+    packed[rows] = lines  # CPU tensors of the gloo tests
+    xyz[rows], opa[rows], sca[rows], rot[rows] = lines[:, 0:3], lines[:, 3:4], lines[:, 4:7], lines[:, 7:11]
+
+
 def camera_shares(filters, n_total, n_ranks):
     """[len(filters), n_ranks] int64 (host): how many of each camera's rows lie in each rank's range."""
     dev = filters[0].device
@@ -671,10 +714,13 @@ def deal_cameras(cameras, gaussians, n_ranks=None, chunk=8, per_rank=None):
     return assign_cameras(shares, per_rank), shares
 
 
-def exchange_bytes(touched_per_rank, n_total):
+def exchange_bytes(touched_per_rank, n_total, small_refresh=8):
     """Wire bytes per rank and batch of the three exchanges for given per-rank touched sets (ascending int64 id
     tensors, one per rank) -- pure index arithmetic, no communication: used to account a partition of the bench
-    scenes into virtual ranks.  -> {"allreduce": [...], "owner": [...], "locality": [...], "union": U, ...}"""
+    scenes into virtual ranks.  -> {"allreduce": [...], "owner": [...], "locality": [...], "union": U, ...}
+    "locality" is the exchange with step F (dp_small_owner off); "locality_small_owner" the default: no F, step S
+    instead (ids + 48 B lines of the candidates -- counted as the border rows, which the candidates exceed by the rim
+    the drift margins add) and the all-gather of the owned small-attribute ranges every `small_refresh` batches."""
     G = len(touched_per_rank)
     dev = touched_per_rank[0].device
     cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
@@ -691,12 +737,16 @@ def exchange_bytes(touched_per_rank, n_total):
     allreduce = [f * (240.0 * U + n_total)] * G                        # packed rows + the uint8 touched mask
     chunk = max(own_touched)
     owner = [(G - 1) * 192.0 * chunk * 2 + f * (48.0 * U + n_total)] * G
-    locality = []
+    locality, locality_so = [], []
+    own_max = max(((q + 1) * n_total) // G - (q * n_total) // G for q in range(G))
     for r in range(G):
         border = sum(per[r][q] for q in range(G) if q != r)
         serve = sum(per[p][r] for p in range(G) if p != r)
-        locality.append(8.0 * (3 * G + border) + 192.0 * serve + 240.0 * border + (G - 1) * 52.0 * chunk + 8.0 * (G - 1))
-    return {"allreduce": allreduce, "owner": owner, "locality": locality, "union": U, "n_ranks": G,
+        core = 8.0 * (3 * G + border) + 192.0 * serve + 240.0 * border + 8.0 * (G - 1)
+        locality.append(core + (G - 1) * 52.0 * chunk)
+        locality_so.append(core + 8.0 * (G + border) + 48.0 * serve + (G - 1) * 44.0 * own_max / float(small_refresh))
+    return {"allreduce": allreduce, "owner": owner, "locality": locality, "locality_small_owner": locality_so,
+            "union": U, "n_ranks": G,
             "touched": [int(t.numel()) for t in touched_per_rank],
             "border": [sum(per[r][q] for q in range(G) if q != r) for r in range(G)],
             "own_touched": own_touched, "reference_240B_x_union": 240.0 * U}

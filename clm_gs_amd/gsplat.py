@@ -145,6 +145,24 @@ def visibility_select(means, quats_raw, log_scales, viewmats, Ks, width, height,
     return pieces[:C], pieces[C]
 
 
+def visibility_candidates(means, log_scales, viewmats, Ks, width, height, pos_margin, scale_gain, own_lo, own_hi,
+                          eps2d=0.3, near_plane=0.01, far_plane=1e10):
+    """Camera-DP, small attributes computed by their owners: ascending int64 ids of the rows OUTSIDE [own_lo, own_hi)
+    that may pass visibility_select's cull in any camera while their stored mean is off by up to pos_margin and their
+    largest scale by a factor up to scale_gain (clmgs_visibility_candidates: a superset of what the exact cull keeps
+    for the true values).  One host read inside torch.nonzero (the count)."""
+    L = _lib.lib()
+    means, log_scales = means.contiguous(), log_scales.contiguous()
+    viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+    C, N = viewmats.shape[0], means.shape[0]
+    mask = torch.empty((N,), dtype=torch.uint8, device=means.device)
+    check(L.clmgs_visibility_candidates(
+        stream(), C, N, int(own_lo), int(own_hi), dptr(means, F32), dptr(log_scales, F32), dptr(viewmats, F32),
+        dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+        float(pos_margin), float(scale_gain), dptr(mask)))
+    return torch.nonzero(mask).flatten()
+
+
 # ------------------------------------------------------------ spherical harmonics
 class _SphericalHarmonics(torch.autograd.Function):
     @staticmethod

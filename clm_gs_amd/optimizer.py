@@ -104,12 +104,14 @@ class UnifiedAdam(torch.optim.Optimizer):
         self.state = self.gpu_adam.state | self.cpu_adam.state
 
     @torch.no_grad()
-    def gpu_step_packed(self, packed_p, packed_g, grad_scale=1.0, g_stamp=None, cur_step=0):
+    def gpu_step_packed(self, packed_p, packed_g, grad_scale=1.0, g_stamp=None, cur_step=0, row_range=None):
         """Dense Adam of the four GPU-resident tensors from the packed [N,12] gradient table
         (clmgs_adam_small_packed): updates p / exp_avg / exp_avg_sq of every group in place,
         refreshes the packed parameter mirror and zeroes the gradient table, all in one pass.
         g_stamp / cur_step: first-touch gradient table (only rows stamped cur_step carry a gradient;
-        nothing is zeroed)."""
+        nothing is zeroed).  row_range = (lo, hi): only these rows are stepped (camera-DP: the small attributes are
+        computed by the owner of a row range, clm_offload/gaussian_model.py small_owner); the step counters advance
+        as usual -- they are per tensor, and every rank steps its range at every batch."""
         import ctypes
         from . import _lib
         assert not isinstance(self.gpu_adam, SelectiveAdam)
@@ -139,8 +141,9 @@ class UnifiedAdam(torch.optim.Optimizer):
         g0 = order[0]
         arr = lambda xs: (ctypes.c_void_p * 4)(*xs)
         L = _lib.lib()
-        _lib.check(L.clmgs_adam_small_packed(
-            _lib.stream(), int(packed_p.shape[0]), arr(ps), arr(ms), arr(vs), (ctypes.c_double * 4)(*lrs),
+        lo, hi = (0, -1) if row_range is None else (int(row_range[0]), int(row_range[1]))
+        _lib.check(L.clmgs_adam_small_packed_range(
+            _lib.stream(), int(packed_p.shape[0]), lo, hi, arr(ps), arr(ms), arr(vs), (ctypes.c_double * 4)(*lrs),
             _lib.dptr(packed_p), _lib.dptr(packed_g), float(g0["betas"][0]), float(g0["betas"][1]),
             float(g0["eps"]), int(step), 1, float(grad_scale),
             None if g_stamp is None else _lib.dptr(g_stamp, torch.int32), int(cur_step)))

@@ -231,6 +231,13 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]
     touched = touched_rows = None
+    # camera-DP, small attributes at their owners (gaussian_model.small_owner): step S -- the current values of every
+    # foreign row that may be visible this batch arrive BEFORE the visibility pass reads them
+    small_owner = bool(getattr(gaussians, "small_owner", False) and gaussians.lazy_rows and dp.active()
+                       and not args.stop_update_param)
+    if small_owner:
+        with torch.no_grad(), _lib.host_region("dp_small_fetch"):
+            gaussians.small_prepare(batched_cameras)
     with torch.no_grad():
         if getattr(args, "fused_front_end", True):
             # same fast exp as the fused front end -> filter and render agree on every cull;
@@ -554,7 +561,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
             else:
                 dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
-            dp.publish_small(small_gk, ft_stamp, step, N, border)
+            if not small_owner:  # (small_owner: the summed lines are home, and only the owner steps the row)
+                dp.publish_small(small_gk, ft_stamp, step, N, border)
         elif owner is not None:
             # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
             # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);
@@ -582,7 +590,10 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         return losses, ordered_cams, sparsity
     if use_packed:
         gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()),
-                                            g_stamp=ft_stamp, cur_step=step)
+                                            g_stamp=ft_stamp, cur_step=step,
+                                            row_range=dp.owner_range(N) if (small_owner and locality) else None)
+        if small_owner and locality:
+            gaussians.small_after_step()
     else:
         _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
                        grad_div=bsz * dp.world_size())
@@ -1004,13 +1015,15 @@ def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_gr
 def clm_offload_eval_one_cam(camera, gaussians, background, scene):
     """Single-camera render of the visible rows (engine.py:928-979) -> image[3,H,W]."""
     with torch.no_grad():
+        a_ = utils.get_args()
+        dp_partial = bool(getattr(gaussians, "lazy_rows", False) and dp.active()
+                          and (getattr(a_, "dp_owner_computes", False) or getattr(a_, "dp_locality", False)))
+        if dp_partial:  # before the filter: with small_owner the positions of foreign rows are stale until then
+            gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
         filters, _, _ = calculate_filters([camera], gaussians.get_xyz, gaussians.get_opacity,
                                           gaussians.get_scaling, gaussians.get_rotation)
         f = filters[0]
         if getattr(gaussians, "lazy_rows", False):
-            a_ = utils.get_args()
-            if dp.active() and (getattr(a_, "dp_owner_computes", False) or getattr(a_, "dp_locality", False)):
-                gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
             if not getattr(gaussians, "moments_sharded", False):  # (sharded moments: the flush left every row current)
                 gaussians.catch_up_rows(f.to(torch.int32))
         if getattr(gaussians, "deferred_host_rows", False):  # host rows: apply what is waiting for them

@@ -100,6 +100,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                                  and dp.active() and getattr(a, "dp_locality", False)
                                  and getattr(a, "dp_shard_moments", True))
         self._mom_lo, self._mom_n = 0, n
+        # ... and the small attributes (xyz / opacity / scaling / rotation): their dense Adam runs on the owned row range
+        # only; a rank's copies of foreign rows go stale by a BOUNDED amount and are refreshed on demand (small_prepare)
+        self._small_owner = bool((not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True)
+                                 and dp.active() and getattr(a, "dp_locality", False)
+                                 and getattr(a, "dp_small_owner", True) and getattr(a, "fused_front_end", True)
+                                 and getattr(a, "packed_small", True))
+        self._small_since, self._small_drift = 0, [0.0, 0.0]  # batches since all copies were current; drift bounds
         m_cap, m_n = cap, n
         if self._mom_sharded:
             lo, hi = dp.owner_range(n)
@@ -192,6 +199,75 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                                   lambda self, v: (self.merge_stats(), setattr(self, "_xyz_gradient_accum", v))[0])
     denom = property(lambda self: self._stat_get("_denom"),
                      lambda self, v: (self.merge_stats(), setattr(self, "_denom", v))[0])
+
+    # ---------------------------------------------------- camera-DP: small attributes at their owners
+    @property
+    def small_owner(self):
+        """Camera-DP locality exchange, dp_small_owner (default): xyz / opacity / scaling / rotation of a row are
+        stepped by the rank that owns the row (the packed dense Adam on the owned range, 1/ranks of the rows), and
+        step F of the exchange (the owners' summed gradients all-gathered to every rank, 52 B x (ranks-1) per touched
+        row) is gone.  What replaces it:
+          * a rank's copies of foreign rows are STALE between refreshes, by at most Adam's step bound per batch
+            (small_after_step) -- enough to cull conservatively (clmgs_visibility_candidates);
+          * step S at the head of a batch (small_prepare): the candidates' current lines are fetched from their owners
+            (48 B per candidate row, point to point), after which the exact visibility pass selects exactly the rows it
+            selects on one rank and every row a camera renders from is current;
+          * every `dp_small_refresh` batches (and at every flush_lazy_rows()) the owned ranges are all-gathered, which
+            resets the drift bounds."""
+        return bool(getattr(self, "_small_owner", False))
+
+    def _small_params(self):
+        return [self._xyz.data, self._opacity.data, self._scaling.data, self._rotation.data]
+
+    def small_refresh(self, moments=False):
+        """All ranks' copies of the small attributes <- their owners' (a collective); moments too for flush_lazy_rows
+        (structural changes carry every row's moments along)."""
+        from ... import dp
+        n = self._xyz.shape[0]
+        tables = self._small_params()
+        if moments:
+            for p in self._small_tensors():
+                st = self.optimizer.gpu_adam.state.get(p, {})
+                if "exp_avg" in st:
+                    tables += [st["exp_avg"], st["exp_avg_sq"]]
+        dp.owner_gather_dense(tables, n)
+        self.invalidate_small_packed()  # the mirror is rebuilt from the tensors at its next use
+        self._small_since, self._small_drift = 0, [0.0, 0.0]
+
+    def small_prepare(self, cameras):
+        """Step S, before the batch's visibility pass (all ranks, every batch).  See small_owner."""
+        if self._small_since == 0:
+            return  # every copy is current (start, refresh, flush): nothing can be stale
+        from ... import dp
+        from ...gsplat import visibility_candidates
+        if self._small_since >= int(getattr(self.args, "dp_small_refresh", 8)):
+            self.small_refresh()
+            return
+        n = self._xyz.shape[0]
+        lo, hi = dp.owner_range(n)
+        Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in cameras])
+        viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in cameras])
+        d_xyz, d_ls = self._small_drift
+        import math
+        cand = visibility_candidates(self._xyz.data, self._scaling.data, viewmats, Ks, int(utils.get_img_width()),
+                                     int(utils.get_img_height()), pos_margin=math.sqrt(3.0) * d_xyz * 1.001 + 1e-12,
+                                     scale_gain=math.exp(d_ls) * 1.001, own_lo=lo, own_hi=hi)
+        pk = self.small_packed()
+        lines = dp.small_fetch(cand, n, pk)
+        dp.small_scatter(cand, lines, pk, self._small_params())
+
+    def small_after_step(self):
+        """After the owners' Adam step of a batch: how far a foreign copy may now be off.  |m_hat| / sqrt(v_hat) of
+        Adam is bounded by (1 - b1) / sqrt(1 - b2) / sqrt(1 - b1^2 / b2) (Cauchy-Schwarz on the two moment sums; the
+        bias-correction ratio sqrt(1 - b2^t) / (1 - b1^t) is <= 1), i.e. 7.28 for (0.9, 0.999): no element moves by
+        more than that times its learning rate in one step, whatever the gradients."""
+        import math
+        groups = {g["name"]: g for g in self.optimizer.gpu_adam.param_groups}
+        b1, b2 = groups["xyz"]["betas"]
+        c = (1.0 - b1) / math.sqrt(1.0 - b2) / math.sqrt(1.0 - b1 * b1 / b2) * 1.001
+        self._small_drift[0] += c * float(groups["xyz"]["lr"])
+        self._small_drift[1] += c * float(groups["scaling"]["lr"])
+        self._small_since += 1
 
     # ---------------------------------------------------- deferred dense Adam
     @property
@@ -290,6 +366,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             if not self.first_touch_grads:  # clearing policy: the owners' consumed (zeroed) rows replace the partial sums
                 tables.append(self.parameters_grad_buffer[:n])
             dp.owner_gather_dense(tables, n)
+            if self.small_owner:
+                self.small_refresh(moments=True)
             self._row_last_step[:n] = self.optimizer.cpu_adam.global_step
             self._row_g_step[:n] = 0
             return
@@ -596,5 +674,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         return utils.select_rows(p, mask)
 
     def reset_opacity(self):
+        if self.small_owner:
+            self.flush_lazy_rows()  # every copy current (and identical on all ranks) before all of them are rewritten
         new = utils.inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))
         self._replace_gpu("opacity", "_opacity", new, lambda s: torch.zeros_like(s))

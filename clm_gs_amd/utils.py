@@ -53,6 +53,8 @@ def default_args(**over):
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         dp_overlap=True,        # camera-DP locality exchange: split B / D so that they hide behind the first / last camera
         dp_shard_moments=True,  # camera-DP locality exchange (dense deferred row optimizer): m / v of the SH row table only for the owned row range
+        dp_small_owner=True,    # ... and xyz / opacity / scaling / rotation stepped by the owner of a row range only (no step F)
+        dp_small_refresh=8,     # ... batches between two all-gathers of the owned small-attribute ranges (bounds the staleness)
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)

@@ -405,6 +405,28 @@ int clmgs_host_groups(void* stream, int64_t n, const int64_t* touched, const voi
 int clmgs_publish_pack(void* stream, float* msg, const float* table, const int64_t* own_rows, const int32_t* stamp,
                        int step, int64_t lo, int64_t n_rows, int64_t chunk, int cols);
 
+/* Camera-DP, the small attributes (xyz / opacity / scaling / rotation) computed by the OWNER of a row range (net-new:
+ * the reference is single GPU; its SelectiveAdam, optimizer.py:6-88, is the sparse form on one device).  Between two
+ * refreshes a rank's copies of the rows it does not own are stale by a bounded amount; three entries:
+ *  - clmgs_visibility_candidates: mask[N] (u8) = 1 for every row OUTSIDE [own_lo, own_hi) that may pass the cull of
+ *    clmgs_visibility_select_count in any of the C cameras if its stored mean is off by up to pos_margin (Euclidean) and
+ *    its largest scale by a factor up to scale_gain -- a superset of the rows the exact cull keeps for the true values;
+ *    the caller fetches the candidates' current lines from their owners before the exact pass.
+ *  - clmgs_small_rows_scatter: packed [n_rows,12] lines (xyz 3 | opacity 1 | scaling 3 | rotation 4 | pad) written to
+ *    the four parameter tensors and the packed mirror at the unique row ids `rows`.
+ *  - clmgs_adam_small_packed_range: clmgs_adam_small_packed on the rows row_begin <= r < row_end only (row_end < 0:
+ *    all rows); every other row of every table is left bit for bit as it was. */
+int clmgs_visibility_candidates(void* stream, int C, int N, int own_lo, int own_hi, const float* means,
+                                const float* log_scales, const float* viewmats, const float* Ks, int width,
+                                int height, float eps2d, float near_plane, float far_plane, float pos_margin,
+                                float scale_gain, uint8_t* mask);
+int clmgs_small_rows_scatter(void* stream, int64_t n_rows, const int64_t* rows, const void* lines, float* xyz,
+                             float* opacity, float* scaling, float* rotation, void* packed_p);
+int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t row_begin, int64_t row_end, float* const* params,
+                                  float* const* exp_avg, float* const* exp_avg_sq, const double* lr4, void* packed_p,
+                                  void* packed_g, double beta1, double beta2, double eps, int step,
+                                  int bias_correction, float grad_scale, const int32_t* g_stamp, int cur_step);
+
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);
 

@@ -51,7 +51,8 @@ def _train(m, batches, args, world=1):
     m.flush_lazy_rows()
     torch.cuda.synchronize()
     # row moments: sharded by owner range under the locality exchange; row_moments_full() assembles them (collective)
-    _train.info = {"moments_sharded": bool(getattr(m, "moments_sharded", False)),
+    _train.info = {"small_owner": bool(getattr(m, "small_owner", False)),
+                   "moments_sharded": bool(getattr(m, "moments_sharded", False)),
                    "moment_rows_held": int(m._exp_avg_buffer.shape[0]), "n": int(m._parameters.shape[0])}
     _train.moments = [t.clone() for t in m.row_moments_full()]
     return [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
@@ -135,6 +136,9 @@ def main():
     sparse = mode_arg.endswith("_sparse")
     args = utils.default_args(bsz=BSZ, sh_residency="hbm", sparse_adam=sparse)
     args.clm_offload = True
+    for kv in filter(None, os.environ.get("CLMGS_DPW_OPTS", "").split(",")):  # e.g. "dp_small_owner=0,dp_small_refresh=2"
+        k, v = kv.split("=")
+        setattr(args, k, type(getattr(args, k))(int(v)))
     utils.set_args(args)
     utils.set_img_size(H, W)
     sc = synth_gaussians(N, seed=0, device="cuda")

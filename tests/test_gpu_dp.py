@@ -80,20 +80,29 @@ def test_trainer_owner_computes_densify_keeps_replicas_identical(dev):
     assert res["n_after"] != res["n_before"] and res["split"], res
 
 
-def test_locality_exchange_equals_single_rank_with_global_batch(dev):
+@pytest.mark.parametrize("opts", ["", "dp_small_refresh=2", "dp_small_owner=0"])
+def test_locality_exchange_equals_single_rank_with_global_batch(dev, opts):
     """dp_locality (dp.py "locality exchange"): Z-ordered rows, cameras dealt to the rank owning most of their
-    rows, only border rows travel (all_to_all: parameters out, gradient rows back), owners publish the summed
-    small-attribute gradients.  After flush_lazy_rows() the replicas are identical and equal the single-rank run
-    on the global batches (union of the ranks' batches)."""
+    rows, only border rows travel (all_to_all: parameters out, gradient rows back).  The small attributes are stepped
+    by the owner of a row range (default; foreign copies go stale inside Adam's step bound, the candidates of every
+    visibility pass are fetched from their owners -- also with the all-gather refresh every 2 batches), or,
+    dp_small_owner=0, the owners publish the summed small-attribute gradients to everybody (step F).  After
+    flush_lazy_rows() the replicas are identical and equal the single-rank run on the global batches (union of the
+    ranks' batches)."""
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                os.path.join(ROOT, "tests", "dp_worker.py"), "locality"])
+                os.path.join(ROOT, "tests", "dp_worker.py"), "locality"], env=dict(os.environ, CLMGS_DPW_OPTS=opts))
     line = [l for l in out.splitlines() if l.startswith("DPRESULT ")][-1]
     res = json.loads(line[len("DPRESULT "):])
     assert res["replicas_equal"] is True, res
     assert max(res["rel_l2_vs_single"]) < 2e-4, res
     assert res["local_share"] > 0.5, res                      # the deal keeps most touched rows at home
-    assert res["wire"]["all_to_all_grads"] > 0 and res["wire"]["all_gather_small"] > 0, res
+    assert res["wire"]["all_to_all_grads"] > 0, res
+    if opts == "dp_small_owner=0":
+        assert res["small_owner"] is False and res["wire"]["all_gather_small"] > 1000, res
+    else:
+        assert res["small_owner"] is True and res["wire"]["all_to_all_small"] > 0, res
+        assert res["wire"]["all_gather_small"] < 1000, res   # (the plan's row counts only: nothing is published)
     # row moments live at the owner of a row range only (VERDICT r3 item 7): half the table per rank at 2 ranks, and
     # the assembled tables equal the single-rank run's
     assert res["moments_sharded"] is True and res["moment_rows_held"] <= res["n"] // 2 + 2, res

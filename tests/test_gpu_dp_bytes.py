@@ -51,8 +51,8 @@ def test_exchange_bytes_of_virtual_ranks(dev, name, N, W, H, bsz, vis):
         local_share = sum(int(shares[c, q]) for c, q in enumerate(ranks_of)) / float(shares.sum())
         acc = {}
         for deal_name in ("strided", "locality_deal"):
-            tot = {"allreduce": 0.0, "owner": 0.0, "locality": 0.0, "union": 0.0, "ref240": 0.0, "border": 0.0,
-                   "touched": 0.0}
+            tot = {"allreduce": 0.0, "owner": 0.0, "locality": 0.0, "locality_small_owner": 0.0, "union": 0.0,
+                   "ref240": 0.0, "border": 0.0, "touched": 0.0}
             for s in range(steps):
                 T = []
                 for r in range(G):
@@ -64,7 +64,7 @@ def test_exchange_bytes_of_virtual_ranks(dev, name, N, W, H, bsz, vis):
                         _, tr = select_filters(batch, g._xyz, g._scaling, g._rotation)
                     T.append(tr.long())
                 b = dp.exchange_bytes(T, N)
-                for k in ("allreduce", "owner", "locality"):
+                for k in ("allreduce", "owner", "locality", "locality_small_owner"):
                     tot[k] += max(b[k]) / steps           # the slowest rank sets the pace
                 tot["union"] += b["union"] / steps
                 tot["ref240"] += b["reference_240B_x_union"] / steps
@@ -72,6 +72,8 @@ def test_exchange_bytes_of_virtual_ranks(dev, name, N, W, H, bsz, vis):
                 tot["touched"] += max(b["touched"]) / steps
                 del T
             acc[deal_name] = {k: round(v, 1) for k, v in tot.items()}
+        # round 4: the small attributes at their owners (no step F) never cost more than the published sums did
+        assert acc["locality_deal"]["locality_small_owner"] <= acc["locality_deal"]["locality"] * 1.02
         best = acc["locality_deal"]["locality"]
         report["ranks"][str(G)] = dict(
             acc, local_share_of_the_deal=round(local_share, 4),

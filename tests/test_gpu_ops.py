@@ -834,3 +834,117 @@ def test_host_groups_equals_index_arithmetic(dev, bsz):
         untouched = torch.ones(N, dtype=torch.bool, device=dev)
         untouched[want_late] = False
         assert bool((slot_of[untouched] == -5).all())
+
+
+@pytest.mark.gpu
+def test_visibility_candidates_cover_every_state_inside_the_drift_bounds(dev):
+    """Camera-DP, small attributes at their owners (clmgs_visibility_candidates): whatever the owner did to a row
+    inside the bounds (mean moved by <= pos_margin, scales multiplied by <= scale_gain or shrunk, ANY rotation), the
+    rows the exact cull keeps for the TRUE state are candidates of the STALE state.  Stress scene of the conservative
+    bound test (tilted / off-centre cameras, heavy-tailed scales, rows behind the camera / at the near plane, NaNs),
+    several margins; the candidate set is not the trivial one; own rows are never listed."""
+    from clm_gs_amd import gsplat as G
+    from clm_gs_amd.cameras import Camera
+    g = torch.Generator().manual_seed(21)
+    n, w, h = 60000, 200, 120
+    xyz = (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([60.0, 60.0, 60.0])
+    rot = torch.randn(n, 4, generator=g)
+    log_s = torch.randn(n, 3, generator=g) * 1.2 - 2.0
+    log_s[::97] += 3.0
+    log_s[7::1511, 1] = float("nan")
+    xyz[13::2003, 0] = float("nan")
+    cams = []
+    for i in range(6):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        w2c = torch.eye(4)
+        w2c[:3, :3] = q
+        w2c[:3, 3] = torch.randn(3, generator=g) * 8.0
+        cams.append(Camera(i, w2c, 0.9 + 0.1 * i, 0.6 + 0.05 * i, w, h, device="cuda"))
+    Ks = torch.stack([c.K for c in cams])
+    Ks[1, 0, 2] += 37.0
+    vms = torch.stack([c.world_view_transform.t() for c in cams])
+    xyz, rot, log_s = xyz.cuda(), rot.cuda(), log_s.cuda()
+    gc = torch.Generator(device="cuda").manual_seed(5)
+    sizes = []
+    for margin, gain in ((0.0, 1.0), (0.05, 1.1), (0.5, 1.5), (3.0, 4.0)):
+        # the TRUE state: the stale one moved to the edge of the bounds in random directions
+        d = torch.randn(n, 3, device="cuda", generator=gc)
+        d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-9) * margin * torch.rand(n, 1, device="cuda", generator=gc) ** 0.2
+        true_xyz = xyz + d
+        true_ls = log_s + (torch.rand(n, 3, device="cuda", generator=gc) * 2.0 - 1.0) * math.log(gain)
+        true_rot = torch.randn(n, 4, device="cuda", generator=gc)
+        _, union_true = G.visibility_select(true_xyz, true_rot, true_ls, vms, Ks, w, h)
+        _, union_stale = G.visibility_select(xyz, rot, log_s, vms, Ks, w, h)
+        cand = G.visibility_candidates(xyz, log_s, vms, Ks, w, h, pos_margin=margin, scale_gain=gain,
+                                       own_lo=0, own_hi=0)
+        assert cand.dtype == torch.int64 and bool((cand[1:] > cand[:-1]).all())
+        is_c = torch.zeros(n, dtype=torch.bool, device="cuda")
+        is_c[cand] = True
+        missed = union_true[~is_c[union_true]]
+        assert missed.numel() == 0, (margin, gain, missed[:10].tolist())
+        assert bool(is_c[union_stale].all())              # ... and of course what the stale state itself shows
+        sizes.append((cand.numel(), union_true.numel()))
+        # own rows are never candidates, the others are unaffected by the range
+        lo, hi = n // 3, 2 * n // 3
+        c2 = G.visibility_candidates(xyz, log_s, vms, Ks, w, h, pos_margin=margin, scale_gain=gain, own_lo=lo, own_hi=hi)
+        assert torch.equal(c2, cand[(cand < lo) | (cand >= hi)])
+    assert sizes[0][0] < 1.6 * sizes[0][1] and sizes[1][0] < 1.8 * sizes[1][1], sizes   # tight at small margins
+    assert sizes[-1][0] < n, sizes
+
+
+@pytest.mark.gpu
+def test_small_adam_on_a_row_range_and_small_rows_scatter(dev):
+    """clmgs_adam_small_packed_range steps rows [lo, hi) exactly as the full call does and leaves every other row of
+    every table bit for bit alone (ranges that are not multiples of the 256-row block, of 4, or of anything);
+    clmgs_small_rows_scatter writes packed lines to the four tensors + the mirror at the listed rows only."""
+    import ctypes
+    from clm_gs_amd import _lib, dp
+    n = 10007
+    g = torch.Generator(device="cuda").manual_seed(3)
+    widths = (3, 1, 3, 4)
+
+    def state():
+        gg = torch.Generator(device="cuda").manual_seed(9)
+        ps = [torch.randn(n, w, device="cuda", generator=gg) for w in widths]
+        ms = [torch.randn(n, w, device="cuda", generator=gg) * 0.1 for w in widths]
+        vs = [torch.rand(n, w, device="cuda", generator=gg) * 0.01 for w in widths]
+        pk = torch.empty(n, 12, device="cuda")
+        _lib.check(_lib.lib().clmgs_pack_small(_lib.stream(), n, *[_lib.dptr(x) for x in ps], _lib.dptr(pk)))
+        return ps, ms, vs, pk
+    grads = torch.randn(n, 12, device="cuda", generator=g)
+    stamp = torch.where(torch.rand(n, device="cuda", generator=g) < 0.5, 7, 3).to(torch.int32)
+    arr = lambda xs: (ctypes.c_void_p * 4)(*[x.data_ptr() for x in xs])
+    lrs = (ctypes.c_double * 4)(1e-2, 5e-2, 5e-3, 1e-3)
+
+    def run(st, lo, hi):
+        ps, ms, vs, pk = st
+        _lib.check(_lib.lib().clmgs_adam_small_packed_range(
+            _lib.stream(), n, lo, hi, arr(ps), arr(ms), arr(vs), lrs, _lib.dptr(pk), _lib.dptr(grads.clone()),
+            0.9, 0.999, 1e-15, 5, 1, 0.25, _lib.dptr(stamp), 7))
+    full = state()
+    run(full, 0, -1)
+    for lo, hi in ((0, n), (1, 2), (255, 257), (1001, 7777), (3334, 6669), (n - 1, n), (500, 500)):
+        part, ref = state(), state()
+        run(part, lo, hi)
+        for kind in range(3):
+            for t_part, t_full, t_ref in zip(part[kind], full[kind], ref[kind]):
+                assert torch.equal(t_part[lo:hi], t_full[lo:hi])
+                assert torch.equal(t_part[:lo], t_ref[:lo]) and torch.equal(t_part[hi:], t_ref[hi:])
+        assert torch.equal(part[3][lo:hi], full[3][lo:hi])
+        assert torch.equal(part[3][:lo], ref[3][:lo]) and torch.equal(part[3][hi:], ref[3][hi:])
+    # scatter
+    ps, _, _, pk = state()
+    before = [p.clone() for p in ps] + [pk.clone()]
+    rows = torch.randperm(n, device="cuda", generator=g)[:1234].sort().values
+    lines = torch.randn(rows.numel(), 12, device="cuda", generator=g)
+    dp.small_scatter(rows, lines, pk, ps)
+    want = lines.clone()
+    want[:, 11] = 0.0
+    assert torch.equal(pk[rows], want)
+    assert torch.equal(torch.cat([p[rows] for p in ps], dim=1), lines[:, :11])
+    rest = torch.ones(n, dtype=torch.bool, device="cuda")
+    rest[rows] = False
+    for a, b in zip(ps + [pk], before):
+        assert torch.equal(a[rest], b[rest])
