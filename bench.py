@@ -962,6 +962,8 @@ def main():
                                 if host_regions else {})},
         "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
         "dp": ({"mode": dp_mode, "deal": deal_info,
+                "small_attributes_at_owner": bool(getattr(gaussians, "small_owner", False)),
+                "row_moments_sharded": bool(getattr(gaussians, "moments_sharded", False)),
                 "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
                 "by_collective_per_step": {k: round(v / a.steps, 1) for k, v in wire.items() if k != "total"},
                 "note": "bytes rank 0 SENDS per batch (clm_gs_amd.dp.wire_bytes: ring model for all-reduce, exact sizes for "

@@ -28,6 +28,8 @@ import math
 import threading
 import time
 
+import os
+
 import torch
 
 from ... import _lib, clm_kernels, dp, fast_tsp, utils
@@ -248,6 +250,19 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         else:
             filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
                                               gaussians.get_scaling, gaussians.get_rotation)
+    if small_owner and os.environ.get("CLMGS_DP_DEBUG") and touched_rows is not None:
+        # debug: every foreign row the exact pass selected must have been a candidate of step S
+        lo_, hi_ = dp.owner_range(N)
+        foreign = touched_rows[(touched_rows < lo_) | (touched_rows >= hi_)]
+        cand_ = getattr(gaussians, "_dbg_cand", None)
+        miss = -1
+        if cand_ is not None and gaussians._small_since > 0:
+            isc = torch.zeros((N,), dtype=torch.bool, device=foreign.device)
+            isc[cand_] = True
+            miss = int((~isc[foreign]).sum())
+        print("DPDEBUG batch rank %d since %d foreign touched rows %d not candidates %d" % (
+            dp.rank(), gaussians._small_since, foreign.numel(), miss), flush=True)
+        assert miss <= 0
     sparsity = [len(f) / float(N) for f in filters]
     ordered_cams = list(range(bsz))
     if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)

@@ -12,6 +12,8 @@ The attribute surface (parameters_buffer, parameters_grad_buffer, _parameters, _
 _rest as split views, all_parameters() order, optimizer.gpu_adam/.cpu_adam/.columns_lr) is
 the reference's, so the engine and train loop read the same in both modes.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -255,6 +257,10 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         pk = self.small_packed()
         lines = dp.small_fetch(cand, n, pk)
         dp.small_scatter(cand, lines, pk, self._small_params())
+        if os.environ.get("CLMGS_DP_DEBUG"):
+            self._dbg_cand = cand
+            print("DPDEBUG small_prepare rank %d since %d drift %s candidates %d of %d foreign rows" % (
+                dp.rank(), self._small_since, self._small_drift, cand.numel(), n - (hi - lo)), flush=True)
 
     def small_after_step(self):
         """After the owners' Adam step of a batch: how far a foreign copy may now be off.  |m_hat| / sqrt(v_hat) of

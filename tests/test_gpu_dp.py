@@ -115,11 +115,13 @@ def test_locality_exchange_at_28m_two_ranks_share_the_gpu(dev, ranks):
     (and four) ranks of bsz 4 sharing the device (gloo; 2-4 x 37 GB of replicas), the locality exchange with the cameras
     dealt by row ownership and the exchange in parts behind the first / last camera: after two global batches and
     flush_lazy_rows() the replicas are bit-identical and equal the single-rank run on the global batches (bsz 8 / 16);
-    border rows and published sums really travelled."""
+    border rows and the candidates' small-attribute lines really travelled."""
     import torch
     if ranks * 40e9 + 45e9 > torch.cuda.get_device_properties(0).total_memory:
         pytest.skip("needs %d replicas of 37 GB + the single-rank run on one device" % ranks)
-    env = dict(os.environ, CLMGS_DPW_SIZE="4608,3456,28000000,4,2,0.10")
+    # CLMGS_DP_DEBUG: the engine asserts, batch by batch, that every foreign row the exact visibility pass selected
+    # was a candidate of step S (the drift-dilated cull is a superset at full size too)
+    env = dict(os.environ, CLMGS_DPW_SIZE="4608,3456,28000000,4,2,0.10", CLMGS_DP_DEBUG="1")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                 os.path.join(ROOT, "tests", "dp_worker.py"), "locality"], timeout=1500, env=env)
@@ -128,7 +130,11 @@ def test_locality_exchange_at_28m_two_ranks_share_the_gpu(dev, ranks):
     assert res["replicas_equal"] is True, res
     assert max(res["rel_l2_vs_single"]) < 2e-4, res
     assert res["wire"]["all_to_all_params"] > 1e8 and res["wire"]["all_to_all_grads"] > 1e8, res  # > 100 MB of border rows
-    assert res["wire"]["all_gather_small"] > 1e7, res
+    # the small attributes are stepped at their owners: the second batch fetched its candidates' current lines (step S)
+    # (rank 0 asked for, or served, more than a megabyte of them; which of the two depends on whose cameras look
+    # across the range border in the second batch)
+    assert res["small_owner"] is True, res
+    assert res["wire"]["all_to_all_small_ids"] + res["wire"]["all_to_all_small"] > 1e6, res
 
 
 def test_locality_exchange_sparse_adam_equals_single_rank(dev):
