@@ -12,10 +12,15 @@ Three exchanges (engine option in brackets), same result after flush_lazy_rows()
   owner-computes  [dp_owner_computes]  rows owned by index range; all-gather params / reduce-scatter grads
   locality        [dp_locality]        owner-computes + point-to-point: a rank fetches ONLY the rows its own
                                        cameras touch outside its range from their owners (all_to_all), sends
-                                       their gradients back, and the owners publish the summed small-attribute
-                                       gradients of their touched rows (all-gather).  With Z-ordered rows a
-                                       rank's range is a spatial region; assign_cameras() deals every camera to
-                                       the rank owning most of its rows, so most touched rows never travel.
+                                       their gradients back.  The small attributes are stepped by their
+                                       owner too [dp_small_owner, default]: foreign copies go stale inside
+                                       Adam's step bound, every batch starts by fetching the current lines of
+                                       the rows that may be visible (small_fetch, step S); or [dp_small_owner
+                                       off, round 3] the owners publish the summed small-attribute gradients of
+                                       their touched rows (all-gather, step F) and every rank steps every row.
+                                       With Z-ordered rows a rank's range is a spatial region; assign_cameras()
+                                       deals every camera to the rank owning most of its rows, so most touched
+                                       rows never travel.
 WIRE counts the bytes this rank SENDS per exchange (ring model for all-reduce), see wire_bytes().
 """
 import os
@@ -289,10 +294,16 @@ def owner_gather_dense(tables, n_total):
 #   D  border_grads_home  : the requester returns the gradient rows (SH row | packed small row, 240 B) of its
 #                           border rows; the owner adds them, requester by requester in rank order (deterministic),
 #                           storing instead of adding -- and stamping -- where the row had no gradient this step yet
-#   F  publish_small      : every owner all-gathers (row id, summed packed small gradient) of ITS rows touched
-#                           this step, so that the replicated small-attribute Adam (the next visibility pass
-#                           needs every row's position on every rank) sees the same global sum everywhere
-# Nothing else travels: a row deep inside a rank's region costs 52 B per peer (step F) instead of 240 B x 2 (G-1)/G.
+#   F  publish_small      : (dp_small_owner off) every owner all-gathers (row id, summed packed small gradient) of
+#                           ITS rows touched this step, so that the replicated small-attribute Adam (the next
+#                           visibility pass needs every row's position on every rank) sees the same global sum
+#                           everywhere: 52 B per peer for a row deep inside a rank's region
+#   S  small_fetch        : (dp_small_owner, default; at the HEAD of the batch, before the visibility pass) the
+#                           current packed small-attribute lines of the foreign rows that may be visible -- the
+#                           candidates of clmgs_visibility_candidates -- from their owners, who alone step them;
+#                           a row deep inside a rank's region then costs nothing but its share of the periodic
+#                           all-gather of the owned ranges (gaussian_model.small_refresh)
+# Nothing else travels.
 class BorderPlan:
     __slots__ = ("n_ranks", "rank", "lo", "hi", "n_total", "mine", "border", "need", "serve", "serve_rows",
                  "own_rows", "own_counts", "parts")
