@@ -55,6 +55,21 @@ def _train(m, batches, args, world=1):
                    "moments_sharded": bool(getattr(m, "moments_sharded", False)),
                    "moment_rows_held": int(m._exp_avg_buffer.shape[0]), "n": int(m._parameters.shape[0])}
     _train.moments = [t.clone() for t in m.row_moments_full()]
+    if world > 1 and getattr(args, "dp_locality", False) and not args.sparse_adam and N <= 100000:
+        # capture() / restore() with sharded row moments: capture assembles the full tables (a collective), restore
+        # keeps this rank's shard of them -- the restored model holds the same state
+        from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload
+        state = m.capture()
+        m2 = GaussianModelCLMOffload(3)
+        m2.restore(state, args)
+        same = all(torch.equal(a.detach(), b.detach()) for a, b in zip(m.all_parameters(), m2.all_parameters()))
+        same &= all(torch.equal(a, b) for a, b in zip(_train.moments, m2.row_moments_full()))
+        same &= m2.moments_sharded == m.moments_sharded and m2._mom_lo == m._mom_lo
+        for p_, q_ in zip(m._small_tensors(), m2._small_tensors()):
+            sa, sb = m.optimizer.gpu_adam.state[p_], m2.optimizer.gpu_adam.state[q_]
+            same &= bool(torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]))
+        _train.info["capture_restore_same"] = bool(same)
+        del m2, state
     return [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
             m._rotation.detach().clone(), m._parameters.detach().clone()]
 

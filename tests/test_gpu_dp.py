@@ -106,6 +106,7 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev, opts):
     # row moments live at the owner of a row range only: half the table per rank at 2 ranks, and
     # the assembled tables equal the single-rank run's
     assert res["moments_sharded"] is True and res["moment_rows_held"] <= res["n"] // 2 + 2, res
+    assert res["capture_restore_same"] is True, res           # capture (collective) -> restore keeps the sharded state
     assert max(res["moments_rel_l2_vs_single"]) < 1e-3, res
 
 
