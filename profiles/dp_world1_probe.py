@@ -48,5 +48,27 @@ pl = timed("A_border_plan", lambda: dp.border_plan(touched, N))
 timed("B_border_params_out", lambda: dp.border_params_out(params, pl))
 timed("D_border_grads_home", lambda: dp.border_grads_home([g_sh, g_small], stamp, step, pl))
 timed("F_publish_small", lambda: dp.publish_small(g_small, stamp, step, N, pl))
+# step S (round 4, dp_small_owner): the drift-dilated candidate pass over ALL rows of the bench scene for a batch of 4
+# cameras (own range empty = every row evaluated, the cost on a rank of a large world), the same with every row owned
+# (what a 1-rank group pays), the three all_to_alls of an empty request, and the unpack of a million fetched lines
+del params, g_sh
+from clm_gs_amd import gsplat as G
+from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+sc = synth_gaussians(N, seed=0, device="cuda")
+cams = nadir_cameras(4, N, 4608, 3456, 0.10, seed=0, device="cuda")
+Ks = torch.stack([c.K for c in cams])
+vms = torch.stack([c.world_view_transform.t() for c in cams])
+cand = timed("S_candidates_all_rows", lambda: G.visibility_candidates(sc["xyz"], sc["scaling"], vms, Ks, 4608, 3456,
+                                                                      pos_margin=0.02, scale_gain=1.3, own_lo=0, own_hi=0))
+res["S_candidates"] = int(cand.numel())
+timed("S_candidates_all_owned", lambda: G.visibility_candidates(sc["xyz"], sc["scaling"], vms, Ks, 4608, 3456,
+                                                                pos_margin=0.02, scale_gain=1.3, own_lo=0, own_hi=N))
+pk = torch.zeros((N, 12), device="cuda")
+none = torch.empty((0,), dtype=torch.int64, device="cuda")
+timed("S_small_fetch_empty", lambda: dp.small_fetch(none, N, pk))
+rows = cand[:1_000_000].contiguous()
+lines = torch.randn((rows.numel(), 12), device="cuda")
+tens = [sc["xyz"], sc["opacity"].reshape(N, 1).contiguous(), sc["scaling"], sc["rotation"]]
+timed("S_scatter_1M_lines", lambda: dp.small_scatter(rows, lines, pk, tens))
 print("DPPROBE " + json.dumps(res))
 dist.destroy_process_group()
