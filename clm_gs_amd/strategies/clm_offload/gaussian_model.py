@@ -242,7 +242,11 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             return  # every copy is current (start, refresh, flush): nothing can be stale
         from ... import dp
         from ...gsplat import visibility_candidates
-        if self._small_since >= int(getattr(self.args, "dp_small_refresh", 8)):
+        # refresh (the same decision on every rank: counters and learning rates are replicated) after dp_small_refresh
+        # batches, or earlier once the scale bound has grown past dp_small_max_log_gain -- large global batches scale
+        # the learning rates up, and a candidate set inflated by exp(1.6) costs more than the all-gather it avoids
+        if (self._small_since >= int(getattr(self.args, "dp_small_refresh", 8))
+                or self._small_drift[1] > float(getattr(self.args, "dp_small_max_log_gain", 0.7))):
             self.small_refresh()
             return
         n = self._xyz.shape[0]

@@ -55,6 +55,7 @@ def default_args(**over):
         dp_shard_moments=True,  # camera-DP locality exchange (dense deferred row optimizer): m / v of the SH row table only for the owned row range
         dp_small_owner=True,    # ... and xyz / opacity / scaling / rotation stepped by the owner of a row range only (no step F)
         dp_small_refresh=8,     # ... batches between two all-gathers of the owned small-attribute ranges (bounds the staleness)
+        dp_small_max_log_gain=0.7,  # ... or earlier, once the bound on the growth of a stale scale exceeds exp(this)
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
         raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
