@@ -329,7 +329,7 @@ def _isin_sorted(values, sorted_set):
     return sorted_set[pos] == values
 
 
-def border_plan(touched_rows, n_total, first_rows=None, last_rows=None):
+def border_plan(touched_rows, n_total, first_rows=None, last_rows=None, publish_counts=True):
     """touched_rows: ascending int64 ids this rank's cameras touch.  Two small collectives + the count all-gather; two
     host reads (the owner boundaries, before any collective; the split sizes).
 
@@ -341,7 +341,9 @@ def border_plan(touched_rows, n_total, first_rows=None, last_rows=None):
         second-to-last backward has run: they travel under the last camera's backward), `grads1` = the rest.
     Within every peer's segment the border list is ordered (first-camera rows, then the others), ascending inside each
     group; the in-last flag travels in bit 62 of the ids, so both sides derive the same D lists.  Without first_rows /
-    last_rows there is one part each (`params0` / `grads0` empty), the exchange is what it was."""
+    last_rows there is one part each (`params0` / `grads0` empty), the exchange is what it was.
+    publish_counts=False (dp_small_owner: nothing is published, step F does not run) skips the all-gather of the
+    own-row counts and its host read."""
     G, r = world_size(), rank()
     dev = touched_rows.device
     cuts = torch.tensor([(q * n_total) // G for q in range(G + 1)], dtype=torch.int64).to(dev)
@@ -430,11 +432,13 @@ def border_plan(touched_rows, n_total, first_rows=None, last_rows=None):
     # the rows of this rank's range anybody touches this batch, and how many every rank has: known NOW, so the
     # end-of-batch publication of the small-gradient sums (step F) needs no size readback of its own
     pl.own_rows = border_own_rows(pl)
-    k = torch.tensor([pl.own_rows.numel()], dtype=torch.int64, device=dev)
-    counts = torch.empty((G,), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, k)
-    pl.own_counts = counts.tolist()
-    _count("all_gather_small", 8 * (G - 1))
+    pl.own_counts = None
+    if publish_counts:
+        k = torch.tensor([pl.own_rows.numel()], dtype=torch.int64, device=dev)
+        counts = torch.empty((G,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, k)
+        pl.own_counts = counts.tolist()
+        _count("all_gather_small", 8 * (G - 1))
     return pl
 
 
@@ -755,7 +759,7 @@ def exchange_bytes(touched_per_rank, n_total, small_refresh=8):
         serve = sum(per[p][r] for p in range(G) if p != r)
         core = 8.0 * (3 * G + border) + 192.0 * serve + 240.0 * border + 8.0 * (G - 1)
         locality.append(core + (G - 1) * 52.0 * chunk)
-        locality_so.append(core + 8.0 * (G + border) + 48.0 * serve + (G - 1) * 44.0 * own_max / float(small_refresh))
+        locality_so.append(core - 8.0 * (G - 1) + 8.0 * (G + border) + 48.0 * serve + (G - 1) * 44.0 * own_max / float(small_refresh))
     return {"allreduce": allreduce, "owner": owner, "locality": locality, "locality_small_owner": locality_so,
             "union": U, "n_ranks": G,
             "touched": [int(t.numel()) for t in touched_per_rank],

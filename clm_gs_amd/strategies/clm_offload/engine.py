@@ -342,7 +342,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         dp_split = bool(pipelined and bsz >= 2 and getattr(args, "dp_overlap", True))
         with _lib.host_region("dp_border_plan"):
             border = dp.border_plan(touched_rows.long(), N, first_rows=filters[0] if dp_split else None,
-                                    last_rows=filters[bsz - 1] if dp_split else None)
+                                    last_rows=filters[bsz - 1] if dp_split else None,
+                                    publish_counts=not small_owner)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
         own_rows = border.own_rows
         if own_rows.numel():

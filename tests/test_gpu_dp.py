@@ -102,7 +102,7 @@ def test_locality_exchange_equals_single_rank_with_global_batch(dev, opts):
         assert res["small_owner"] is False and res["wire"]["all_gather_small"] > 1000, res
     else:
         assert res["small_owner"] is True and res["wire"]["all_to_all_small"] > 0, res
-        assert res["wire"]["all_gather_small"] < 1000, res   # (the plan's row counts only: nothing is published)
+        assert res["wire"].get("all_gather_small", 0) == 0, res   # nothing is published
     # row moments live at the owner of a row range only: half the table per rank at 2 ranks, and
     # the assembled tables equal the single-rank run's
     assert res["moments_sharded"] is True and res["moment_rows_held"] <= res["n"] // 2 + 2, res
