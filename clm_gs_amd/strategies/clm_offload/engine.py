@@ -25,10 +25,9 @@ processed, and `ordered_cams` / `sparsity` reported, in that order, as the refer
 """
 import ctypes
 import math
+import os
 import threading
 import time
-
-import os
 
 import torch
 
