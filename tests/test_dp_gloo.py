@@ -138,8 +138,19 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     T = torch.nonzero(pick).flatten()
     split = mode == "parts"
     first_rows, last_rows = (T[::3].clone(), T[1::2].clone()) if split else (None, None)
-    pl = dp.border_plan(T, N, first_rows=first_rows, last_rows=last_rows)
+    so = mode == "small_owner"   # round 4: nothing is published (step F off), the candidates' lines are fetched (step S)
+    pl = dp.border_plan(T, N, first_rows=first_rows, last_rows=last_rows, publish_counts=not so)
     fails = []
+    if so:
+        if pl.own_counts is not None:
+            fails.append(20)
+        # step S with the batch's border rows as the candidate list (ascending): the owners' current packed lines
+        packed = torch.full((N, 12), -7.0)
+        packed[lo:hi] = (torch.arange(lo, hi).float()[:, None] + torch.arange(12).float()[None, :] * 0.001)
+        cand = torch.sort(pl.border).values
+        lines = dp.small_fetch(cand, N, packed)
+        if not torch.equal(lines, cand.float()[:, None] + torch.arange(12).float()[None, :] * 0.001):
+            fails.append(21)
     if not (torch.equal(torch.sort(torch.cat((pl.mine, pl.border))).values, T)):
         fails.append(1)
     if not (bool(((pl.mine >= lo) & (pl.mine < hi)).all()) and bool(((pl.border < lo) | (pl.border >= hi)).all())):
@@ -197,7 +208,8 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     else:
         dp.border_grads_home([g_sh, g_small], stamp, step, pl)
     own_touched = dp.border_own_rows(pl)
-    dp.publish_small(g_small, stamp, step, N, pl)
+    if not so:
+        dp.publish_small(g_small, stamp, step, N, pl)
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(dense_sh=dense_sh, dense_small=dense_small, T=T))
     want_sh = sum(x["dense_sh"] for x in gathered)
@@ -215,16 +227,27 @@ def _locality_worker(rank, world, port, out, mode="mixed"):
     if mode != "undrawn" and not (bool((stamp[own_U] == step).all())):
         fails.append(8)
     rows_U = torch.nonzero(U).flatten()
-    if not (torch.allclose(eff(g_small, rows_U), want_small[rows_U], atol=1e-6)):  # everybody holds the summed small rows
-        fails.append(9)
-    if mode != "undrawn" and not (bool((stamp[rows_U] == step).all())):
-        fails.append(10)
+    if so:
+        # the OWNERS hold the summed small rows (step D brought the lines home); nobody else was told anything
+        if not (torch.allclose(eff(g_small, own_U), want_small[own_U], atol=1e-6)):
+            fails.append(22)
+    else:
+        if not (torch.allclose(eff(g_small, rows_U), want_small[rows_U], atol=1e-6)):  # everybody holds the summed small rows
+            fails.append(9)
+        if mode != "undrawn" and not (bool((stamp[rows_U] == step).all())):
+            fails.append(10)
     if not (bool((stamp[~U] == 3).all()) and bool((g_small[~U] == 9.0).all())):  # untouched rows: untouched
         fails.append(11)
     # wire accounting: the model of exchange_bytes == what the collectives counted
     acct = dp.exchange_bytes([x["T"] for x in gathered], N)
     w = dp.wire_bytes()
-    if not (abs(w["total"] - acct["locality"][rank]) < 1e-6 * max(1.0, w["total"])):
+    if so:
+        # the model's small-owner column minus its amortised refresh term (no refresh ran here)
+        own_max = max(dp.owner_range(N, q, world)[1] - dp.owner_range(N, q, world)[0] for q in range(world))
+        want_bytes = acct["locality_small_owner"][rank] - (world - 1) * 44.0 * own_max / 8.0
+        if not (abs(w["total"] - want_bytes) < 1e-6 * max(1.0, w["total"])):
+            fails.append(23)
+    elif not (abs(w["total"] - acct["locality"][rank]) < 1e-6 * max(1.0, w["total"])):
         fails.append(12)
     if not (acct["union"] == int(U.sum()) and acct["border"][rank] == int(pl.border.numel())):
         fails.append(13)
@@ -275,6 +298,14 @@ def test_dp_locality_exchange_in_parts_gloo():
     exchange leaves it (world 2 and 3, incl. the wire-byte account)."""
     _run_world(_locality_worker, 2, "parts")
     _run_world(_locality_worker, 3, "parts")
+
+
+def test_dp_locality_exchange_small_attributes_at_their_owners_gloo():
+    """Round 4 (dp_small_owner): the plan without the published counts, step S for the batch's border rows, B and D as
+    before, no step F -- the owners hold the summed small-gradient lines, and the wire-byte model's
+    `locality_small_owner` column equals what the collectives counted (world 2, 3, 4)."""
+    for world in (2, 3, 4):
+        _run_world(_locality_worker, world, "small_owner")
 
 
 def test_dp_locality_exchange_ignores_rows_the_backward_did_not_draw():
