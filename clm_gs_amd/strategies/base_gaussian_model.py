@@ -332,10 +332,17 @@ class BaseGaussianModel(ABC):
         self.max_radii2D = state["max_radii2D"].cuda()
 
     # -------------------------------------------------------------------- I/O
+    def _flush_before_read(self):
+        """Deferred optimizer steps applied and (camera-DP owner modes: a collective, already done by the caller on all
+        ranks, then a no-op here) the replicas completed BEFORE any parameter tensor is read out."""
+        if hasattr(self, "flush_lazy_rows"):
+            self.flush_lazy_rows()
+
     def save_tensors(self, folder):
         """Five-file .pt layout (clm_offload/gaussian_model.py:236-243)."""
         import os
         os.makedirs(folder, exist_ok=True)
+        self._flush_before_read()
         torch.save(self._xyz.detach().cpu(), os.path.join(folder, "xyz.pt"))
         torch.save(self._opacity.detach().cpu(), os.path.join(folder, "opacity.pt"))
         torch.save(self._scaling.detach().cpu(), os.path.join(folder, "scaling.pt"))
@@ -347,6 +354,7 @@ class BaseGaussianModel(ABC):
         import os
         from ..io_ply import save_ply
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self._flush_before_read()
         save_ply(path, self._xyz, self._shs48_rows(None), self._opacity, self._scaling, self._rotation)
 
     def save_sub_plys(self, path, n_split, split_size):
@@ -358,6 +366,7 @@ class BaseGaussianModel(ABC):
         assert path.endswith(".ply")
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         n = self._xyz.shape[0]
+        self._flush_before_read()
         shs = self._shs48_rows(None)
         written = []
         for i in range(n_split):
