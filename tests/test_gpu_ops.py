@@ -948,3 +948,52 @@ def test_small_adam_on_a_row_range_and_small_rows_scatter(dev):
     rest[rows] = False
     for a, b in zip(ps + [pk], before):
         assert torch.equal(a[rest], b[rest])
+
+
+def test_visibility_candidates_kernel_brackets_its_numpy_restatement(dev):
+    """The kernel's candidate set pinned from both sides by the float64 restatement of tests/test_dp_drift_bounds.py:
+    it contains the restatement evaluated WITHOUT the kernel's rounding slack (1 px + 0.1 % on the radius), and is
+    contained in the restatement with TWICE that slack -- the kernel computes the documented test, nothing looser."""
+    import numpy as np
+    from clm_gs_amd import gsplat as G
+    from clm_gs_amd.cameras import Camera
+    from tests import test_dp_drift_bounds as T
+    g = torch.Generator().manual_seed(31)
+    n, w, h = 50000, 320, 200
+    xyz = (torch.rand(n, 3, generator=g) - 0.5) * 60.0
+    log_s = torch.randn(n, 3, generator=g) * 1.2 - 2.0
+    for i, (d, gain) in enumerate(((0.0, 1.0), (0.3, 1.5), (2.0, 3.0))):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        w2c = torch.eye(4)
+        w2c[:3, :3] = q
+        w2c[:3, 3] = torch.randn(3, generator=g) * 6.0
+        cam = Camera(i, w2c, 0.9, 0.7, w, h, device="cuda")
+        K = cam.K.cpu().double().numpy()
+        cand = G.visibility_candidates(xyz.cuda(), log_s.cuda(), cam.world_view_transform.t()[None].contiguous(),
+                                       cam.K[None].contiguous(), w, h, pos_margin=d, scale_gain=gain, own_lo=0, own_hi=0)
+        got = np.zeros(n, dtype=bool)
+        got[cand.cpu().numpy()] = True
+        cam_np = (q.double().numpy(), w2c[:3, 3].double().numpy(), K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        smax = np.exp(log_s.double().numpy().max(axis=1))
+
+        def restated(slack_px, slack_rel):
+            R, t, fx, fy, cx, cy = cam_np
+            x, y, z = (xyz.double().numpy() @ R.T + t).T
+            zl, zh = z - d, z + d
+            alive = ~((zh < 0.01) | (zl > 1e10))
+            zc = np.maximum(np.maximum(zl, 0.01), 1e-12)
+            zf = np.maximum(np.minimum(zh, 1e10), zc)
+            xh, xl, yh, yl = x + d, x - d, y + d, y - d
+            tx_max, tx_min = np.where(xh > 0, xh / zc, xh / zf), np.where(xl < 0, xl / zc, xl / zf)
+            ty_max, ty_min = np.where(yh > 0, yh / zc, yh / zf), np.where(yl < 0, yl / zc, yl / zf)
+            B = (smax * gain) ** 2 / (zc * zc) * T._kc(fx, fy, cx, cy, w, h) + 0.3
+            Rb = (1.0 + slack_rel) * (3.03 * np.sqrt(2 * B + 0.1) + 2.0) + slack_px
+            out = ((fx * tx_max + cx + Rb <= 0) | (fx * tx_min + cx - Rb >= w)
+                   | (fy * ty_max + cy + Rb <= 0) | (fy * ty_min + cy - Rb >= h))
+            return alive & ~out
+        inner, outer = restated(0.0, 0.0), restated(2.0, 0.0022)
+        assert not np.any(inner & ~got), (d, gain, int(np.sum(inner & ~got)))
+        assert not np.any(got & ~outer), (d, gain, int(np.sum(got & ~outer)))
+        assert 0 < inner.sum() < n
