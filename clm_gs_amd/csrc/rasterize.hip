@@ -175,11 +175,18 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const float4* rec = packed + REC_F4 * (size_t)cur_g;
     nA = rec[0]; nB = rec[1]; nblue = rec[2].x;
   }
+  // Per-quadrant termination (gsplat's per-pixel `done`, at the granularity this kernel branches on): bit k of
+  // `alive` = some pixel of quadrant k still accumulates.  A quadrant whose 64 pixels have all terminated (or lie
+  // outside the image) takes no further pass -- a pass over it changes nothing (`valid` needs T > 0) -- and an entry
+  // that only reaches dead quadrants is not even staged.  Wave-uniform (SGPR), refreshed by the passes themselves.
+  int alive = 0;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) alive |= __any(T[k] > 0.f) ? (1 << k) : 0;
   for (int bs = rs; bs < re; bs += 64) {
-    if (!__any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) break;
+    if (!alive) break;
     const float4 A = nA, B = nB;
     const float blue = nblue;
-    const int mask = (cur_g >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
+    const int mask = (cur_g >= 0) ? (quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) & alive) : 0;
     cur_g = nxt_g;
     if (cur_g >= 0) {  // records of the next round (their ids arrived a round ago)
       const float4* rec = packed + REC_F4 * (size_t)cur_g;
@@ -209,7 +216,7 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       asm("v_mov_b32 %0, %1" : "=v"(gi_v) : "s"(gi));  // next to its mask; the compiler re-moved it per pass)
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        if (meta & (1 << k)) {  // wave-uniform: this quadrant can be touched
+        if (meta & alive & (1 << k)) {  // wave-uniform: this quadrant can be touched and still accumulates
           const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
           const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
           const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
@@ -223,9 +230,12 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           cr[k] += RB.z * vis; cg[k] += RB.w * vis; cb[k] += rblue * vis;
           last[k] = acc ? gi_v : last[k];
           T[k] = acc ? next_T : (term ? -T[k] : T[k]);
+          // only a pass in which some pixel terminated can empty its quadrant: one ballot of `term` per pass
+          // (it replaces the per-entry whole-tile test: three v_max + a compare over all four T)
+          if (__any(term) && !__any(T[k] > 0.f)) alive &= ~(1 << k);
         }
       }
-      if (!__any(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) break;
+      if (!alive) break;
     }
   }
 
@@ -303,6 +313,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   float T[PPL], Bk[PPL], vr[PPL], vg[PPL], vb[PPL];
   int bin[PPL];
   int max_bin = -1;
+  int qmax[PPL];  // per quadrant: the deepest contributor of its 64 pixels (wave-uniform)
   float bgr = 0.f, bgg = 0.f, bgb = 0.f;
   if (backgrounds) { bgr = backgrounds[3 * cam]; bgg = backgrounds[3 * cam + 1]; bgb = backgrounds[3 * cam + 2]; }
   const float px0 = tile_x0 + (float)qx + 0.5f, py0 = tile_y0 + (float)qy + 0.5f;
@@ -325,7 +336,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       T[k] = 1.f; bin[k] = -1; vr[k] = vg[k] = vb[k] = Bk[k] = 0.f;
     }
   }
-  max_bin = wave_max_i32(max_bin);
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) qmax[k] = __builtin_amdgcn_readfirstlane(wave_max_i32(bin[k]));
+  max_bin = max(max(qmax[0], qmax[1]), max(qmax[2], qmax[3]));
   const int hi = min(re - 1, max_bin);  // nothing behind the deepest contributor matters
   unsigned long long c_stage = 0, c_loop = 0, c_flush = 0, n_ent = 0, n_valid = 0, n_quad = 0, n_round = 0;
   const unsigned long long t_begin = DBG_CLK();
@@ -358,7 +371,13 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     const float blue = nblue;
     const int gid = cur_g;
     const int pid = cur_p;
-    const int mask = (gid >= 0) ? quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) : 0;
+    // Per-quadrant termination: entry gi matters to quadrant k only while gi <= qmax[k] (`valid` needs
+    // gi <= bin of the pixel); the staging lane drops the other quadrants from its mask, and an entry left
+    // without a quadrant is not staged at all (its partial line is the zero line below).  Results unchanged.
+    const int gidx = bh - lane;
+    const int reach = (gidx <= qmax[0] ? 1 : 0) | (gidx <= qmax[1] ? 2 : 0) | (gidx <= qmax[2] ? 4 : 0) |
+                      (gidx <= qmax[3] ? 8 : 0);
+    const int mask = (gid >= 0) ? (quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, tile_x0, tile_y0) & reach) : 0;
     cur_g = nxt_g;
     cur_p = nxt_p;
     if (cur_g >= 0) {

@@ -274,7 +274,7 @@ def compare(hip, orc):
 
 # Tolerances (fp32 on both sides, different operation orders).  Step functions of fp32 values cannot be
 # bit-compared across two implementations at millions of samples; every exception is counted and explained.
-TOL = dict(psnr_db=60.0, loss_abs=1e-5, same_cotangent_rel_l2=1e-3, natural_rel_l2=2e-2,
+TOL = dict(psnr_db=60.0, loss_abs=1e-5, same_cotangent_rel_l2=1e-3, natural_rel_l2=5e-3,
            cotangent_rel_l2_without_flips=1e-3, tie_fraction=1e-5)
 
 

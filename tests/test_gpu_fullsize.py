@@ -41,7 +41,10 @@ class _Scene:
 
 
 _REPORT = {}
-_TOL = dict(loss_abs=1e-5, grad_rel_l2=2e-2)  # whole-batch test below; per-camera rules: camera_parity.TOL
+# whole-batch test below (per-camera rules: camera_parity.TOL).  grad_rel_l2: each side backpropagates its OWN loss
+# cotangent (measured 3.3e-4 .. 7.3e-4, bounded by the counted sign(image - gt) ties of the L1 term);
+# same_cotangent_rel_l2: the oracle backward re-run on the cotangent the HIP backward consumed -- the gate proper.
+_TOL = dict(loss_abs=1e-5, grad_rel_l2=3e-3, same_cotangent_rel_l2=1e-3)
 
 
 def _save_report():
@@ -340,14 +343,24 @@ def test_config3_rubble10m_host_resident_batch_vs_oracle(dev):
     pos[tr] = torch.arange(T, device="cuda")
     acc = {k: np.zeros((T, c), np.float64) for k, c in (("g_xyz", 3), ("g_opacity", 1), ("g_scaling", 3),
                                                         ("g_rotation", 4), ("g_shs", 48))}
+    acc_same = {k: np.zeros_like(v) for k, v in acc.items()}
     o_losses, secs = [], 0.0
+    from clm_gs_amd import fused
     for cam, f in zip(cams, filters):
-        orc, dt = CP.oracle_camera(CP.oracle_inputs(m, cam, f), W, H, 3)
+        # the loss cotangent the batch's backward of this camera consumes: the fused forward is bitwise reproducible
+        # and the model does not move (debug_skip_optimizer), so a forward of the same rows yields exactly it
+        sh = CP._sh_rows_of(m, f)
+        p_ = fused.camera_forward(m, cam, f, sh, 0, None, cam.original_image)
+        fused.camera_verify(m, p_)
+        v_hip = p_.v_out.permute(2, 0, 1).contiguous().cpu().numpy()
+        del p_, sh
+        orc, dt = CP.oracle_camera(CP.oracle_inputs(m, cam, f), W, H, 3, v_image_hip=v_hip)
         secs += dt
         o_losses.append(orc["loss"])
         at = pos[f].cpu().numpy()
         for k in acc:
             acc[k][at] += np.asarray(orc[k], np.float64).reshape(len(at), -1)
+            acc_same[k][at] += np.asarray(orc["same_cotangent"][k], np.float64).reshape(len(at), -1)
     losses, order, _ = _clm_batch(m, cams, args)
     trc = tr.cpu()
     hip = dict(g_shs=m.parameters_grad_buffer[:N][trc].numpy(), g_xyz=m._xyz.grad[tr].cpu().numpy(),
@@ -359,10 +372,13 @@ def test_config3_rubble10m_host_resident_batch_vs_oracle(dev):
         assert rep[f"loss{i}_abs"] <= _TOL["loss_abs"], rep
     for k in acc:
         rep[k + "_rel_l2"] = float(np.linalg.norm(hip[k].astype(np.float64) - acc[k]) / np.linalg.norm(acc[k]))
+        rep["same_cotangent_" + k + "_rel_l2"] = float(np.linalg.norm(hip[k].astype(np.float64) - acc_same[k])
+                                                       / np.linalg.norm(acc_same[k]))
     _REPORT["config3.rubble10m.clm_offload.host_resident.batch"] = rep
     _save_report()
     for k in acc:
         assert rep[k + "_rel_l2"] <= _TOL["grad_rel_l2"], (k, rep)
+        assert rep["same_cotangent_" + k + "_rel_l2"] <= _TOL["same_cotangent_rel_l2"], (k, rep)
     # rows outside the union carry nothing
     untouched = torch.ones(N, dtype=torch.bool)
     untouched[trc] = False
