@@ -169,6 +169,18 @@ def parse():
                          "end-to-end clock) -> trainer_img_s / trainer_peak_gpu_bytes")
     ap.add_argument("--trainer-images", type=int, default=400)
     ap.add_argument("--trainer-grad-threshold", type=float, default=0.0002)
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="--gpus > 1: skip the camera-DP pre-flight (clm_gs_amd/dp_preflight.py: the exchange's collectives, the "
+                         "exchange itself on a seeded table and two tiny locality batches, run by one child process per rank on "
+                         "the real backend; a failure or a timeout makes the run fall back to --dp-mode allreduce)")
+    ap.add_argument("--preflight-timeout", type=float, default=float(os.environ.get("CLMGS_PREFLIGHT_TIMEOUT", "150")))
+    ap.add_argument("--no-allreduce-leg", action="store_true",
+                    help="--gpus > 1 with the locality / owner exchange: skip the second, short leg that runs the plain "
+                         "all-reduce camera-DP (north_star's design) on a fresh model -> dp.allreduce_leg")
+    ap.add_argument("--allreduce-steps", type=int, default=6)
+    ap.add_argument("--no-heavy-leg", action="store_true",
+                    help="skip the extra short single-GPU leg on the heavy-tailed scene (--scene heavy, I/V ~ 11) -> value_heavy")
+    ap.add_argument("--heavy-steps", type=int, default=8)
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -562,6 +574,59 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
     return out
 
 
+def run_preflight(world, rank, device, backend, timeout_s):
+    """Camera-DP pre-flight on the real backend (clm_gs_amd/dp_preflight.py): every rank runs ONE child process; the
+    children form their own group and exercise the exchange.  -> (summary dict, ok on ALL ranks).  The verdict is agreed
+    through the run's own group with object collectives (all_gather_object), the most basic thing it must be able to do."""
+    import shutil
+    import tempfile
+
+    import torch.distributed as dist
+    from clm_gs_amd import dp_preflight
+    box = [tempfile.mkdtemp(prefix="clmgs_preflight_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    rep_ = dp_preflight.run(rank, world, backend, device, box[0], timeout_s)
+    reps = [None] * world
+    dist.all_gather_object(reps, rep_)
+    if rank == 0:
+        shutil.rmtree(box[0], ignore_errors=True)
+    ok = all(bool(r and r.get("ok")) for r in reps)
+    errors = {str(r["rank"]): r.get("error") for r in reps if r and not r.get("ok")}
+    return {"ok": ok, "wall_s_max": max(r.get("wall_s", 0.0) for r in reps),
+            "stages_s_rank0": reps[0].get("stages_s"), "errors": errors or None,
+            "what": "one child process per rank, own process group on the run's backend: raw collectives (uneven / empty "
+                    "all_to_all splits, reduce_scatter, all_gather), dp.border_plan + B + D in parts on a seeded table, two "
+                    "tiny locality batches + flush with the replicas' checksums compared"}, ok
+
+
+def heavy_leg(a):
+    """`value_heavy`: the same workload on the heavy-tailed scene (--scene heavy: I/V ~ 11, long per-tile lists -- what
+    opaque trained scenes add), as a short run of this script in a child process (fresh allocator, nothing resident
+    from the other legs).  The headline `value` / `config.scene` stay the slab scene of SURVEY 8d."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--scene", "heavy", "--config", a.config, "--steps", str(a.heavy_steps),
+           "--warmup", "2", "--no-cpu-baseline", "--no-host-leg", "--no-trainer-leg", "--no-heavy-leg", "--gt", "resident",
+           "--prime-seconds", "3", "--camera-order", a.camera_order, "--row-order", a.row_order]
+    for kv in a.opt:
+        cmd += ["--opt", kv]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    if pr.returncode != 0 or len(lines) != 1:
+        return {"value": None, "error": f"rc {pr.returncode}: {pr.stderr[-300:]}"}
+    j = json.loads(lines[0])
+    solo = j.get("kernels_solo_ms") or {}
+    return {"value": j["value"], "unit": "img/s", "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+            "scene": "heavy", "I_over_V": j["measured"]["I_over_V"], "I_avg": j["measured"]["I_avg"],
+            "I_emitted_avg": j["measured"]["I_emitted_avg"], "peak_gpu_bytes": j["peak_gpu_bytes"],
+            "loss_first_last": [j["measured"]["loss_first"], j["measured"]["loss_last"]],
+            "roofline_frac": (j.get("roofline") or {}).get("frac"), "roofline_frac_solo": (j.get("roofline") or {}).get("frac_solo"),
+            "tile_kernels_solo_ms": {k: solo.get(k) for k in ("clmgs_rasterize_fwd", "clmgs_rasterize_bwd")},
+            "binning_solo_ms": {k: solo.get(k) for k in ("clmgs_isect2_order_count", "clmgs_isect2_emit_sort")},
+            "wall_s": round(time.perf_counter() - t0, 1)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -608,6 +673,17 @@ def main():
     if dp_mode == "auto":
         dp_mode = "locality" if (world > 1 and a.strategy == "clm_offload" and a.residency == "hbm"
                                  and a.row_order == "morton") else "allreduce"
+    preflight = dp_fallback = None
+    if world > 1 and dp_mode in ("locality", "owner") and not a.no_preflight:
+        # the first contact with the real backend must not be able to lose the run: see clm_gs_amd/dp_preflight.py
+        preflight, pf_ok = run_preflight(world, rank, local_rank, os.environ.get("CLMGS_DIST_BACKEND", "nccl"),
+                                         a.preflight_timeout)
+        if not pf_ok:
+            dp_fallback = {"from": dp_mode, "to": "allreduce", "reason": preflight["errors"]}
+            if rank == 0:
+                sys.stderr.write(f"bench: camera-DP pre-flight FAILED ({preflight['errors']}): falling back from "
+                                 f"--dp-mode {dp_mode} to the plain all-reduce exchange\n")
+            dp_mode = "allreduce"
     if world > 1 or under_torchrun:
         args.dp_locality = dp_mode == "locality"
         args.dp_owner_computes = dp_mode == "owner"
@@ -785,8 +861,23 @@ def main():
         dt = float(t.item())
     peak_timed = torch.cuda.max_memory_allocated()
     wire = _dpm.wire_bytes()
+    completing_flush_ms = None
     if owner_dp:
+        tf0 = time.perf_counter()
         gaussians.flush_lazy_rows()  # replicas complete again (collective), outside the timed region
+        torch.cuda.synchronize()
+        completing_flush_ms = (time.perf_counter() - tf0) * 1e3
+
+    def replicas_equal():
+        """Checksums (float64 sums of every parameter tensor) of the completed replicas, compared over the ranks."""
+        if not grouped:
+            return None
+        with torch.no_grad():
+            sums = torch.stack([t.detach().double().sum() for t in gaussians.all_parameters()])
+        allsums = [torch.empty_like(sums) for _ in range(world)]
+        torch.distributed.all_gather(allsums, sums)
+        return bool(all(torch.equal(x, allsums[0]) for x in allsums))
+    rep_equal = replicas_equal() if (world > 1 and a.strategy == "clm_offload") else None
     n_loss_timed = len(all_losses)
     # ---- the same K steps once more with the ground-truth images where the reference keeps them (pinned host
     # memory, train.py:310-312), every batch's images uploaded on a side stream one batch ahead: reported beside
@@ -815,14 +906,19 @@ def main():
     # C-ABI call on the stream it is launched on: the per-kernel table and the roofline entry.  Its
     # throughput is reported as value_instrumented; `value` above never carries the instrumentation.
     dt_instr = None
+    dp_phase_ms = None
     if not a.no_kernel_timing:
         _lib.TIMING = {}
+        if grouped:
+            _dpm.PHASES = {}
         fence()
         ti = time.perf_counter()
         for b in range(a.warmup, a.warmup + a.steps):
             step(b)
         fence()
         dt_instr = time.perf_counter() - ti
+        if grouped:
+            dp_phase_ms, _dpm.PHASES = _dpm.phase_summary(a.steps), None
     peak = peak_timed
     def _merge_dev(tm):  # the device-count forms (clmgs_*_dev) are the same kernels as their exact forms
         out_ = {}
@@ -865,6 +961,56 @@ def main():
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
 
     dist_backend = torch.distributed.get_backend() if grouped else None
+    # ---- camera-DP: a second, short leg with the PLAIN all-reduce exchange (north_star's design: every rank steps every
+    # row, one all-reduce of the touched rows' gradient lines per batch) on a fresh model, so that the scaling record
+    # carries the simple design beside the locality one
+    allreduce_leg = None
+    if world > 1 and dp_mode != "allreduce" and a.strategy == "clm_offload" and not a.no_allreduce_leg:
+        try:
+            gaussians = None
+            gc.unfreeze()
+            gc.collect()
+            torch.cuda.empty_cache()
+            args2 = utils.default_args(**{**vars(args), "dp_locality": False, "dp_owner_computes": False})
+            utils.set_args(args2)
+            sc2 = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
+            if a.row_order == "morton":
+                o2 = utils.morton_order(sc2["xyz"])
+                for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+                    sc2[k] = utils.gather_rows(sc2[k], o2)
+                del o2
+            gaussians = GaussianModelCLMOffload(3)
+            gaussians.create_from_tensors(sc2["xyz"], sc2["shs48"], sc2["scaling"], sc2["rotation"], sc2["opacity"],
+                                          spatial_lr_scale=lr_extent)
+            del sc2
+            gaussians.active_sh_degree = 3
+            gaussians.training_setup(args2)
+            state["iteration"] = 1
+            n_ar = max(1, min(a.allreduce_steps, a.steps))
+            for b in range(min(2, a.warmup)):
+                step(b)
+            fence()
+            _dpm.reset_wire()
+            ta0 = time.perf_counter()
+            for b in range(a.warmup, a.warmup + n_ar):
+                step(b)
+            gaussians.flush_lazy_rows()
+            fence()
+            dt_ar = time.perf_counter() - ta0
+            t = torch.tensor([dt_ar], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_ar = float(t.item())
+            w_ar = _dpm.wire_bytes()
+            allreduce_leg = {"mode": "allreduce", "value": round(n_ar * bsz * world / dt_ar, 4), "unit": "img/s",
+                             "ms_per_step": round(dt_ar / n_ar * 1e3, 3), "steps": n_ar, "warmup": min(2, a.warmup),
+                             "dp_exchange_bytes_per_step": round(w_ar.get("total", 0) / n_ar, 1),
+                             "replicas_equal": replicas_equal(),
+                             "what": "fresh model, dp_locality / dp_owner_computes off: OR of the touched-row masks, ONE "
+                                     "all-reduce of (packed small gradient | SH gradient row) of the globally touched rows per "
+                                     "batch, every rank steps every row (dp.py all-reduce exchange)"}
+            utils.set_args(args)
+        except Exception as e:  # reported, never fatal for the headline
+            allreduce_leg = {"value": None, "error": f"{type(e).__name__}: {e}"}
     if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -961,7 +1107,17 @@ def main():
                              **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
                                 if host_regions else {})},
         "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
-        "dp": ({"mode": dp_mode, "deal": deal_info,
+        "dp": ({"mode": dp_mode, "fallback": dp_fallback, "preflight": preflight, "deal": deal_info,
+                "replicas_equal": rep_equal,
+                "completing_flush_ms": round(completing_flush_ms, 2) if completing_flush_ms is not None else None,
+                "phase_ms": dp_phase_ms,
+                "phase_ms_note": "per step, from the instrumented pass (value_instrumented): device_ms = event pairs on the "
+                                 "stream each phase is enqueued on (B0 / B1 / D0 on the exchange's side stream, i.e. under "
+                                 "rendering), host_ms = wall time of the enqueueing block incl. its host reads; plan = "
+                                 "dp.border_plan, S = small_prepare (candidates + fetch), catch_up_own = deferred row steps of "
+                                 "the rows anybody renders, B = parameter rows out, D = gradient lines home, D_apply = "
+                                 "owner-side accumulation, tail_exchange = everything the exchange adds after the last backward",
+                "allreduce_leg": allreduce_leg,
                 "small_attributes_at_owner": bool(getattr(gaussians, "small_owner", False)),
                 "row_moments_sharded": bool(getattr(gaussians, "moments_sharded", False)),
                 "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
@@ -1035,6 +1191,16 @@ def main():
                 out["trainer_vs_value"] = round(out["trainer_img_s"] / value, 4)
         except Exception as e:  # reported, never fatal for the headline
             out["trainer"] = {"trainer_img_s": None, "error": f"{type(e).__name__}: {e}"}
+    if (not a.no_heavy_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+            and a.scene == "slab" and a.config in ("rubble28m", "rubble10m", "small")):
+        try:
+            gaussians = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["heavy"] = heavy_leg(a)
+            out["value_heavy"] = out["heavy"].get("value")
+        except Exception as e:  # reported, never fatal for the headline
+            out["heavy"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
     sys.stdout.flush()
     if not train_ok:

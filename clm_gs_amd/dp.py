@@ -24,6 +24,7 @@ Three exchanges (engine option in brackets), same result after flush_lazy_rows()
 WIRE counts the bytes this rank SENDS per exchange (ring model for all-reduce), see wire_bytes().
 """
 import os
+import time as _time
 
 import torch
 import torch.distributed as dist
@@ -65,6 +66,47 @@ def _put(table, idx, src):
 
 
 WIRE = {}  # exchange kind -> bytes this rank has sent since reset_wire()
+
+# Per-phase timing of the exchange (bench.py `dp.phase_ms`): PHASES = {} switches it on.  Every phase() block records an
+# event pair on the stream it is ENQUEUED on (a collective of the nccl backend runs on the backend's own stream, which
+# waits for the current stream and is waited for by it: the pair brackets it) and the host wall time of the block (the
+# host reads of the plan, the host-blocking collectives of gloo).  Off (None): no event, no clock -- the product path.
+PHASES = None
+
+
+class phase:
+    __slots__ = ("name", "t0", "e0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PHASES is not None:
+            self.t0 = _time.perf_counter()
+            self.e0 = None
+            if torch.cuda.is_available():
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if PHASES is not None:
+            e1 = None
+            if self.e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(torch.cuda.current_stream())
+            PHASES.setdefault(self.name, []).append((_time.perf_counter() - self.t0, self.e0, e1))
+        return False
+
+
+def phase_summary(n_steps):
+    """-> {phase: {"device_ms": per step, "host_ms": per step, "calls": n}}; call after a device synchronisation."""
+    out = {}
+    for name, recs in (PHASES or {}).items():
+        dev = sum(e0.elapsed_time(e1) for _, e0, e1 in recs if e0 is not None)
+        out[name] = {"device_ms": round(dev / max(1, n_steps), 3),
+                     "host_ms": round(sum(r[0] for r in recs) * 1e3 / max(1, n_steps), 3), "calls": len(recs)}
+    return out
 
 
 def _count(kind, nbytes):

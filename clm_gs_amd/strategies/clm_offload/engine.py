@@ -237,7 +237,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
     small_owner = bool(getattr(gaussians, "small_owner", False) and gaussians.lazy_rows and dp.active()
                        and not args.stop_update_param)
     if small_owner:
-        with torch.no_grad(), _lib.host_region("dp_small_fetch"):
+        with torch.no_grad(), _lib.host_region("dp_small_fetch"), dp.phase("S"):
             gaussians.small_prepare(batched_cameras)
     with torch.no_grad():
         if getattr(args, "fused_front_end", True):
@@ -339,28 +339,32 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         #      backward, i.e. under the last camera's backward (side stream, read-only on rows nobody writes any more);
         #      the rest, the owner-side accumulation and F (the owners' published sums) stay at the tail.
         dp_split = bool(pipelined and bsz >= 2 and getattr(args, "dp_overlap", True))
-        with _lib.host_region("dp_border_plan"):
+        with _lib.host_region("dp_border_plan"), dp.phase("plan"):
             border = dp.border_plan(touched_rows.long(), N, first_rows=filters[0] if dp_split else None,
                                     last_rows=filters[bsz - 1] if dp_split else None,
                                     publish_counts=not small_owner)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
         own_rows = border.own_rows
         if own_rows.numel():
-            gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
+            with dp.phase("catch_up_own"):
+                gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
         if dp_split:
             dp_comm = getattr(gaussians, "_dp_comm_stream", None)
             if dp_comm is None:
                 dp_comm = gaussians._dp_comm_stream = torch.cuda.Stream()
             dp_comm.wait_stream(default_stream)  # the owners' rows are current
             with torch.cuda.stream(dp_comm):
-                dp.border_params_out(params.data, border, "params0")
+                with dp.phase("B0"):
+                    dp.border_params_out(params.data, border, "params0")
                 dp_ev_b0 = torch.cuda.Event()
                 dp_ev_b0.record(dp_comm)
-                dp.border_params_out(params.data, border, "params1")
+                with dp.phase("B1"):
+                    dp.border_params_out(params.data, border, "params1")
                 dp_ev_b1 = torch.cuda.Event()
                 dp_ev_b1.record(dp_comm)
         else:
-            dp.border_params_out(params.data, border)
+            with dp.phase("B"):
+                dp.border_params_out(params.data, border)
     elif locality_sparse:
         with _lib.host_region("dp_border_plan"):
             border = dp.border_plan(touched_rows.long(), N)
@@ -469,7 +473,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                     ev = torch.cuda.Event()
                     ev.record(s_mem)
                     dp_comm.wait_event(ev)
-                    with torch.cuda.stream(dp_comm):
+                    with torch.cuda.stream(dp_comm), dp.phase("D0"):
                         dp_recv0[0] = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads0")
 
             def _front(k):
@@ -547,6 +551,8 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
         losses.append(loss)
 
+    ph_tail = dp.phase("tail_exchange")  # (bench.py dp.phase_ms: what the exchange adds after the last backward)
+    ph_tail.__enter__()
     if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
         # the Adam gradient scale, so no tensor is touched just to be divided)
         if border is not None and locality_sparse:
@@ -571,9 +577,11 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
                 for t_ in (r0[0], r0[1], r0[3]):  # allocated on the side stream, consumed here
                     if isinstance(t_, torch.Tensor) and t_.is_cuda:
                         t_.record_stream(default_stream)
-                r1 = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads1")
-                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r0)
-                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
+                with dp.phase("D1"):
+                    r1 = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads1")
+                with dp.phase("D_apply"):
+                    dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r0)
+                    dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
             else:
                 dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
             if not small_owner:  # (small_owner: the summed lines are home, and only the owner steps the row)
@@ -595,6 +603,7 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
             dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
                                       gaussians._scaling.grad, gaussians._rotation.grad], average=False)
             dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
+    ph_tail.__exit__()
     if getattr(args, "debug_skip_optimizer", False):
         # test hook: the batch ran exactly as in production (packed tables, lazy catch-up, DP exchange)
         # but no optimizer consumes the accumulated gradients; they stay in parameters_grad_buffer[:N],

@@ -204,6 +204,33 @@ def test_bench_plain_python_starts_its_own_ranks(dev):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["dp"]["mode"] == "locality" and j["dp"]["dp_exchange_bytes_per_step"] > 0
+    # round 5: the pre-flight ran on the run's backend and passed (all three stages), the per-phase device times of the
+    # exchange, the replicas' checksums after the completing flush and the plain all-reduce leg are in the line
+    d = j["dp"]
+    assert d["fallback"] is None and d["preflight"]["ok"], d["preflight"]
+    assert set(d["preflight"]["stages_s_rank0"]) == {"raw_collectives", "exchange_on_seeded_table", "tiny_locality_training"}
+    assert d["replicas_equal"] is True and d["completing_flush_ms"] is not None
+    assert {"plan", "S", "B0", "B1", "D0", "D1", "tail_exchange"} <= set(d["phase_ms"]), d["phase_ms"]
+    ar = d["allreduce_leg"]
+    assert ar["mode"] == "allreduce" and ar["value"] > 0 and ar["replicas_equal"] is True, ar
+
+
+def test_bench_falls_back_to_allreduce_when_the_preflight_fails(dev):
+    """the first contact with a multi-GPU backend must not be able to lose the run.  The locality
+    collective of the pre-flight is made to fail on rank 0 (CLMGS_PREFLIGHT_INJECT): the run must still print ONE line
+    with n_gpus == 2, in the plain all-reduce mode, and say why."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1", CLMGS_PREFLIGHT_INJECT="raise")
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                "--config", "small", "--prime-seconds", "0"], env=env)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    d = j["dp"]
+    assert d["mode"] == "allreduce" and d["fallback"]["from"] == "locality" and d["fallback"]["to"] == "allreduce", d
+    assert "injected failure" in json.dumps(d["fallback"]["reason"]), d["fallback"]
+    assert d["preflight"]["ok"] is False and d["allreduce_leg"] is None
 
 
 def test_bench_refuses_more_ranks_than_gpus(dev):
