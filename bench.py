@@ -510,9 +510,11 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
     for c in cams:  # the loop takes cameras whose ground truth is on the GPU (trainer.training docstring)
         if c.original_image is None:
             c.original_image = c.image_host.to("cuda")
+    # the reference's cadence (densification.py:5-20, arguments/__init__.py: densification_interval 100): a
+    # densify_and_prune every 100 images -- 3 in the default 400-image leg -- and one opacity reset
     args = utils.default_args(bsz=bsz, sh_residency="hbm", iterations=n_img,
-                              densify_from_iter=n_img // 4, densification_interval=n_img // 2,
-                              densify_until_iter=3 * n_img // 4, opacity_reset_interval=3 * n_img // 4,
+                              densify_from_iter=50, densification_interval=100,
+                              densify_until_iter=n_img - 50, opacity_reset_interval=3 * (n_img // 4),
                               densify_grad_threshold=float(a.trainer_grad_threshold),
                               # row tables with 5 % of head room, as a training run sizes them (the reference's
                               # --prealloc_capacity, train.py:107-115): the densification appends in place instead of
@@ -560,14 +562,17 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
            "eval_train_l1_psnr": [float(x) for x in psnr[-1]] if psnr else None,
            "loss_first_last_batch": [[float(x) for x in first.group(1).split()] if first else None,
                                      [float(x) for x in last[-1].split()] if last else None],
-           "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items()},
+           "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items() if k != "reserved_bytes"},
+           "allocator_reserved_bytes": int(phases.get("reserved_bytes", 0)),
            "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
-           "schedule": {"densify_at_image": n_img // 2, "opacity_reset_at_image": 3 * n_img // 4,
+           "schedule": {"densify_at_images": list(range(100, n_img - 49, 100)), "opacity_reset_at_image": 3 * (n_img // 4),
                         "densify_grad_threshold": float(a.trainer_grad_threshold)},
            "what": "clm_gs_amd.trainer.training on a fresh model of the bench scene: shuffled epochs over the run's cameras, "
-                   "LR schedule, engine call per batch, one densify_and_prune + Z-order re-sort and one opacity reset INSIDE the "
-                   "End2endTimer, evaluation outside it; no priming, no allocator reservoir; loss lines written one batch late "
-                   "(defer_loss_log) so the host never drains the device between batches"}
+                   "LR schedule, engine call per batch, a densify_and_prune (+ Z-order re-sort in the same compaction) every 100 "
+                   "images as the reference schedules it and one opacity reset INSIDE the End2endTimer, evaluation outside it; "
+                   "none of bench.py's aids (no priming renders; the allocator warm-up is the trainer's own, inside the clock: "
+                   "host_seconds_by_phase.reserve); loss lines written one batch late (defer_loss_log) so the host never "
+                   "drains the device between batches"}
     del g
     gc.collect()
     torch.cuda.empty_cache()

@@ -9,6 +9,12 @@ without the built library raises.
 
 __version__ = "0.1.0"
 
-from .runtime_env import single_gpu_runtime_defaults as _defaults
+import sys as _sys
 
-_defaults()  # hardware-queue default for single-GPU processes (runtime_env.py); a no-op once HIP has initialised
+# Process-level runtime defaults (runtime_env.py: the hardware-queue count of single-GPU processes) are applied by the
+# product's own ENTRY POINTS only -- bench.py calls runtime_env.single_gpu_runtime_defaults() itself, and
+# `python -m clm_gs_amd.trainer` is recognised here (this file runs before the trainer module imports torch).  A plain
+# `import clm_gs_amd` from somebody else's process changes nothing in that process's environment.
+if "clm_gs_amd.trainer" in list(getattr(_sys, "orig_argv", []))[1:4]:
+    from .runtime_env import single_gpu_runtime_defaults as _defaults
+    _defaults()

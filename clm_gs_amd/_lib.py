@@ -217,34 +217,6 @@ class host_region:
         return False
 
 
-_HIP = None
-_MASKED = []  # (handle, ExternalStream) kept for the life of the process
-
-
-def cu_masked_stream(reserve_cus):
-    """A HIP stream whose kernels may NOT run on `reserve_cus` of the device's CUs (hipExtStream
-    CreateWithCUMask; the top bits of the mask are cleared -- the driver deals mask bits round-robin
-    over the XCDs, so every XCD keeps the same share).  Used for the alpha-blend stream: its one-wave
-    workgroups otherwise refill every freed wave slot of the chip and multi-wave workgroups of the
-    concurrent latency-bound kernels wait until the tile kernel drains."""
-    global _HIP
-    if _HIP is None:
-        _HIP = ctypes.CDLL("libamdhip64.so")
-    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    keep = max(1, n_cu - int(reserve_cus))
-    words = (n_cu + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for i in range(keep):
-        mask[i // 32] |= (1 << (i % 32))
-    h = ctypes.c_void_p()
-    rc = _HIP.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
-    if rc != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
-    st = torch.cuda.ExternalStream(h.value)
-    _MASKED.append((h, st))
-    return st
-
-
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -222,7 +222,13 @@ class BaseGaussianModel(ABC):
             assert torch.all(self.max_radii2D == 0)
             big_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
             prune_mask = torch.logical_or(prune_mask, big_ws)
-        self.prune_points(torch.logical_or(prune_mask, split_mask))  # one compaction instead of two
+        mask = torch.logical_or(prune_mask, split_mask)  # one compaction instead of two
+        if getattr(self, "fuse_sort_into_prune", False):
+            # the trainer keeps the rows in Z-order (spatial_row_order): the compaction of this prune also re-sorts
+            # (clm_offload model, HBM rows) -- the spatial_sort() the trainer calls next finds nothing left to do
+            self.prune_points(mask, resort=True)
+        else:
+            self.prune_points(mask)
 
     # ----------------------------------------------------------- storage order
     def permute_rows(self, order):

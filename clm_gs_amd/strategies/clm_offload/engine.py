@@ -227,32 +227,84 @@ def _gpu_adam_step(gaussians, args, visibility_mask, grad_div=None):
 
 
 # ----------------------------------------------------------------------- HBM-resident
-def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
-                         pipe_args, comm_stream, args):
-    bsz = len(batched_cameras)
-    N = gaussians._xyz.shape[0]
-    touched = touched_rows = None
+def _pipeline_streams(gaussians):
+    """The HIP streams of the camera pipeline, created once per model: `mem` (high priority: front end / loss /
+    projection backward), `raster` (low priority: the alpha-blend kernels), `aux`."""
+    sts = getattr(gaussians, "_clmgs_streams", None)
+    if sts is None:
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
+        except AttributeError:
+            lo, hi = 0, -1
+        sts = gaussians._clmgs_streams = {
+            "aux": torch.cuda.Stream(),
+            "mem": [torch.cuda.Stream(priority=hi) for _ in range(2)],
+            "raster": [torch.cuda.Stream(priority=lo) for _ in range(2)]}
+    return sts
+
+
+def reserve_working_set(gaussians, n_cameras_in_flight=2):
+    """Allocator warm-up of a training run (the product's own form of what bench.py used to do for itself): ONE block per
+    stream pool, sized for the per-camera buffers that stream allocates (fused.py) and freed at once, so that the
+    caching allocator serves the first batches -- and every later, slightly larger request -- by splitting it instead of
+    calling hipMalloc (15-20 ms each in the first process of a fresh box; the 400-image trainer run of round 4 made 45).
+    Sizes from the image size and the model size alone; the data-dependent intersection count is taken as the pixel
+    count (Rubble 4K slab: 0.6-0.8 of it).  The memory stays RESERVED by the allocator, not allocated: it does not count
+    in max_memory_allocated, and on a 288 GB device a few GB of reserve are the cheapest thing there is.
+    -> bytes reserved per pool."""
+    W, H = int(utils.get_img_width()), int(utils.get_img_height())
+    P, N = W * H, int(gaussians._xyz.shape[0])
+    I = int(1.3 * P)
+    V = min(N, max(1, N // 6))
+    k = int(n_cameras_in_flight)
+    sts = _pipeline_streams(gaussians)
+    plan = {
+        "front": (sts["mem"][0], k * (20 * P + 56 * I + 96 * V)),      # image / alpha / last ids, lists + sort space, records
+        "mem": (sts["mem"][1], k * 48 * P + (1 << 20)),                 # SSIM derivative maps + the loss cotangent
+        "raster": (sts["raster"][0], k * 64 * I),                       # one partial-gradient line per intersection
+        # default stream: filters and touched-row lists of a batch, and the temporaries of a densification (masks,
+        # selections and the re-created per-row tensors: ~160 B per row)
+        "default": (torch.cuda.current_stream(), 160 * N + 64 * V * 4),
+    }
+    out = {}
+    for name, (st, nbytes) in plan.items():
+        with torch.cuda.stream(st):
+            blk = torch.empty((int(nbytes),), dtype=torch.uint8, device=gaussians._xyz.device)
+            del blk
+        out[name] = int(nbytes)
+    return out
+
+
+class _Batch:
+    """State of one HBM-resident batch, handed from stage to stage (see _train_one_batch_hbm)."""
+
+
+def _stage_visibility(b):
+    """Stage 1: (camera-DP step S) + the batch's visibility filters and the union of touched rows, selected on the GPU."""
+    gaussians, args, cams = b.gaussians, b.args, b.cameras
+    N = b.N
+    b.touched = b.touched_rows = None
     # camera-DP, small attributes at their owners (gaussian_model.small_owner): step S -- the current values of every
     # foreign row that may be visible this batch arrive BEFORE the visibility pass reads them
-    small_owner = bool(getattr(gaussians, "small_owner", False) and gaussians.lazy_rows and dp.active()
-                       and not args.stop_update_param)
-    if small_owner:
+    b.small_owner = bool(getattr(gaussians, "small_owner", False) and gaussians.lazy_rows and dp.active()
+                         and not args.stop_update_param)
+    if b.small_owner:
         with torch.no_grad(), _lib.host_region("dp_small_fetch"), dp.phase("S"):
-            gaussians.small_prepare(batched_cameras)
+            gaussians.small_prepare(cams)
     with torch.no_grad():
-        if getattr(args, "fused_front_end", True):
+        if b.fused:
             # same fast exp as the fused front end -> filter and render agree on every cull;
             # filters AND the union of touched rows are selected on the GPU in one pass
             with _lib.host_region("select_filters"):
-                filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
-                                                       gaussians._scaling.detach(), gaussians._rotation.detach())
+                b.filters, b.touched_rows = select_filters(cams, gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                                           gaussians._rotation.detach())
         else:
-            filters, _, _ = calculate_filters(batched_cameras, gaussians.get_xyz, gaussians.get_opacity,
-                                              gaussians.get_scaling, gaussians.get_rotation)
-    if small_owner and os.environ.get("CLMGS_DP_DEBUG") and touched_rows is not None:
+            b.filters, _, _ = calculate_filters(cams, gaussians.get_xyz, gaussians.get_opacity,
+                                                gaussians.get_scaling, gaussians.get_rotation)
+    if b.small_owner and os.environ.get("CLMGS_DP_DEBUG") and b.touched_rows is not None:
         # debug: every foreign row the exact pass selected must have been a candidate of step S
         lo_, hi_ = dp.owner_range(N)
-        foreign = touched_rows[(touched_rows < lo_) | (touched_rows >= hi_)]
+        foreign = b.touched_rows[(b.touched_rows < lo_) | (b.touched_rows >= hi_)]
         cand_ = getattr(gaussians, "_dbg_cand", None)
         miss = -1
         if cand_ is not None and gaussians._small_since > 0:
@@ -262,74 +314,86 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         print("DPDEBUG batch rank %d since %d foreign touched rows %d not candidates %d" % (
             dp.rank(), gaussians._small_since, foreign.numel(), miss), flush=True)
         assert miss <= 0
-    sparsity = [len(f) / float(N) for f in filters]
-    ordered_cams = list(range(bsz))
+    b.sparsity = [len(f) / float(N) for f in b.filters]
+    b.ordered_cams = list(range(b.bsz))
     if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
-        _, batched_cameras, filters, sparsity, ordered_cams = order_calculation(
-            list(filters), list(batched_cameras), N, bsz, None, args)[:5]
-    lazy_mode = gaussians.lazy_rows and not args.stop_update_param
-    fused = getattr(args, "fused_front_end", True)
+        _, b.cameras, b.filters, b.sparsity, b.ordered_cams = order_calculation(
+            list(b.filters), list(cams), N, b.bsz, None, args)[:5]
+
+
+def _stage_plan(b):
+    """Stage 2: which optimizer / exchange form this batch runs in; the touched mask where a form needs it; the row
+    optimizer's step counter."""
+    gaussians, args, N, bsz = b.gaussians, b.args, b.N, b.bsz
+    b.lazy = gaussians.lazy_rows and not args.stop_update_param
     mode = getattr(args, "overlap_cameras", True)
-    mode = {True: "pipeline", False: "off"}.get(mode, mode)
-    pipelined = fused and mode == "pipeline"
+    b.pipelined = b.fused and mode in (True, "pipeline")
     # packed [N,12] mirror + packed gradient table for the four small tensors (dense fused path)
-    use_packed = (fused and getattr(args, "packed_small", True) and not args.sparse_adam
-                  and not args.stop_update_param)
+    b.use_packed = (b.fused and getattr(args, "packed_small", True) and not args.sparse_adam
+                    and not args.stop_update_param)
     # camera-DP, locality exchange (dp.py): every rank works on ITS cameras' rows; no global touched mask
-    locality = bool(lazy_mode and dp.active() and getattr(args, "dp_locality", False))
+    b.locality = bool(b.lazy and dp.active() and getattr(args, "dp_locality", False))
     # ... and its sparse_adam form (config 5 as the reference scripts it: SelectiveAdam for the small attributes, the
     # SH rows of visible Gaussians only): eager row optimizer at the owner, clearing-policy gradient tables
-    locality_sparse = bool(dp.active() and getattr(args, "dp_locality", False) and args.sparse_adam and fused
-                           and not args.stop_update_param and not lazy_mode)
+    b.locality_sparse = bool(dp.active() and getattr(args, "dp_locality", False) and args.sparse_adam and b.fused
+                             and not args.stop_update_param and not b.lazy)
     if getattr(args, "dp_locality", False) and dp.active():
-        assert touched_rows is not None and (locality_sparse or (locality and use_packed and gaussians.first_touch_grads)), (
+        assert b.touched_rows is not None and (b.locality_sparse or (b.locality and b.use_packed and gaussians.first_touch_grads)), (
             "dp_locality needs the fused front end and either the dense deferred row optimizer with the packed "
             "small-attribute tables and first-touch gradient stores (defaults) or sparse_adam")
-    need_mask = touched_rows is None or args.sparse_adam or (dp.active() and not locality) or not lazy_mode
+    need_mask = b.touched_rows is None or args.sparse_adam or (dp.active() and not b.locality) or not b.lazy
     if need_mask:
-        touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
-        if touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
-            utils.fill_rows(touched, touched_rows, True)
+        b.touched = torch.zeros((N,), dtype=torch.bool, device=gaussians._xyz.device)
+        if b.touched_rows is not None:  # index_fill_: scalar as kernel argument, no blocking H2D copy
+            utils.fill_rows(b.touched, b.touched_rows, True)
         else:
-            for f in filters:
-                utils.fill_rows(touched, f, True)
+            for f in b.filters:
+                utils.fill_rows(b.touched, f, True)
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
-        if dp.active() and not locality_sparse:  # (locality: the global mask is assembled from what the owners publish)
-            touched = dp.allreduce_touched(touched)
-            touched_rows = None
-    row_adam = gaussians.optimizer.cpu_adam
-    params = gaussians._parameters
-    grad_buf = parameters_grad_buffer[:N]
-    params.grad = grad_buf
-    row_adam.global_step += 1
-    step = row_adam.global_step
-    group = row_adam.param_groups[0]
-    st = row_adam.state[params]
-    default_stream = torch.cuda.current_stream()
-    side_event = None
-    col_lr = row_adam._col_lr(params.device)
-
-    def row_update(rows, zero_grad_rows=False):
-        # explicit row lists: the kernel walks |rows| x 48 elements instead of scanning all N rows;
-        # rows the batch never touches have an all-zero gradient -> the grad buffer is not read
-        clm_kernels.adam_rows(params.data, None if zero_grad_rows else grad_buf, st["exp_avg"],
-                              st["exp_avg_sq"], rows, col_lr,
-                              group["betas"][0], group["betas"][1], group["eps"], step,
-                              group["bias_correction"], 1.0 / (bsz * dp.world_size()), True)
-
-    if touched_rows is None:
-        touched_rows = torch.nonzero(touched).flatten()
-    touched_rows = touched_rows.to(torch.int32)
-    _lib.STATS.setdefault("touched_rows", []).append(int(touched_rows.shape[0]))  # shape known on the host
-    lazy = gaussians.lazy_rows and not args.stop_update_param
+        if dp.active() and not b.locality_sparse:  # (locality: the global mask is assembled from what the owners publish)
+            b.touched = dp.allreduce_touched(b.touched)
+            b.touched_rows = None
+    b.row_adam = gaussians.optimizer.cpu_adam
+    b.params = gaussians._parameters
+    b.grad_buf = b.parameters_grad_buffer[:N]
+    b.params.grad = b.grad_buf
+    b.row_adam.global_step += 1
+    b.step = b.row_adam.global_step
+    gaussians._lazy_dirty = True   # deferred row steps will be waiting (flush_lazy_rows clears it)
+    gaussians._sorted_tag = None   # positions move: "the rows are in Z-order of their current positions" ends here
+    b.group = b.row_adam.param_groups[0]
+    b.st = b.row_adam.state[b.params]
+    b.default_stream = torch.cuda.current_stream()
+    b.side_event = None
+    b.col_lr = b.row_adam._col_lr(b.params.device)
+    if b.touched_rows is None:
+        b.touched_rows = torch.nonzero(b.touched).flatten()
+    b.touched_rows = b.touched_rows.to(torch.int32)
+    _lib.STATS.setdefault("touched_rows", []).append(int(b.touched_rows.shape[0]))  # shape known on the host
     # first-touch gradient stores (gaussian_model.first_touch_grads): the projection/SH backward stamps
     # `_row_g_step` itself and stores instead of accumulating on a row's first touch of this step
-    ft_stamp = gaussians._row_g_step if (lazy and fused and gaussians.first_touch_grads) else None
-    owner = border = None  # owner-computes camera-DP (dp.py): rows owned by index range
-    dp_ev_b0 = dp_ev_b1 = dp_comm = None
-    dp_split = False
-    if locality:
+    b.ft_stamp = gaussians._row_g_step if (b.lazy and b.fused and gaussians.first_touch_grads) else None
+
+
+def _row_update(b, rows, zero_grad_rows=False):
+    # explicit row lists: the kernel walks |rows| x 48 elements instead of scanning all N rows;
+    # rows the batch never touches have an all-zero gradient -> the grad buffer is not read
+    clm_kernels.adam_rows(b.params.data, None if zero_grad_rows else b.grad_buf, b.st["exp_avg"],
+                          b.st["exp_avg_sq"], rows, b.col_lr,
+                          b.group["betas"][0], b.group["betas"][1], b.group["eps"], b.step,
+                          b.group["bias_correction"], 1.0 / (b.bsz * dp.world_size()), True)
+
+
+def _stage_exchange_head(b):
+    """Stage 3, before rendering: the rows the batch renders from are brought up to date (deferred row optimizer) and,
+    camera-DP, fetched from their owners (steps A + B of the locality exchange / the all-gather of owner-computes)."""
+    gaussians, args, N, bsz, step = b.gaussians, b.args, b.N, b.bsz, b.step
+    params, touched_rows = b.params, b.touched_rows
+    b.owner = b.border = None  # owner-computes camera-DP (dp.py): rows owned by index range
+    b.dp_ev_b0 = b.dp_ev_b1 = b.dp_comm = None
+    b.dp_split = False
+    if b.locality:
         # A + B of the locality exchange: who needs which of my rows; bring every own row anybody renders from
         # up to date (waiting gradient step + replays); parameter rows out to the ranks that asked for them.
         # OVERLAP (round 4, dp_overlap): under the camera pipeline the exchange is split (dp.border_plan parts) --
@@ -338,311 +402,277 @@ def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buff
         #   D  gradient lines of the border rows the LAST camera does not touch leave right after the second-to-last
         #      backward, i.e. under the last camera's backward (side stream, read-only on rows nobody writes any more);
         #      the rest, the owner-side accumulation and F (the owners' published sums) stay at the tail.
-        dp_split = bool(pipelined and bsz >= 2 and getattr(args, "dp_overlap", True))
+        b.dp_split = bool(b.pipelined and bsz >= 2 and getattr(args, "dp_overlap", True))
         with _lib.host_region("dp_border_plan"), dp.phase("plan"):
-            border = dp.border_plan(touched_rows.long(), N, first_rows=filters[0] if dp_split else None,
-                                    last_rows=filters[bsz - 1] if dp_split else None,
-                                    publish_counts=not small_owner)
+            b.border = dp.border_plan(touched_rows.long(), N, first_rows=b.filters[0] if b.dp_split else None,
+                                      last_rows=b.filters[bsz - 1] if b.dp_split else None,
+                                      publish_counts=not b.small_owner)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
-        own_rows = border.own_rows
+        own_rows = b.border.own_rows
         if own_rows.numel():
             with dp.phase("catch_up_own"):
                 gaussians.catch_up_rows(own_rows.to(torch.int32), to_step=step - 1)
-        if dp_split:
-            dp_comm = getattr(gaussians, "_dp_comm_stream", None)
-            if dp_comm is None:
-                dp_comm = gaussians._dp_comm_stream = torch.cuda.Stream()
-            dp_comm.wait_stream(default_stream)  # the owners' rows are current
-            with torch.cuda.stream(dp_comm):
+        if b.dp_split:
+            b.dp_comm = getattr(gaussians, "_dp_comm_stream", None)
+            if b.dp_comm is None:
+                b.dp_comm = gaussians._dp_comm_stream = torch.cuda.Stream()
+            b.dp_comm.wait_stream(b.default_stream)  # the owners' rows are current
+            with torch.cuda.stream(b.dp_comm):
                 with dp.phase("B0"):
-                    dp.border_params_out(params.data, border, "params0")
-                dp_ev_b0 = torch.cuda.Event()
-                dp_ev_b0.record(dp_comm)
+                    dp.border_params_out(params.data, b.border, "params0")
+                b.dp_ev_b0 = torch.cuda.Event()
+                b.dp_ev_b0.record(b.dp_comm)
                 with dp.phase("B1"):
-                    dp.border_params_out(params.data, border, "params1")
-                dp_ev_b1 = torch.cuda.Event()
-                dp_ev_b1.record(dp_comm)
+                    dp.border_params_out(params.data, b.border, "params1")
+                b.dp_ev_b1 = torch.cuda.Event()
+                b.dp_ev_b1.record(b.dp_comm)
         else:
             with dp.phase("B"):
-                dp.border_params_out(params.data, border)
-    elif locality_sparse:
-        with _lib.host_region("dp_border_plan"):
-            border = dp.border_plan(touched_rows.long(), N)
+                dp.border_params_out(params.data, b.border)
+    elif b.locality_sparse:
+        with _lib.host_region("dp_border_plan"), dp.phase("plan"):
+            b.border = dp.border_plan(touched_rows.long(), N)
         gaussians._owner_dirty = True
-        dp.border_params_out(params.data, border)  # the owners' rows are always current (eager row optimizer)
-    elif lazy and dp.active() and getattr(args, "dp_owner_computes", False):
-        owner = dp.owner_plan(touched_rows.long(), N)
+        with dp.phase("B"):
+            dp.border_params_out(params.data, b.border)  # the owners' rows are always current (eager row optimizer)
+    elif b.lazy and dp.active() and getattr(args, "dp_owner_computes", False):
+        b.owner = dp.owner_plan(touched_rows.long(), N)
         gaussians._owner_dirty = True  # replicas are partial until the next flush_lazy_rows()
-        own_rows = touched_rows[owner.lo:owner.hi]
-        if owner.hi > owner.lo:  # waiting gradient step + replays, on the rows this rank owns
+        own_rows = touched_rows[b.owner.lo:b.owner.hi]
+        if b.owner.hi > b.owner.lo:  # waiting gradient step + replays, on the rows this rank owns
             gaussians.catch_up_rows(own_rows, to_step=step - 1)
-        dp.owner_gather_rows(params.data, owner)  # every rank renders from the owners' current rows
-    elif lazy:
+        dp.owner_gather_rows(params.data, b.owner)  # every rank renders from the owners' current rows
+    elif b.lazy:
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
         gaussians.catch_up_rows(touched_rows, to_step=step - 1)
     elif not args.stop_update_param and not args.sparse_adam:
         # rows this batch never touches: zero gradient, pure momentum decay -> overlap with render
-        untouched_rows = torch.nonzero(~touched).flatten().to(torch.int32)
-        comm_stream.wait_stream(default_stream)
-        with torch.cuda.stream(comm_stream):
-            row_update(untouched_rows, zero_grad_rows=True)
-            side_event = torch.cuda.Event()
-            side_event.record(comm_stream)
-        untouched_rows.record_stream(comm_stream)
+        untouched_rows = torch.nonzero(~b.touched).flatten().to(torch.int32)
+        b.comm_stream.wait_stream(b.default_stream)
+        with torch.cuda.stream(b.comm_stream):
+            _row_update(b, untouched_rows, zero_grad_rows=True)
+            b.side_event = torch.cuda.Event()
+            b.side_event.record(b.comm_stream)
+        untouched_rows.record_stream(b.comm_stream)
 
-    small_pk = small_gk = stats_d = None
-    if use_packed:
-        small_pk, small_gk = gaussians.small_packed(), gaussians.small_grad()
+
+def _cameras_pipelined(b):
+    """Software pipeline over the cameras of the batch, streams by kernel TYPE:
+      front  (high priority): projection + binning of camera k, one camera ahead
+      mem    (high priority): loss of camera k, projection/SH backward of camera k-1
+      raster (low priority) : the ALU-bound tile kernels, enqueued RF0 RF1 RB0 RF2 RB1 ...
+    so the tile stream always has the next forward to run while a loss is being computed, and the latency-bound kernels
+    fill the memory system underneath it.  Measured-out variants of this schedule (a CU mask on the tile stream, a
+    second front stream running a camera ahead of the host's count wait, two forwards ahead of the oldest backward,
+    all streams at one priority, one stream pair per camera) are recorded in DESIGN.md section 6 and gone from the code."""
+    from ...fused import camera_backward, camera_forward_finish, camera_front, camera_loss
+    gaussians, bsz, step = b.gaussians, b.bsz, b.step
+    sts = _pipeline_streams(gaussians)
+    s_front, s_mem, s_raster = sts["mem"][0], sts["mem"][1], sts["raster"][0]
+    if getattr(gaussians, "_clmgs_one", None) is None:  # the loss cotangent (1.0), made on the
+        gaussians._clmgs_one = torch.ones((1,), dtype=torch.float32, device=b.params.device)  # default stream
+    for st_ in (s_front, s_mem, s_raster):
+        st_.wait_stream(b.default_stream)
+    # the previous batch's per-camera tensors: every stream that read them has been joined
+    # into the default stream, which the three streams now wait for -> safe to recycle
+    gaussians._clmgs_passes = None
+    passes = []
+    dp_recv0 = [None]
+
+    def backward(k):
+        with _lib.host_region("camera_backward"):
+            camera_backward(gaussians, passes[k], b.grad_buf, b.small_gk, stats_delta=b.stats_d,
+                            sh_stamp=b.ft_stamp, cur_step=step, release=True)
+        # camera-DP, locality exchange: the gradient lines of the border rows the last camera does not touch are
+        # final once camera bsz-2's backward is enqueued -- they travel now, under the last camera's backward
+        if b.dp_split and k == bsz - 2:
+            ev = torch.cuda.Event()
+            ev.record(s_mem)
+            b.dp_comm.wait_event(ev)
+            with torch.cuda.stream(b.dp_comm), dp.phase("D0"):
+                dp_recv0[0] = dp.border_grads_send([b.grad_buf, b.small_gk], b.ft_stamp, step, b.border, "grads0")
+
+    for k in range(bsz):
+        if b.dp_split:  # parameters of this camera's border rows have landed (part 0: camera 0, part 1: the rest)
+            s_front.wait_event(b.dp_ev_b0 if k == 0 else b.dp_ev_b1)
+        with _lib.host_region("camera_front"):
+            cur_pass = camera_front(gaussians, b.cameras[k], b.filters[k], b.params.data, 1, b.background,
+                                    b.cameras[k].original_image, small_packed=b.small_pk,
+                                    streams=(s_front, s_mem, s_raster))
+        with _lib.host_region("camera_forward"):
+            passes.append(camera_forward_finish(gaussians, cur_pass))
+        if k >= 1:  # the forward runs one camera ahead of the backward
+            backward(k - 1)
+    backward(bsz - 1)
+    if b.dp_split:
+        b.default_stream.wait_stream(b.dp_comm)
+        gaussians._dp_recv0 = dp_recv0[0]
+    for st_ in (s_front, s_mem, s_raster):
+        b.default_stream.wait_stream(st_)
+    losses = [camera_loss(p_) for p_ in passes]  # loss values: after the join, off the chain
+    gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)
+    return losses
+
+
+def _stage_cameras(b):
+    """Stage 4: every camera of the batch -- forward, loss, backward; gradients accumulate by row id."""
+    gaussians, args, bsz = b.gaussians, b.args, b.bsz
+    b.small_pk = b.small_gk = b.stats_d = None
+    if b.use_packed:
+        b.small_pk, b.small_gk = gaussians.small_packed(), gaussians.small_grad()
         if (getattr(args, "packed_stats", True) and (not args.disable_auto_densification)
                 and utils.get_cur_iter() <= args.densify_until_iter):
-            stats_d = gaussians.stats_delta()
+            b.stats_d = gaussians.stats_delta()
     else:
         _zero_small_grads(gaussians)
+    if b.pipelined:
+        return _cameras_pipelined(b)
     losses = []
-    if fused:
-        # Two cameras in flight on two streams: the ALU-bound tile kernels of one overlap with the
-        # HBM-bound front end / sort / loss of the other; the accumulating kernels are chained by
-        # events so the read-modify-write gradient sums stay ordered.
-        from ...fused import (camera_backward, camera_forward_finish, camera_front, camera_loss,
-                              train_one_camera)
-        n_lanes = max(1, int(getattr(args, "overlap_lanes", 2)))
-        sts = getattr(gaussians, "_clmgs_streams", None)
-        if sts is None or len(sts["mem"]) < max(2, n_lanes):
-            try:
-                lo, hi = torch.cuda.Stream.priority_range()  # (lowest, highest), e.g. (0, -1)
-            except AttributeError:
-                lo, hi = 0, -1
-            if getattr(args, "flat_stream_priorities", False):  # experiment knob: every stream at the default priority
-                lo = hi = 0
-            sts = gaussians._clmgs_streams = {
-                "aux": torch.cuda.Stream(),
-                "mem": [torch.cuda.Stream(priority=hi) for _ in range(max(2, n_lanes))],
-                "raster": [torch.cuda.Stream(priority=lo) for _ in range(max(2, n_lanes))]}
-            sts["raster_masked"] = {}
-            sts["front2"] = torch.cuda.Stream(priority=hi)
-        n_tiles = ((int(utils.get_img_width()) + 15) // 16) * ((int(utils.get_img_height()) + 15) // 16)
-        if mode == "pipeline":
-            # Software pipeline over the cameras of the batch, streams by kernel TYPE:
-            #   front  (high priority): projection + binning of camera k, one camera ahead
-            #   mem    (high priority): loss of camera k, projection/SH backward of camera k-1
-            #   raster (low priority) : the ALU-bound tile kernels, enqueued RF0 RF1 RB0 RF2 RB1 ...
-            # so the tile stream always has the next forward to run while a loss is being computed,
-            # and the latency-bound kernels fill the memory system underneath it.  The per-camera
-            # tensors stay alive until the end-of-batch synchronisation (several streams read them).
-            s_front, s_mem, s_raster = sts["mem"][0], sts["mem"][1], sts["raster"][0]
-            # CU mask of the tile stream (raster_reserve_cus CUs kept for the other streams; -1 = the measured default).
-            # Round 2 kept 64 CUs out of the tile stream's mask at 28 M / 4K (+1.8 %: the tile kernels' one-wave
-            # workgroups refill every freed wave slot and the multi-wave workgroups of the front end waited for them).
-            # Re-measured in round 3 (three interleaved rounds in one call, GT resident): 0 CUs 157.7 / 156.2 / 158.1,
-            # 64 CUs 152.3 / 151.6 / 151.0, 16 CUs 148.9 / 148.2 / 149.4 img/s -- with Z-ordered rows, first-touch
-            # stores and the folded row sum the front end is no longer the long pole, and the masked stream (default
-            # priority) costs more than it protects.  Default: no mask, the low-priority tile stream.
-            reserve = int(getattr(args, "raster_reserve_cus", -1))
-            if reserve < 0:
-                reserve = 0
-            if reserve > 0:
-                if reserve not in sts["raster_masked"]:
-                    sts["raster_masked"][reserve] = _lib.cu_masked_stream(reserve)
-                s_raster = sts["raster_masked"][reserve]
-            if getattr(gaussians, "_clmgs_one", None) is None:  # the loss cotangent (1.0), made on the
-                gaussians._clmgs_one = torch.ones((1,), dtype=torch.float32, device=params.device)  # default stream
-            for st_ in (s_front, sts["front2"], s_mem, s_raster):
-                st_.wait_stream(default_stream)
-            # the previous batch's per-camera tensors: every stream that read them has been joined
-            # into the default stream, which the three streams now wait for -> safe to recycle
-            gaussians._clmgs_passes = None
-            passes = []
-            # forwards run `depth` cameras ahead of the backwards: RF0 .. RF(depth) RB0 RF(depth+1) RB1 ...
-            depth = max(1, int(getattr(args, "pipeline_depth", 1)))
-            # front_ahead: the host stays one camera ahead of the device (projection + tile counting
-            # of camera k+1 enqueued on a second front stream before the host waits for camera k's
-            # intersection count; the wait is an event on an asynchronous readback either way).
-            # Measured 3 % SLOWER than the plain order (the early kernels co-run with camera k's
-            # tile sort, which is on the chain to RF_k), so it is off by default.
-            ahead = bool(getattr(args, "front_ahead", False))
-            fronts = (s_front, sts["front2"]) if ahead else (s_front, s_front)
-
-            dp_recv0 = [None]
-
-            def _after_backward(k):
-                # camera-DP, locality exchange: the gradient lines of the border rows the last camera does not touch are
-                # final once camera bsz-2's backward is enqueued -- they travel now, under the last camera's backward
-                if dp_split and k == bsz - 2:
-                    ev = torch.cuda.Event()
-                    ev.record(s_mem)
-                    dp_comm.wait_event(ev)
-                    with torch.cuda.stream(dp_comm), dp.phase("D0"):
-                        dp_recv0[0] = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads0")
-
-            def _front(k):
-                if dp_split:  # parameters of this camera's border rows have landed (part 0: camera 0, part 1: the rest)
-                    fronts[k % 2].wait_event(dp_ev_b0 if k == 0 else dp_ev_b1)
-                with _lib.host_region("camera_front"):
-                    return camera_front(
-                        gaussians, batched_cameras[k], filters[k], params.data, 1, background,
-                        batched_cameras[k].original_image, small_packed=small_pk,
-                        streams=(fronts[k % 2], s_mem, s_raster))
-
-            nxt = _front(0)
-            for micro_idx in range(bsz):
-                if ahead:
-                    cur_pass, nxt = nxt, (_front(micro_idx + 1) if micro_idx + 1 < bsz else None)
-                else:
-                    cur_pass = nxt if micro_idx == 0 else _front(micro_idx)
-                with _lib.host_region("camera_forward"):
-                    passes.append(camera_forward_finish(gaussians, cur_pass))
-                if micro_idx >= depth:
-                    with _lib.host_region("camera_backward"):
-                        camera_backward(gaussians, passes[micro_idx - depth], grad_buf, small_gk,
-                                        stats_delta=stats_d, sh_stamp=ft_stamp, cur_step=step, release=True)
-                    _after_backward(micro_idx - depth)
-            for k in range(max(0, bsz - depth), bsz):
-                with _lib.host_region("camera_backward"):
-                    camera_backward(gaussians, passes[k], grad_buf, small_gk, stats_delta=stats_d,
-                                    sh_stamp=ft_stamp, cur_step=step, release=True)
-                _after_backward(k)
-            if dp_split:
-                default_stream.wait_stream(dp_comm)
-                gaussians._dp_recv0 = dp_recv0[0]
-            default_stream.wait_stream(fronts[1])
-            for st_ in (s_front, s_mem, s_raster):
-                default_stream.wait_stream(st_)
-            losses = [camera_loss(p_) for p_ in passes]  # loss values: after the join, off the chain
-            gaussians._clmgs_passes = passes  # released at the start of the next batch (see above)
-        else:
-            rasters = None
-            if mode == "typed":
-                # one camera per memory lane, tile kernels on low-priority streams (one shared tile
-                # stream for large images, one per lane for small ones)
-                lanes = sts["mem"][:n_lanes]
-                rasters = sts["raster"][:n_lanes] if n_tiles < 20000 else [sts["raster"][0]] * n_lanes
-            elif mode == "camera":
-                lanes = [default_stream, sts["aux"]]
-            else:
-                lanes = [default_stream]
-            for ln in lanes:
-                if ln is not default_stream:
-                    ln.wait_stream(default_stream)
-            prev = None
-            for micro_idx in range(bsz):
-                with torch.cuda.stream(lanes[micro_idx % len(lanes)]):
-                    loss, prev = train_one_camera(
-                        gaussians, batched_cameras[micro_idx], filters[micro_idx], params.data, 1, grad_buf,
-                        background, batched_cameras[micro_idx].original_image, accumulate_after=prev,
-                        return_event=True,
-                        raster_stream=rasters[micro_idx % len(lanes)] if rasters is not None else None,
-                        small_packed=small_pk, small_grad=small_gk, stats_delta=stats_d,
-                        sh_stamp=ft_stamp, cur_step=step)
-                losses.append(loss)
-            for ln in lanes:
-                if ln is not default_stream:
-                    default_stream.wait_stream(ln)
-    for micro_idx in range(0 if fused else bsz):  # op-by-op path (fused_front_end=False)
-        this_filter = filters[micro_idx]
+    if b.fused:  # overlap_cameras=False: one camera after the other on the current stream
+        from ...fused import train_one_camera
+        for k in range(bsz):
+            losses.append(train_one_camera(
+                gaussians, b.cameras[k], b.filters[k], b.params.data, 1, b.grad_buf, b.background,
+                b.cameras[k].original_image, small_packed=b.small_pk, small_grad=b.small_gk,
+                stats_delta=b.stats_d, sh_stamp=b.ft_stamp, cur_step=b.step))
+        return losses
+    for k in range(bsz):  # op-by-op path (fused_front_end=False): the reference's chain of gsplat / clm_kernels calls
+        this_filter = b.filters[k]
         with torch.no_grad():
-            shs = torch.empty((this_filter.shape[0], 48), device=params.device)
-            send_shs2gpu_stream(shs, params.data, this_filter)
+            shs = torch.empty((this_filter.shape[0], 48), device=b.params.device)
+            send_shs2gpu_stream(shs, b.params.data, this_filter)
             shs_grad = torch.zeros_like(shs)
-        loss = _render_and_backward(gaussians, scene, batched_cameras[micro_idx], background,
-                                    pipe_args, this_filter, shs, shs_grad)
+        loss = _render_and_backward(gaussians, b.scene, b.cameras[k], b.background, b.pipe_args, this_filter, shs,
+                                    shs_grad)
         with torch.no_grad():
-            send_shs2cpu_grad_buffer_stream(shs_grad, grad_buf, this_filter, True)
+            send_shs2cpu_grad_buffer_stream(shs_grad, b.grad_buf, this_filter, True)
         losses.append(loss)
+    return losses
 
-    ph_tail = dp.phase("tail_exchange")  # (bench.py dp.phase_ms: what the exchange adds after the last backward)
-    ph_tail.__enter__()
-    if dp.active():  # camera-DP: the one exchange of the batch (sums; 1/ranks rides on
-        # the Adam gradient scale, so no tensor is touched just to be divided)
-        if border is not None and locality_sparse:
-            # D + F, clearing policy: SH gradient rows and the four small gradients of the border rows are added
-            # at their owners; the owners publish the summed small gradients of every row anybody touched, which
-            # also tells every rank the global visibility set SelectiveAdam steps
-            small_grads = [gaussians._xyz.grad, gaussians._opacity.grad, gaussians._scaling.grad, gaussians._rotation.grad]
-            dp.border_grads_home([grad_buf] + small_grads, None, 0, border)
-            own_rows = border.own_rows
-            _, got = dp.publish_rows(small_grads, own_rows, N, counts=border.own_counts)
-            touched = torch.zeros((N,), dtype=torch.bool, device=params.device)
-            for ids in [own_rows] + got:
-                if ids.numel():
-                    utils.fill_rows(touched, ids, True)
-            touched_rows = own_rows.to(torch.int32)  # the SH rows THIS rank steps
-        elif border is not None:
-            # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
-            # their owners; the owners publish the summed small-attribute gradients of their touched rows
-            if dp_split:
-                r0 = gaussians._dp_recv0
-                gaussians._dp_recv0 = None
-                for t_ in (r0[0], r0[1], r0[3]):  # allocated on the side stream, consumed here
-                    if isinstance(t_, torch.Tensor) and t_.is_cuda:
-                        t_.record_stream(default_stream)
-                with dp.phase("D1"):
-                    r1 = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads1")
-                with dp.phase("D_apply"):
-                    dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r0)
-                    dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
-            else:
+
+def _stage_exchange_tail(b):
+    """Stage 5 (camera-DP only): the one gradient exchange of the batch (sums; 1/ranks rides on the Adam gradient
+    scale, so no tensor is touched just to be divided)."""
+    if not dp.active():
+        return
+    gaussians, N, step = b.gaussians, b.N, b.step
+    grad_buf, small_gk, ft_stamp, border = b.grad_buf, b.small_gk, b.ft_stamp, b.border
+    if border is not None and b.locality_sparse:
+        # D + F, clearing policy: SH gradient rows and the four small gradients of the border rows are added
+        # at their owners; the owners publish the summed small gradients of every row anybody touched, which
+        # also tells every rank the global visibility set SelectiveAdam steps
+        small_grads = [gaussians._xyz.grad, gaussians._opacity.grad, gaussians._scaling.grad, gaussians._rotation.grad]
+        dp.border_grads_home([grad_buf] + small_grads, None, 0, border)
+        own_rows = border.own_rows
+        _, got = dp.publish_rows(small_grads, own_rows, N, counts=border.own_counts)
+        b.touched = torch.zeros((N,), dtype=torch.bool, device=b.params.device)
+        for ids in [own_rows] + got:
+            if ids.numel():
+                utils.fill_rows(b.touched, ids, True)
+        b.touched_rows = own_rows.to(torch.int32)  # the SH rows THIS rank steps
+    elif border is not None:
+        # D + F of the locality exchange: border rows' gradient lines (SH row | packed small row) go home to
+        # their owners; the owners publish the summed small-attribute gradients of their touched rows
+        if b.dp_split:
+            r0 = gaussians._dp_recv0
+            gaussians._dp_recv0 = None
+            for t_ in (r0[0], r0[1], r0[3]):  # allocated on the side stream, consumed here
+                if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                    t_.record_stream(b.default_stream)
+            with dp.phase("D1"):
+                r1 = dp.border_grads_send([grad_buf, small_gk], ft_stamp, step, border, "grads1")
+            with dp.phase("D_apply"):
+                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r0)
+                dp.border_grads_apply([grad_buf, small_gk], ft_stamp, step, border, r1)
+        else:
+            with dp.phase("D"):
                 dp.border_grads_home([grad_buf, small_gk], ft_stamp, step, border)
-            if not small_owner:  # (small_owner: the summed lines are home, and only the owner steps the row)
-                dp.publish_small(small_gk, ft_stamp, step, N, border)
-        elif owner is not None:
-            # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
-            # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);
-            # SH gradient rows: summed AT THEIR OWNER, which alone will step them
-            if use_packed:
-                dp.allreduce_tables_rows([small_gk], touched_rows, N, average=False)
-            else:
-                dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
-                                          gaussians._scaling.grad, gaussians._rotation.grad], average=False)
-            dp.owner_reduce_rows(grad_buf, owner)
-        elif use_packed:
-            # one collective: packed small gradients + SH gradient rows of the globally touched set
-            dp.allreduce_tables_rows([small_gk, grad_buf], touched_rows, N, average=False)
+        if not b.small_owner:  # (small_owner: the summed lines are home, and only the owner steps the row)
+            dp.publish_small(small_gk, ft_stamp, step, N, border)
+    elif b.owner is not None:
+        # small gradients: all-reduce over the touched rows (their dense Adam stays replicated: the
+        # next batch's visibility pass needs every row's xyz / scale / rotation on every rank);
+        # SH gradient rows: summed AT THEIR OWNER, which alone will step them
+        if b.use_packed:
+            dp.allreduce_tables_rows([small_gk], b.touched_rows, N, average=False)
         else:
             dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
                                       gaussians._scaling.grad, gaussians._rotation.grad], average=False)
-            dp.allreduce_rows(grad_buf, touched, average=False, rows=touched_rows)
-    ph_tail.__exit__()
-    if getattr(args, "debug_skip_optimizer", False):
-        # test hook: the batch ran exactly as in production (packed tables, lazy catch-up, DP exchange)
-        # but no optimizer consumes the accumulated gradients; they stay in parameters_grad_buffer[:N],
-        # the packed small-gradient table / the four .grad tensors, UNSCALED (sum over the cameras)
-        row_adam.global_step -= 1
-        if side_event is not None:
-            default_stream.wait_event(side_event)
-        return losses, ordered_cams, sparsity
-    if use_packed:
-        gaussians.optimizer.gpu_step_packed(small_pk, small_gk, 1.0 / (bsz * dp.world_size()),
-                                            g_stamp=ft_stamp, cur_step=step,
-                                            row_range=dp.owner_range(N) if (small_owner and locality) else None)
-        if small_owner and locality:
+        dp.owner_reduce_rows(grad_buf, b.owner)
+    elif b.use_packed:
+        # one collective: packed small gradients + SH gradient rows of the globally touched set
+        with dp.phase("allreduce"):
+            dp.allreduce_tables_rows([small_gk, grad_buf], b.touched_rows, N, average=False)
+    else:
+        dp.allreduce_small_grads([gaussians._xyz.grad, gaussians._opacity.grad,
+                                  gaussians._scaling.grad, gaussians._rotation.grad], average=False)
+        dp.allreduce_rows(grad_buf, b.touched, average=False, rows=b.touched_rows)
+
+
+def _stage_optimizer(b):
+    """Stage 6: the small attributes' Adam step now; the SH rows' step now (eager modes) or deferred to their next touch."""
+    gaussians, args, N, bsz, step = b.gaussians, b.args, b.N, b.bsz, b.step
+    if b.use_packed:
+        gaussians.optimizer.gpu_step_packed(b.small_pk, b.small_gk, 1.0 / (bsz * dp.world_size()),
+                                            g_stamp=b.ft_stamp, cur_step=step,
+                                            row_range=dp.owner_range(N) if (b.small_owner and b.locality) else None)
+        if b.small_owner and b.locality:
             gaussians.small_after_step()
     else:
-        _gpu_adam_step(gaussians, args, touched if args.sparse_adam else None,
+        _gpu_adam_step(gaussians, args, b.touched if args.sparse_adam else None,
                        grad_div=bsz * dp.world_size())
         gaussians.invalidate_small_packed()
-    if lazy:
+    if b.lazy:
         # DEFERRED: the touched rows' Adam step of this batch is not run now.  Their (reduced) gradient
         # rows stay in the gradient table, stamped with this step, and catch_up_rows applies them -- at
         # this step, before the zero-gradient replays -- the next time a row is rendered / evaluated /
         # saved / densified: p, m, v of a row make one round trip per touch instead of two.
         # (index_fill_ takes the scalar as a kernel argument; `t[rows] = step` would copy a host scalar
         # to the device and block the host until the whole batch has drained)
-        stamp = touched_rows[owner.lo:owner.hi] if owner is not None else touched_rows
-        if stamp.numel() and ft_stamp is None:  # first-touch mode: the backward kernels stamped their rows
+        stamp = b.touched_rows[b.owner.lo:b.owner.hi] if b.owner is not None else b.touched_rows
+        if stamp.numel() and b.ft_stamp is None:  # first-touch mode: the backward kernels stamped their rows
             utils.fill_rows(gaussians._row_g_step, stamp.long(), step)
     elif not args.stop_update_param:
-        row_update(touched_rows)
-    st["step"] = step
-    if side_event is not None:
-        default_stream.wait_event(side_event)
+        _row_update(b, b.touched_rows)
+    b.st["step"] = step
+
+
+def _train_one_batch_hbm(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
+                         pipe_args, comm_stream, args):
+    """One batch with the SH rows and their optimizer state in HBM, in six stages (each a function above):
+    visibility -> plan -> exchange head (camera-DP: parameter rows in; deferred row steps of the rows rendered from)
+    -> cameras (software pipeline over three kernel-type streams) -> exchange tail (camera-DP: gradient lines home)
+    -> optimizer (small attributes now, SH rows deferred)."""
+    b = _Batch()
+    b.gaussians, b.scene, b.cameras, b.args = gaussians, scene, batched_cameras, args
+    b.parameters_grad_buffer, b.background, b.pipe_args, b.comm_stream = parameters_grad_buffer, background, pipe_args, comm_stream
+    b.bsz, b.N = len(batched_cameras), gaussians._xyz.shape[0]
+    b.fused = bool(getattr(args, "fused_front_end", True))
+    _stage_visibility(b)
+    _stage_plan(b)
+    _stage_exchange_head(b)
+    losses = _stage_cameras(b)
+    with dp.phase("tail_exchange"):  # (bench.py dp.phase_ms: what the exchange adds after the last backward)
+        _stage_exchange_tail(b)
+    if getattr(args, "debug_skip_optimizer", False):
+        # test hook: the batch ran exactly as in production (packed tables, lazy catch-up, DP exchange)
+        # but no optimizer consumes the accumulated gradients; they stay in parameters_grad_buffer[:N],
+        # the packed small-gradient table / the four .grad tensors, UNSCALED (sum over the cameras)
+        b.row_adam.global_step -= 1
+        if b.side_event is not None:
+            b.default_stream.wait_event(b.side_event)
+        return losses, b.ordered_cams, b.sparsity
+    _stage_optimizer(b)
+    if b.side_event is not None:
+        b.default_stream.wait_event(b.side_event)
     # No device synchronisation here: everything above is ordered on the default stream, so the
     # host can already prepare the next batch (its first host wait is the filter sizes) while the
     # optimizer kernels run; callers that read the losses synchronise by doing so.
     if getattr(args, "sync_each_batch", False):
         torch.cuda.synchronize()
-    return losses, ordered_cams, sparsity
+    return losses, b.ordered_cams, b.sparsity
 
 
 # ---------------------------------------------------------------------- host-resident

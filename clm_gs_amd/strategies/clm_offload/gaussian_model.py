@@ -381,7 +381,12 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             self._row_last_step[:n] = self.optimizer.cpu_adam.global_step
             self._row_g_step[:n] = 0
             return
+        # single rank: a pass over all N rows' stamps (3.5 ms at 28 M) -- skipped when no batch has run since the last
+        # flush (a densification calls this six times: clone, split, prune, re-sort, ...; `_lazy_dirty` is set by the engine)
+        if not getattr(self, "_lazy_dirty", True):
+            return
         self.catch_up_rows(None)
+        self._lazy_dirty = False
 
     # ---------------------------------------------------- deferred host row optimizer
     @property
@@ -593,32 +598,38 @@ class GaussianModelCLMOffload(BaseGaussianModel):
 
     def _regather_row_tables(self, idx, m):
         """Every [capacity,48] row table <- its rows idx[0..m) (int64, on the GPU), for pruning (ascending kept rows) and
-        re-ordering.  One HBM pass per table through a scratch table of the same capacity and the library's row mover
-        (clmgs_rows_gather: 64-bit row arithmetic, 16 B per lane), after which the scratch table IS the table and the
-        old one becomes the scratch: no temporary of the selected rows, no copy back.  (Rounds 1-3: torch advanced
-        indexing into a temporary + copy_ back, per table -- 60 ms per prune and 67 ms per re-sort at 28 M rows, and the
-        first densification of a run paid ~0.8 s of hipMalloc for the temporaries.)"""
+        re-ordering: one HBM pass per table with the library's row mover (clmgs_rows_gather: 64-bit row arithmetic, 16 B
+        per lane), and NO scratch table (round 5).  The gradient table holds nothing that is still needed when a
+        structural change happens -- every caller has applied the deferred steps (flush_lazy_rows: no gradient waits, all
+        stamps are reset), the eager modes leave it zeroed after every batch -- so it is the destination of the first
+        gather; every table then lands in the one vacated before it, and the last vacated table, zeroed, is the new
+        gradient table: 3 gathers + one clear instead of 4 gathers through a fifth table of the model's capacity
+        (5.6 GB at 28 M rows, which was the training run's peak)."""
         from ... import clm_kernels
-        cap = self.parameters_buffer.shape[0]
-        scr = getattr(self, "_row_scratch", None)
-        if scr is None or scr.shape[0] != cap:
-            scr = torch.empty((cap, 48), dtype=torch.float32, device=self.parameters_buffer.device)
         idx = idx.contiguous()
+        free = self.parameters_grad_buffer
         for attr in self._full_row_buffers():
+            if attr == "parameters_grad_buffer":
+                continue
             buf = getattr(self, attr)
+            assert buf.shape == free.shape
             if m:
-                clm_kernels._rows("clmgs_rows_gather", scr[:m], buf, None, idx, 0)
-            setattr(self, attr, scr)
-            scr = buf
-        self._row_scratch = scr
+                clm_kernels._rows("clmgs_rows_gather", free[:m], buf, None, idx, 0)
+            setattr(self, attr, free)
+            free = buf
+        free.zero_()
+        self.parameters_grad_buffer = free
         if self.moments_sharded:
             self._redistribute_moments(idx[:m], m)
 
     def drop_row_scratch(self):
-        """Hand the scratch table of _regather_row_tables back to the allocator (one table of the model's capacity)."""
+        """(Rounds 3-4 kept a scratch table of the model's capacity for _regather_row_tables; there is none any more.)"""
         self._row_scratch = None
 
-    def prune_points(self, mask):
+    def prune_points(self, mask, resort=False):
+        """Remove the rows of `mask`.  resort=True (HBM rows): the kept rows are ALSO put in Z-order of their positions by
+        the same single pass over every table -- exactly prune_points(mask) followed by spatial_sort() (same keys, same
+        stable sort), for the price of one compaction instead of a compaction and a permutation."""
         keep = ~mask
         n = self._parameters.shape[0]
         m = int(keep.sum())
@@ -634,15 +645,29 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             for attr in _ROW_BUFFERS:
                 buf = getattr(self, attr)
                 buf[:m].copy_(utils.select_rows(buf[:n], keep_rows))  # in-place compaction (clm/gaussian_model.py:566-570)
+            pick = lambda t: utils.select_rows(t, keep).contiguous()
         else:
-            self._regather_row_tables(torch.nonzero(keep).flatten(), m)
+            idx = torch.nonzero(keep).flatten()
+            if resort and m:
+                idx = utils.take_rows(idx, utils.morton_order(utils.take_rows(self._xyz.detach(), idx)))
+            self._regather_row_tables(idx, m)
+            pick = lambda t: utils.take_rows(t, idx).contiguous()
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
-            self._replace_gpu(name, attr, utils.select_rows(cur, keep).contiguous(), lambda s: utils.select_rows(s, keep).contiguous())
+            self._replace_gpu(name, attr, pick(cur), pick)
         self._rebind_row_state(m)
-        self.xyz_gradient_accum = utils.select_rows(self.xyz_gradient_accum, keep)
-        self.denom = utils.select_rows(self.denom, keep)
-        self.max_radii2D = utils.select_rows(self.max_radii2D, keep)
+        self.xyz_gradient_accum = pick(self.xyz_gradient_accum)
+        self.denom = pick(self.denom)
+        self.max_radii2D = pick(self.max_radii2D)
+        if self.sh_on_host and resort:
+            self.spatial_sort()
+        self.invalidate_small_packed()
+        self._sorted_tag = (self._xyz.data_ptr(), m) if resort else None
+
+    def spatial_sort(self):
+        if getattr(self, "_sorted_tag", None) == (self._xyz.data_ptr(), self._xyz.shape[0]):
+            return  # prune_points(resort=True) has just left the rows in this very order (the engine clears the tag)
+        super().spatial_sort()
 
     def permute_rows(self, order):
         n = self._parameters.shape[0]
@@ -658,7 +683,6 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                 buf[:n].copy_(utils.gather_rows(buf[:n], order_rows))  # out of place, one table at a time
         else:
             self._regather_row_tables(order.to(torch.int64), n)
-            self.drop_row_scratch()  # a re-sort ends a densification: steady-state memory stays what it was
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
             if self.optimizer is not None:

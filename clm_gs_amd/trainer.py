@@ -178,6 +178,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     spatial = bool(getattr(args, "spatial_row_order", True)) and hasattr(gaussians, "spatial_sort") and not naive
     if spatial:
         gaussians.spatial_sort()  # rows along a Z-order curve: a camera's rows become contiguous runs
+        # the prune that ends a densification re-sorts in the same pass over the row tables (clm_offload model, HBM rows)
+        gaussians.fuse_sort_into_prune = clm_hbm_only(args)
     # a full cyclic GC pass over torch's ~10^6 long-lived objects stalls the enqueueing thread for
     # ~100 ms: freeze what exists now, later collections only see what the loop allocates
     gc.collect()
@@ -208,6 +210,12 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     if locality:
         assert spatial, "dp_locality needs the Z-ordered row tables (spatial_row_order)"
         deal()
+    from . import _lib
+
+    def _check_device():
+        # the host has just synchronised: an asynchronous device fault / a timed-out pass of the profiling build's
+        # look-back binning route surfaces HERE, not at the end of the run with the model unsaved
+        _lib.check_device_errors()
     defer = bool(getattr(args, "defer_loss_log", True))
     loss_log = _LossLog(log_file, defer)
     pt = phase_times if phase_times is not None else {}
@@ -216,6 +224,13 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         pt[key] = pt.get(key, 0.0) + time.perf_counter() - t_start
     timer = End2endTimer()
     timer.start()
+    if clm_hbm_only(args) and getattr(args, "allocator_reservoir", True) and getattr(args, "fused_front_end", True):
+        # allocator warm-up, inside the clock: one block per stream pool instead of dozens of hipMalloc calls spread
+        # over the first batches and every densification (strategies/clm_offload/engine.py reserve_working_set)
+        from .strategies.clm_offload.engine import reserve_working_set
+        _t = time.perf_counter()
+        pt["reserved_bytes"] = float(sum(reserve_working_set(gaussians).values()))
+        _acc("reserve", _t)
     next_batch = None
     for iteration in range(1, iterations + 1, gbsz):
         utils.set_cur_iter(iteration)
@@ -262,6 +277,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         if any(iteration <= t < iteration + gbsz for t in test_iterations):
             loss_log.flush()
             timer.stop()  # evaluation is excluded from the throughput figure
+            _check_device()
             if hasattr(gaussians, "flush_lazy_rows"):  # deferred row steps (and, owner-computes DP, the exchange)
                 gaussians.flush_lazy_rows()
             evaluate("train", iteration, train_cameras, render_fn, log_file, max_images=5)
@@ -272,6 +288,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         _t = time.perf_counter()
         gsplat_densification(iteration, scene, gaussians, None)
         _acc("densify", _t)
+        if gaussians.get_xyz.shape[0] != n_before:
+            _check_device()  # (densify_and_prune read its counts back: the device is drained)
         if spatial and gaussians.get_xyz.shape[0] != n_before:
             _t = time.perf_counter()
             gaussians.spatial_sort()  # clones / splits were appended at the end of the tables
@@ -299,8 +317,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     loss_log.flush()
     timer.stop()
     _acc("final_sync", _t)
-    from . import _lib
-    _lib.check_device_errors()  # the binning chain's look-back kernels never timed out (raises otherwise)
+    _check_device()
     n_done = ((iterations - 1) // gbsz + 1) * gbsz + 1
     timer.print_time(log_file, n_done)
     log_file.write(memory_line(iteration, gbsz, gaussians, what="final"))

@@ -46,21 +46,19 @@ def default_args(**over):
         # this build: fused front-end kernels + no autograd tape inside the engines (fused.py);
         # False = the op-by-op gsplat/clm_kernels chain the reference engines spell out
         fused_front_end=True,
-        overlap_cameras=True, overlap_lanes=2, packed_small=True, packed_stats=True, exact_tile_cull=True,
-        front_ahead=False,  # True: camera k+1's projection + tile counting enqueued (2nd front stream) before the
-                            # host waits for camera k's count; measured -3 %: they then co-run with camera k's sort
-        pipeline_depth=1,  # cameras whose forward runs ahead of the oldest pending backward
+        overlap_cameras=True,  # False: one camera after the other on one stream (A/B, kernel timing); True: the pipeline
+        packed_small=True, packed_stats=True, exact_tile_cull=True,
         sync_each_batch=False,  # True: torch.cuda.synchronize() at the end of every batch
         dp_overlap=True,        # camera-DP locality exchange: split B / D so that they hide behind the first / last camera
         dp_shard_moments=True,  # camera-DP locality exchange (dense deferred row optimizer): m / v of the SH row table only for the owned row range
         dp_small_owner=True,    # ... and xyz / opacity / scaling / rotation stepped by the owner of a row range only (no step F)
         dp_small_refresh=8,     # ... batches between two all-gathers of the owned small-attribute ranges (bounds the staleness)
         dp_small_max_log_gain=0.7,  # ... or earlier, once the bound on the growth of a stale scale exceeds exp(this)
+        allocator_reservoir=True,  # trainer: one block per stream pool allocated and freed before the first batch
+                                   # (engine.reserve_working_set): the caching allocator splits it instead of calling hipMalloc
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
-        raster_reserve_cus=-1,  # CUs kept out of the alpha-blend stream's CU mask; -1: by visible rows per tile
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
-        flat_stream_priorities=False,
         host_speculative_prefetch=True,  # host-resident mode: stage the hinted next batch's untouched rows early
         device_side_counts=True,   # fused engine: consumers of a camera's intersection list read its length on the device
         isect_capacity_margin=1.25,  # ... from buffers sized (largest count seen at this image size) x margin

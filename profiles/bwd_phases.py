@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CLMGS_BWD_DEBUG"] = "3"
 import torch
 from clm_gs_amd import _lib
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-leg", "--no-trainer-leg", "--no-heavy-leg",
+            "--gt", "resident", "--prime-seconds", "0", "--scene", os.environ.get("CLMGS_PHASES_SCENE", "slab")]
 import bench
 L = _lib.lib()
 buf = (ctypes.c_ulonglong * 16)()
