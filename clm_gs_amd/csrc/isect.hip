@@ -8,7 +8,9 @@
 #include "common.h"
 #include "gs_math.h"
 #include "radix.h"
-#include "onesweep.h"
+#ifdef CLMGS_PROFILE_BUILD
+#include "onesweep.h"  // round 4's one-launch-per-digit passes by decoupled look-back: measured slower, profiling builds only
+#endif
 
 namespace clmgs {
 // Device error word of the look-back primitives (onesweep.h): bit 0 = scan look-back timed out, bit 1 = sort
@@ -35,20 +37,26 @@ static int os_rounds(const char* name, int dflt) {
   const int r = env_int(name, dflt);
   return (r == 1 || r == 2 || r == 4 || r == 8) ? r : dflt;
 }
-// Three routes through the binning chain, all producing the same lists element for element (CLMGS_BINNING, read per
-// call so that tests can switch inside one process):
-//   fused    (default) three kernels per radix digit with a multi-chunk histogram kernel and a segment-per-thread row
-//            scan; the two scans folded into their producers + ONE finishing launch each; the last tile-sort pass
-//            writes flatten_ids / emit_slot directly
+// Routes through the binning chain.  The PRODUCT library has ONE (BIN_FUSED):
+//   fused    three kernels per radix digit (multi-chunk histogram, segment-per-thread row scan, scatter); the two scans
+//            folded into their producers + ONE finishing launch each; the tile ids are produced chunk by chunk with
+//            coalesced stores by the kernel that also counts the first digit of the tile sort (isect2_emit_hist_kernel,
+//            round 5); the last tile-sort pass writes flatten_ids / emit_slot directly.
+// A profiling build (make PROFILE=1) can select the older ones per call with CLMGS_BINNING (the equality test of
+// tests/test_gpu_ops.py runs in that build); all produce the same lists element for element:
+//   r4       round 4's default: a thread-per-rank emit kernel (uncoalesced 4 + 8 B stores) + a separate histogram
 //   lookback round 4's single-launch passes by decoupled look-back (onesweep.h) -- measured SLOWER on MI355X (a sort
 //            pass of 3.3 M keys 60-79 us against 30 + 11 + 11 us, of 9.3 M keys 155-205 against 106 + 34 + 34;
-//            DESIGN.md section 3): kept as a tested alternative and as the evidence
+//            DESIGN.md section 3)
 //   legacy   the round-3 chain
-enum { BIN_FUSED = 0, BIN_LOOKBACK = 1, BIN_LEGACY = 2 };
+enum { BIN_FUSED = 0, BIN_LOOKBACK = 1, BIN_LEGACY = 2, BIN_R4 = 3 };
 static int binning_route() {
+#ifdef CLMGS_PROFILE_BUILD
   const char* e = getenv("CLMGS_BINNING");
   if (e && e[0] == 'l' && e[1] == 'o') return BIN_LOOKBACK;
   if (e && e[0] == 'l' && e[1] == 'e') return BIN_LEGACY;
+  if (e && e[0] == 'r' && e[1] == '4') return BIN_R4;
+#endif
   return BIN_FUSED;
 }
 static bool legacy_binning() { return binning_route() == BIN_LEGACY; }
@@ -360,6 +368,99 @@ isect2_emit_kernel(int V, const int32_t* __restrict__ order,
   }
 }
 
+// Round 5: the same list, produced CHUNK BY CHUNK.  Block b owns the entries [1024 b, 1024 (b+1)) of the unsorted
+// list (the chunking of the first tile-sort pass).  It finds the first rank reaching into its chunk with a 256-ary
+// search over `cum` (three dependent steps at 3 M ranks instead of 22), lets one thread per rank expand that rank's
+// tiles into LDS, and then (i) stores tile ids and payload with coalesced 4 / 8 B-per-lane stores -- the
+// thread-per-rank kernel above writes each rank's 2.8 entries at a different address, 112 MB at ~1 TB/s -- and (ii)
+// counts the chunk's first digit into the radix table, which is the whole first histogram launch of the tile sort.
+// Entry for entry the list of isect2_emit_kernel (same index = cum of the ranks before + the tile's place inside
+// the rank's box, same payload).  Capacity form: entries at or beyond min(capacity, *n_dev) do not exist.
+template <bool SLOTS>
+__global__ void __launch_bounds__(256)
+isect2_emit_hist_kernel(int V, int64_t n, const int64_t* __restrict__ n_dev, const int32_t* __restrict__ order,
+                        const unsigned long long* __restrict__ boxes, const int64_t* __restrict__ cum, int tile_w,
+                        const int64_t* __restrict__ row_cum, uint32_t* __restrict__ tkeys,
+                        int32_t* __restrict__ vals, int2* __restrict__ vals2, int n_blocks,
+                        uint32_t* __restrict__ table /*[256][n_blocks]*/) {
+  constexpr int CH = RS_MIN_CHUNK;
+  static_assert(CH == 1024, "four entries per thread below");
+  __shared__ uint32_t gkey[CH];
+  __shared__ int2 gval2[SLOTS ? CH : 1];
+  __shared__ int32_t gval[SLOTS ? 1 : CH];
+  __shared__ uint32_t h[256];
+  if (n_dev) n = min(n, *n_dev);
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  const int64_t E0 = (int64_t)blockIdx.x * CH;
+  if (E0 >= n) {  // (block-uniform) beyond the true count: an empty chunk, whose column of the table must still be zeros
+    table[(size_t)tid * n_blocks + blockIdx.x] = 0;
+    return;
+  }
+  const int64_t E1 = min(E0 + CH, n);
+  // j0 = first rank whose inclusive count exceeds E0 (it exists: E0 < n <= cum[V-1])
+  int lo = 0, hi = V;
+  for (;;) {
+    const int seg = (hi - lo + 255) / 256;
+    const int q = min(hi - 1, lo + (tid + 1) * seg - 1);  // last rank of this thread's segment
+    const int f = __syncthreads_count(cum[q] <= E0);      // segments entirely at or before E0
+    if (f == 256) { lo = hi; break; }
+    lo += f * seg;
+    hi = min(hi, lo + seg);
+    if (seg == 1) break;
+  }
+  for (int jb = lo; jb < V; jb += 256) {
+    const int j = jb + tid;
+    int64_t incl = 0, excl = 0;
+    if (j < V) { incl = cum[j]; excl = j ? cum[j - 1] : 0; }
+    if (j < V && incl > E0 && excl < E1 && incl > excl) {
+      const unsigned long long b = boxes[2 * (size_t)j], m = boxes[2 * (size_t)j + 1];
+      const int x0 = (int)(b & 0xFFFF), y0 = (int)((b >> 16) & 0xFFFF);
+      const int x1 = (int)((b >> 32) & 0xFFFF), y1 = (int)(b >> 48);
+      const int bw = x1 - x0, nt = bw * (y1 - y0);
+      const int i = order[j];
+      const int slot0 = (SLOTS && i > 0) ? (int)row_cum[i - 1] : 0;
+      const int k_lo = (int)max((int64_t)0, E0 - excl), k_hi = (int)min(incl - excl, E1 - excl);
+      const int li0 = (int)(excl - E0);  // LDS index of the rank's entry 0 (negative when the rank starts before the chunk)
+      if (nt > 64) {  // unmasked box: entry k is tile k
+        for (int k = k_lo; k < k_hi; ++k) {
+          const int ty = k / bw, tx = k - ty * bw;
+          gkey[li0 + k] = (uint32_t)((y0 + ty) * tile_w + x0 + tx);
+          if (SLOTS) gval2[li0 + k] = make_int2(i, slot0 + k); else gval[li0 + k] = i;
+        }
+      } else {        // entry k is the k-th set bit of the tile mask
+        unsigned long long mm = m & (nt == 64 ? ~0ull : ((1ull << nt) - 1ull));
+        for (int k = 0; mm && k < k_hi; ++k) {
+          const int t = __ffsll((long long)mm) - 1;
+          mm &= mm - 1ull;
+          if (k >= k_lo) {
+            const int ty = t / bw, tx = t - ty * bw;
+            gkey[li0 + k] = (uint32_t)((y0 + ty) * tile_w + x0 + tx);
+            if (SLOTS) gval2[li0 + k] = make_int2(i, slot0 + k); else gval[li0 + k] = i;
+          }
+        }
+      }
+    }
+    // the chunk is complete once the LAST rank of this round reaches E1 (only the lane holding it votes)
+    const bool more = (j == min(jb + 255, V - 1)) && incl < E1;
+    if (!__syncthreads_or(more)) break;
+  }
+  __syncthreads();
+  const int n_here = (int)(E1 - E0);
+#pragma unroll
+  for (int it = 0; it < CH / 256; ++it) {
+    const int li = it * 256 + tid;
+    if (li < n_here) {
+      const uint32_t key = gkey[li];
+      atomicAdd(&h[key & 0xFFu], 1u);
+      tkeys[E0 + li] = key;
+      if (SLOTS) vals2[E0 + li] = gval2[li]; else vals[E0 + li] = gval[li];
+    }
+  }
+  __syncthreads();
+  table[(size_t)tid * n_blocks + blockIdx.x] = h[tid];
+}
+
 // slot mode: the sorted (row id, emit index) pairs are split into flatten_ids / emit_slot here.
 __global__ void __launch_bounds__(256)
 isect2_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ tkeys, int n_tiles,
@@ -475,8 +576,11 @@ isect2_keys_lb_kernel(int V, const int32_t* __restrict__ radii, const float* __r
         carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
       }
       long long excl = 0;
+#ifdef CLMGS_PROFILE_BUILD
       if constexpr (LOOKBACK) excl = lb_chunk_prefix(status, chunk, carry, sh, err);
-      else if (tid == 0) block_tot[chunk] = carry;
+      else
+#endif
+      if (tid == 0) block_tot[chunk] = carry;
 #pragma unroll
       for (int r = 0; r < LBK_ROUNDS; ++r) {
         const int i = chunk * LBK_CHUNK + r * 256 + tid;
@@ -543,8 +647,11 @@ isect2_count_lb_kernel(int V, const int32_t* __restrict__ order,
       carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     long long excl = 0;
+#ifdef CLMGS_PROFILE_BUILD
     if constexpr (LOOKBACK) excl = lb_chunk_prefix(status, chunk, carry, sh, err);
-    else if (tid == 0) block_tot[chunk] = carry;
+    else
+#endif
+    if (tid == 0) block_tot[chunk] = carry;
 #pragma unroll
     for (int r = 0; r < LBK_ROUNDS; ++r) {
       const int j = chunk * LBK_CHUNK + r * 256 + tid;
@@ -662,10 +769,15 @@ scan_i64_finish_kernel(int n, int64_t* __restrict__ data, const int64_t* __restr
 
 // control block of clmgs_isect2_order_count: [4][256] digit counts | 16 ticket words | scan status of keys_lb | scan
 // status of count_lb | 4 x sort status
+#ifdef CLMGS_PROFILE_BUILD
 static inline size_t order_ctrl_bytes(int V) {
   return 4096 + 256 + 2 * align_up((size_t)lbk_chunks(V) * 8, 256) + 4 * os_status_bytes(V);
 }
 static inline size_t sort_ctrl_bytes(int64_t n) { return 4096 + 256 + 4 * os_status_bytes(n); }
+#else
+static inline size_t order_ctrl_bytes(int) { return 0; }
+static inline size_t sort_ctrl_bytes(int64_t) { return 0; }
+#endif
 
 }  // namespace clmgs
 
@@ -701,7 +813,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
   unsigned long long* box_by_row = (unsigned long long*)base; base += align_up((size_t)V * 16, 256);
   uint32_t* table = (uint32_t*)base; base += radix_table_bytes(V);
   int64_t* scan_tmp = (int64_t*)base;
-  if (binning_route() == BIN_FUSED) {
+  if (binning_route() == BIN_FUSED || binning_route() == BIN_R4) {
     int64_t* tot_a = scan_tmp;                      // chunk totals of the two scans
     int64_t* tot_b = scan_tmp + lbk_chunks(V);
     const int nck = lbk_chunks(V);
@@ -722,6 +834,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
     CLMGS_LAUNCH_CHECK();
     return 0;
   }
+#ifdef CLMGS_PROFILE_BUILD
   if (binning_route() == BIN_LOOKBACK) {
     // control block (zeroed by ONE memset): digit counts | tickets | scan status x 2 | sort status x 4
     char* ctrl = (char*)table;  // (the legacy routes' radix table + scan scratch: the temp size is the max of both)
@@ -755,6 +868,7 @@ extern "C" int clmgs_isect2_order_count(void* stream, int V, const float* means2
     CLMGS_LAUNCH_CHECK();
     return 0;
   }
+#endif
   const int grid = min(ceil_div(V, 256), 256 * 16);
   hipLaunchKernelGGL(isect2_keys_kernel, dim3(grid), dim3(256), 0, s, V, radii, depths, means2d,
                      (const float4*)packed, (float)tile_size, tile_width, tile_height, k_a, v_a,
@@ -791,8 +905,9 @@ static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const fl
   CLMGS_CHECK_ARG(V >= 0 && n_isects >= 0 && offsets);
   hipStream_t s = (hipStream_t)stream;
   const int n_tiles = tile_width * tile_height;
-  const bool lb = binning_route() == BIN_LOOKBACK && n_isects < ((int64_t)1 << 30);  // 30-bit counts in the look-back words
-  const bool fused = binning_route() == BIN_FUSED;
+  const int route = binning_route();
+  const bool lb = route == BIN_LOOKBACK && n_isects < ((int64_t)1 << 30);  // 30-bit counts in the look-back words
+  const bool fused = route == BIN_FUSED || route == BIN_R4;
   if (n_isects == 0 || (n_dev && !lb && !fused)) {  // device-count mode: a true count of 0 leaves no thread to write the offsets
     CLMGS_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
     if (n_isects == 0) return 0;
@@ -811,6 +926,7 @@ static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const fl
   const bool slots = emit_slot != nullptr;
   CLMGS_CHECK_ARG(!slots || row_cum);
   const int tile_bits = ilog2_floor((unsigned)n_tiles) + 1;
+#ifdef CLMGS_PROFILE_BUILD
   if (lb) {
     const int n_pass = (tile_bits + 7) / 8;
     char* ctrl = (char*)table;
@@ -853,21 +969,39 @@ static int isect2_emit_sort_impl(void* stream, int V, int64_t n_isects, const fl
     CLMGS_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
-                     order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
-                     slots ? (int2*)v_a : nullptr, row_cum, n_isects);
-  CLMGS_LAUNCH_CHECK();
+#endif
   uint32_t* sorted = nullptr;
   int rc;
+  const bool emit_hist = route == BIN_FUSED && tile_bits > 0;
+  if (emit_hist) {
+    // round 5: one block per 1024-entry chunk of the (unsorted) list expands the ranks that fall into it through LDS,
+    // stores tile ids + payload coalesced and leaves the chunk's first-digit counts in the radix table
+    const int n_blocks = (int)((n_isects + RS_MIN_CHUNK - 1) / RS_MIN_CHUNK);
+    if (slots)
+      hipLaunchKernelGGL((isect2_emit_hist_kernel<true>), dim3(n_blocks), dim3(256), 0, s, V, n_isects, n_dev, order,
+                         (const unsigned long long*)boxes, cum, tile_width, row_cum, k_a, (int32_t*)nullptr, (int2*)v_a,
+                         n_blocks, table);
+    else
+      hipLaunchKernelGGL((isect2_emit_hist_kernel<false>), dim3(n_blocks), dim3(256), 0, s, V, n_isects, n_dev, order,
+                         (const unsigned long long*)boxes, cum, tile_width, row_cum, k_a, (int32_t*)v_a, (int2*)nullptr,
+                         n_blocks, table);
+  } else {
+    hipLaunchKernelGGL(isect2_emit_kernel, dim3(min(ceil_div(V, 256), 256 * 16)), dim3(256), 0, s, V,
+                       order, (const unsigned long long*)boxes, cum, tile_width, k_a, (int32_t*)v_a,
+                       slots ? (int2*)v_a : nullptr, row_cum, n_isects);
+  }
+  CLMGS_LAUNCH_CHECK();
   if (fused) {
     // the last pass writes flatten_ids / emit_slot itself (no int2 list to split afterwards); the offsets kernel then
     // reads the sorted tile ids only and zero-fills the offsets itself when the true count is 0
     if (slots)
       rc = radix_sort_pairs_impl<uint32_t, int2, RS_DEFAULT_ITEMS>(s, n_isects, k_a, k_b, (int2*)v_a, (int2*)v_b, (int2*)nullptr,
-                                                                    0, tile_bits, table, &sorted, n_dev, flatten_ids, emit_slot);
+                                                                    0, tile_bits, table, &sorted, n_dev, flatten_ids, emit_slot,
+                                                                    true, emit_hist);
     else
-      rc = radix_sort_pairs<uint32_t, int32_t>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b, flatten_ids, 0,
-                                               tile_bits, table, &sorted, n_dev);
+      rc = radix_sort_pairs_impl<uint32_t, int32_t, RS_DEFAULT_ITEMS>(s, n_isects, k_a, k_b, (int32_t*)v_a, (int32_t*)v_b,
+                                                                       flatten_ids, 0, tile_bits, table, &sorted, n_dev,
+                                                                       nullptr, nullptr, true, emit_hist);
     if (rc) return rc;
     hipLaunchKernelGGL(isect2_offsets_lb_kernel, dim3(min(ceil_div(n_isects, 256), 256 * 16)), dim3(256), 0, s,
                        n_isects, sorted, n_tiles, offsets, flatten_ids, depths, isect_ids, n_dev);
@@ -1173,7 +1307,12 @@ visibility_emit_kernel(int C, int N, int W64, const unsigned long long* __restri
 
 extern "C" size_t clmgs_visibility_select_temp_bytes(int C, int N) {
   const size_t words = (size_t)(C + 1) * (size_t)((N + 63) / 64);
-  return 2 * align_up(words * 8, 256) + max(scan_scratch_bytes((int64_t)words), lb_scan_ctrl_bytes((int64_t)words)) + 256;
+#ifdef CLMGS_PROFILE_BUILD
+  const size_t ctrl = lb_scan_ctrl_bytes((int64_t)words);
+#else
+  const size_t ctrl = 0;
+#endif
+  return 2 * align_up(words * 8, 256) + max(scan_scratch_bytes((int64_t)words), ctrl) + 256;
 }
 
 extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const float* means,
@@ -1197,12 +1336,13 @@ extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const f
                      (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, bits, counts);
   CLMGS_LAUNCH_CHECK();
   int rc;
+#ifdef CLMGS_PROFILE_BUILD
   if (binning_route() == BIN_LOOKBACK) {  // one launch (decoupled look-back) + the memset of its control words
     CLMGS_HIP(hipMemsetAsync(scratch, 0, lb_scan_ctrl_bytes((int64_t)words), s));
     rc = lb_inclusive_scan_i64(s, (int64_t)words, counts, scratch);
-  } else {
-    rc = inclusive_scan_i64(s, (int64_t)words, counts, scratch);
-  }
+  } else
+#endif
+  rc = inclusive_scan_i64(s, (int64_t)words, counts, scratch);
   if (rc) return rc;
   // cum_totals[r] = number of set bits in rows 0..r (device array of C+1, read back by the caller)
   for (int r = 0; r <= C; ++r)

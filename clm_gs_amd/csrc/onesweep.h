@@ -91,23 +91,7 @@ __device__ __forceinline__ long long lb_chunk_prefix(unsigned long long* __restr
   return sh[0];
 }
 
-// Inclusive scan of 256 values (one per thread, thread order) -> inclusive result; *block_total (LDS) gets the sum.
-// `wsum` is 4 words of LDS.  Two barriers.
-__device__ __forceinline__ long long block_incl_scan_i64(long long v, long long* wsum) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  long long x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const long long y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
-  __syncthreads();  // wsum free (previous use)
-  if (lane == 63) wsum[wid] = x;
-  __syncthreads();
-  long long off = 0;
-  for (int w = 0; w < wid; ++w) off += wsum[w];
-  return x + off;
-}
+// (block_incl_scan_i64 lives in radix.h: the default route uses it too)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stand-alone single-launch inclusive scan of int64 data in place (visibility select).  Chunk = 2048 elements.

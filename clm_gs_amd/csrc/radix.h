@@ -283,7 +283,8 @@ template <typename KeyT, typename ValT, int ITEMS>
 static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, ValT* valsA,
                                  ValT* valsB, ValT* vals_final, int begin_bit, int end_bit,
                                  uint32_t* table, KeyT** keys_sorted, const int64_t* n_dev = nullptr,
-                                 int32_t* split_a = nullptr, int32_t* split_b = nullptr, bool round4 = true) {
+                                 int32_t* split_a = nullptr, int32_t* split_b = nullptr, bool round4 = true,
+                                 bool hist0_done = false) {
   constexpr int RS_CHUNK = RS_THREADS * ITEMS;
   const int passes = (end_bit - begin_bit + 7) / 8;
   const int n_blocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -300,8 +301,10 @@ static int radix_sort_pairs_impl(hipStream_t s, int64_t n, KeyT* keysA, KeyT* ke
     KeyT* kdst = (ksrc == keysA) ? keysB : keysA;
     ValT* vdst = (p == passes - 1) ? vals_final : ((vsrc == valsA) ? valsB : valsA);
     if (round4) {
-      hipLaunchKernelGGL((radix_hist_multi_kernel<KeyT, ITEMS>), dim3((n_blocks + RS_HIST_HB - 1) / RS_HIST_HB),
-                         dim3(RS_THREADS), 0, s, n, ksrc, shift, n_blocks, table, n_dev);
+      // hist0_done: the producer of the keys (isect2_emit_hist_kernel) has already left the first digit's counts in `table`
+      if (!(hist0_done && p == 0))
+        hipLaunchKernelGGL((radix_hist_multi_kernel<KeyT, ITEMS>), dim3((n_blocks + RS_HIST_HB - 1) / RS_HIST_HB),
+                           dim3(RS_THREADS), 0, s, n, ksrc, shift, n_blocks, table, n_dev);
       hipLaunchKernelGGL(radix_scan_rows_seg_kernel, dim3(256), dim3(RS_SCAN_THREADS), 0, s, n_blocks, table, row_tot);
     } else {
       hipLaunchKernelGGL((radix_hist_kernel<KeyT, ITEMS>), dim3(n_blocks), dim3(RS_THREADS), 0, s, n, ksrc, shift,
@@ -334,6 +337,24 @@ static int radix_sort_pairs(hipStream_t s, int64_t n, KeyT* keysA, KeyT* keysB, 
   return radix_sort_pairs_impl<KeyT, ValT, RS_DEFAULT_ITEMS>(s, n, keysA, keysB, valsA, valsB, vals_final,
                                                       begin_bit, end_bit, table, keys_sorted, n_dev, nullptr, nullptr,
                                                       round4);
+}
+
+// Inclusive scan of 256 values (one per thread, thread order) -> inclusive result; wsum[0..3] (LDS) get the four wave
+// totals.  Two barriers.
+__device__ __forceinline__ long long block_incl_scan_i64(long long v, long long* wsum) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  long long x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();  // wsum free (previous use)
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  long long off = 0;
+  for (int w = 0; w < wid; ++w) off += wsum[w];
+  return x + off;
 }
 
 // ------------------------------------------------------------- inclusive scan of int64

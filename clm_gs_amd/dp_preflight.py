@@ -145,8 +145,9 @@ def _tiny_locality_training(dist, torch, dev, rank, G):
     torch.cuda.synchronize()
     sums = torch.stack([t.detach().double().sum() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters)])
     _check(bool(torch.isfinite(sums).all()), "non-finite parameters after two locality batches")
-    allsums = torch.empty((G, sums.numel()), dtype=torch.float64, device=dev)
+    allsums = torch.empty((G * sums.numel(),), dtype=torch.float64, device=dev)  # (flat: gloo takes no [G, k] output)
     dist.all_gather_into_tensor(allsums, sums)
+    allsums = allsums.view(G, sums.numel())
     _check(bool((allsums == allsums[0:1]).all()), "replicas differ after two locality batches + flush")
     return [float(x) for x in sums.tolist()]
 

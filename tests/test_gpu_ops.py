@@ -710,19 +710,71 @@ def test_device_count_forms_equal_exact_forms(dev, slack):
     assert torch.equal(part2[:I], part[:I]) and bool((part2[I:] == 7.0).all())
 
 
+class _use_library:
+    """with _use_library(path): clm_gs_amd._lib serves the entry points of ANOTHER build of the library (the profiling
+    build, which can still walk the older routes of the binning chain: csrc/isect.hip binning_route)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        from clm_gs_amd import _lib
+        self.keep = (_lib._lib, _lib.LIB_PATH)
+        _lib._lib, _lib.LIB_PATH = None, self.path
+        return _lib.lib()
+
+    def __exit__(self, *exc):
+        from clm_gs_amd import _lib
+        _lib._lib, _lib.LIB_PATH = self.keep
+        return False
+
+
+def _profile_library():
+    import os
+    from clm_gs_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libclmgs_hip_prof.so")
+    if not os.path.exists(path):
+        pytest.skip("profiling build absent (make -C clm_gs_amd/csrc PROFILE=1 BUILD=build_prof OUT=../libclmgs_hip_prof.so; "
+                    "__graft_entry__.build() makes it)")
+    return path
+
+
+def _binning_lists(G, m2, radii, d, tw, th, n, pk, cap_slack, route=None):
+    """Every list the two binning calls produce, through whatever library clm_gs_amd._lib currently serves."""
+    import os
+    if route:
+        os.environ["CLMGS_BINNING"] = route
+    try:
+        c = G.isect2_begin(m2, radii, d, 16, tw, th, want_isect_ids=True, want_slots=True, packed=pk)
+        torch.cuda.synchronize()
+        tot = c.totals.clone()
+        res = [c.order[:n].clone(), c.cum[:n].clone(), c.boxes[:n].clone(), tot, c.row_cum[:n].clone()]
+        cap = None if cap_slack is None else max(1, int(int(tot[0]) * cap_slack))
+        fids, off, ids, (slot, _) = G.isect2_finish(c, capacity=cap)
+        torch.cuda.synchronize()
+        I = int(tot[0]) if cap is None else min(int(tot[0]), cap)
+        return res + [fids[:I].clone(), off.clone(), ids[:I].clone(), slot[:I].clone()]
+    finally:
+        os.environ.pop("CLMGS_BINNING", None)
+
+
+_LIST_NAMES = ("order", "cum", "boxes", "totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot")
+
+
 @pytest.mark.parametrize("n,wh", [(3000, (150, 101)), (180_000, (640, 480))])
 def test_single_launch_binning_equals_legacy_chain(dev, n, wh):
-    """Round 4: the default binning chain (CLMGS_BINNING=fused: scans folded into their producers + one finishing
-    launch, multi-chunk histograms, segment row scans, the last tile-sort pass writing flatten_ids / emit_slot itself) and
-    the look-back chain (CLMGS_BINNING=lookback, csrc/onesweep.h: one launch per radix digit -- measured slower, kept as
-    a tested alternative) == the round-3 chain (CLMGS_BINNING=legacy: three launches per digit and per scan), element for
-    element: depth order, both cumulative counts, boxes / masks, totals, flatten_ids, emit_slot, offsets, isect_ids --
-    exact form, device-count form, with and without exact tile culling; 180 000 rows / ~1 M intersections spread over
-    dozens of look-back tickets per kernel.  Also the visibility selection (its scan is a look-back kernel now)."""
-    import os
+    """The PRODUCT library's binning chain (round 5: scans folded into their producers, multi-chunk histograms, segment
+    row scans, the chunk-driven emit that also counts the first tile-sort digit, the last tile-sort pass writing
+    flatten_ids / emit_slot itself) == the round-3 chain (three launches per digit and per scan), element for element:
+    depth order, both cumulative counts, boxes / masks, totals, flatten_ids, emit_slot, offsets, isect_ids -- exact form,
+    device-count form (also with a capacity BELOW the count), with and without exact tile culling.  The older routes
+    live in the profiling build only (CLMGS_BINNING=legacy | lookback | r4, csrc/isect.hip): they are compared too --
+    r4 = round 4's thread-per-rank emit + separate histogram, lookback = one launch per radix digit (measured slower).
+    Also the visibility selection (look-back scan vs three-launch scan)."""
     from clm_gs_amd import _lib, gsplat as G
     from clm_gs_amd._lib import check, dptr, stream
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    prof = _profile_library()
     L = _lib.lib()
     w, h = wh
     tw, th = math.ceil(w / 16), math.ceil(h / 16)
@@ -741,43 +793,65 @@ def test_single_launch_binning_equals_legacy_chain(dev, n, wh):
     out, al, last = torch.empty((h, w, 3), device=dev), torch.empty((h, w), device=dev), torch.empty((h, w), dtype=torch.int32, device=dev)
     check(L.clmgs_rasterize_fwd(stream(), 1, n, fids0.numel(), dptr(m2), dptr(cn), dptr(colors), dptr(opac), None, w, h, 16, tw,
                                 th, dptr(off0), dptr(fids0), dptr(packed), dptr(out), dptr(al), dptr(last)))  # fills `packed`
-
-    def run(route, pk, cap_slack):
-        os.environ["CLMGS_BINNING"] = route
-        try:
-            c = G.isect2_begin(m2, radii, d, 16, tw, th, want_isect_ids=True, want_slots=True, packed=pk)
-            torch.cuda.synchronize()
-            tot = c.totals.clone()
-            res = [c.order[:n].clone(), c.cum[:n].clone(), c.boxes[:n].clone(), tot, c.row_cum[:n].clone()]
-            cap = None if cap_slack is None else max(1, int(int(tot[0]) * cap_slack))
-            fids, off, ids, (slot, _) = G.isect2_finish(c, capacity=cap)
-            torch.cuda.synchronize()
-            I = int(tot[0])
-            return res + [fids[:I].clone(), off.clone(), ids[:I].clone(), slot[:I].clone()]
-        finally:
-            os.environ.pop("CLMGS_BINNING", None)
-
-    names = ("order", "cum", "boxes", "totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot")
     for pk in (None, packed):
-        ref = run("legacy", pk, None)
-        assert int(ref[3][0]) > (100_000 if n > 100_000 else 100)
-        for route in ("fused", "lookback"):
-            for slack in (None, 1.0, 1.3):
-                got = run(route, pk, slack)
-                for nm, a, b in zip(names, got, ref):
-                    assert torch.equal(a, b), (route, nm, pk is not None, slack)
+        with _use_library(prof):
+            ref = {sl: _binning_lists(G, m2, radii, d, tw, th, n, pk, sl, "legacy") for sl in (None, 0.6)}
+        assert int(ref[None][3][0]) > (100_000 if n > 100_000 else 100)
+        for slack in (None, 1.0, 1.3, 0.6):
+            want = ref[0.6] if slack == 0.6 else ref[None]
+            got = _binning_lists(G, m2, radii, d, tw, th, n, pk, slack)  # the product library
+            for nm, a, b in zip(_LIST_NAMES, got, want):
+                assert torch.equal(a, b), ("product", nm, pk is not None, slack)
+            with _use_library(prof):
+                for route in ("fused", "r4", "lookback"):
+                    got = _binning_lists(G, m2, radii, d, tw, th, n, pk, slack, route)
+                    for nm, a, b in zip(_LIST_NAMES, got, want):
+                        assert torch.equal(a, b), (route, nm, pk is not None, slack)
     # visibility selection through the look-back scan == through the three-launch scan
     cams = nadir_cameras(3, n, w, h, 0.4, seed=5, device="cuda")
     Ks = torch.stack([c.K for c in cams])
     vms = torch.stack([c.world_view_transform.t() for c in cams])
-    os.environ["CLMGS_BINNING"] = "lookback"
-    try:
-        f_ref, u_ref = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
-    finally:
-        os.environ.pop("CLMGS_BINNING", None)
+    import os
+    with _use_library(prof):
+        os.environ["CLMGS_BINNING"] = "lookback"
+        try:
+            f_ref, u_ref = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
+        finally:
+            os.environ.pop("CLMGS_BINNING", None)
+        _lib.check_device_errors()
     f_new, u_new = G.visibility_select(sc["xyz"], sc["rotation"], sc["scaling"], vms, Ks, w, h)
     assert torch.equal(u_new, u_ref) and all(torch.equal(a, b) for a, b in zip(f_new, f_ref))
     _lib.check_device_errors()
+
+
+def test_chunked_emit_with_boxes_spanning_many_chunks(dev):
+    """The chunk-driven emit (isect2_emit_hist_kernel: one block per 1024 entries of the list) on what a thread-per-rank
+    emit never had to think about: rows whose box covers the WHOLE image (1 200 tiles = more than a chunk, unmasked),
+    long runs of culled rows and of rows outside the image (ranks that emit nothing, in the middle of the depth
+    order), exact depth ties, a list that ends in the middle of a chunk, and capacities that cut a rank in two -- against
+    the round-3 chain of the profiling build, element for element."""
+    from clm_gs_amd import gsplat as G
+    prof = _profile_library()
+    n, w, h = 60_000, 640, 480
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    g = torch.Generator().manual_seed(3)
+    m2 = (torch.rand(1, n, 2, generator=g) * torch.tensor([w * 1.4, h * 1.4]) - torch.tensor([w * 0.2, h * 0.2])).to(dev)
+    radii = torch.randint(1, 40, (1, n), generator=g, dtype=torch.int32)
+    radii[0, torch.randperm(n, generator=g)[:40]] = 3000       # the whole image
+    radii[0, torch.randperm(n, generator=g)[: n // 5]] = 0      # culled rows (sorted last)
+    radii[0, 1000:9000] = torch.where(torch.rand(8000, generator=g) < 0.9, torch.zeros(8000, dtype=torch.int32), radii[0, 1000:9000])
+    radii = radii.to(dev)
+    d = (torch.rand(1, n, generator=g) * 50 + 1).to(dev)
+    d[0, :2000] = 7.0
+    m2[0, 20000:26000] = torch.tensor([-500.0, -500.0], device=dev)  # boxes clipped to nothing: ranks with zero entries
+    for slack in (None, 1.0, 0.37, 0.9991):
+        with _use_library(prof):
+            want = _binning_lists(G, m2, radii, d, tw, th, n, None, slack, "legacy")
+            r4 = _binning_lists(G, m2, radii, d, tw, th, n, None, slack, "r4")
+        got = _binning_lists(G, m2, radii, d, tw, th, n, None, slack)
+        assert int(want[3][0]) > 40 * tw * th
+        for nm, a, b, c in zip(_LIST_NAMES, got, want, r4):
+            assert torch.equal(a, b) and torch.equal(c, b), (nm, slack)
 
 
 @pytest.mark.parametrize("bsz", [4, 8, 32, 64])
