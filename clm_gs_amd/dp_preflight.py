@@ -233,6 +233,8 @@ def run(rank, world, backend, device, workdir, timeout_s=150.0):
               "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
               "CLMGS_DP_FORCE"):
         env.pop(k, None)  # the children rendezvous through the file store only
+    if world == 1:
+        env["CLMGS_DP_FORCE"] = "1"  # a one-rank group runs every collective as the identity (tests: RCCL on a 1-GPU box)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")

@@ -262,9 +262,10 @@ def reserve_working_set(gaussians, n_cameras_in_flight=2):
         "front": (sts["mem"][0], k * (20 * P + 56 * I + 96 * V)),      # image / alpha / last ids, lists + sort space, records
         "mem": (sts["mem"][1], k * 48 * P + (1 << 20)),                 # SSIM derivative maps + the loss cotangent
         "raster": (sts["raster"][0], k * 64 * I),                       # one partial-gradient line per intersection
-        # default stream: filters and touched-row lists of a batch, and the temporaries of a densification (masks,
-        # selections and the re-created per-row tensors: ~160 B per row)
-        "default": (torch.cuda.current_stream(), 160 * N + 64 * V * 4),
+        # default stream: filters and touched-row lists of a batch, and the temporaries of a densification -- masks,
+        # selections, the Z-order keys and their sort, and the per-row tensors (parameters + moments 132 B, packed mirror /
+        # gradient / statistics tables 112 B per row), which are re-created BEFORE their predecessors are freed
+        "default": (torch.cuda.current_stream(), 320 * N + 64 * V * 4),
     }
     out = {}
     for name, (st, nbytes) in plan.items():

@@ -56,3 +56,14 @@ def test_bench_under_torchrun_world1_uses_rccl(dev):
     assert len(lines) == 1, out[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["dist_backend"] == "nccl"
+
+
+def test_preflight_child_runs_on_rccl_with_one_rank(dev):
+    """The camera-DP pre-flight (clm_gs_amd/dp_preflight.py) on the REAL backend: a one-rank RCCL group (file-store
+    rendezvous, device binding, the collectives as identities on the backend's own stream, the side-stream overlap of the
+    tiny locality batches) -- everything about the first multi-GPU contact that a one-GPU box can exercise."""
+    import tempfile
+    from clm_gs_amd import dp_preflight
+    rep = dp_preflight.run(0, 1, "nccl", 0, tempfile.mkdtemp(prefix="clmgs_pf_nccl_"), 240.0)
+    assert rep["ok"], rep
+    assert set(rep["stages_s"]) == {"raw_collectives", "exchange_on_seeded_table", "tiny_locality_training"}, rep
