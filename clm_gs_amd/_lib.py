@@ -75,6 +75,9 @@ SIGNATURES = {
     "clmgs_visibility_candidates": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _vp]),
     "clmgs_small_rows_scatter": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_adam_small_packed_range": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f, _vp, _i]),
+    "clmgs_small_deferred_kmax": (_i, []),
+    "clmgs_adam_small_deferred": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _d,
+                                       _f, _i, _vp, _vp, _i, _i, _f, _f, _f, _i]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_device_errors": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),
@@ -117,7 +120,7 @@ class _Namespace:
     pass
 
 
-_NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
+_NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_small_deferred_kmax", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
               "clmgs_isect_sort_temp_bytes", "clmgs_host_groups_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_usable_cpus", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters", "clmgs_device_errors"}
 

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "vis_math.h"
 #include "radix.h"
 
 namespace clmgs {
@@ -552,6 +553,140 @@ adam_small_packed_kernel(int64_t n, int64_t row_begin, int64_t row_end, SmallAda
   }
 }
 
+// DEFERRED dense Adam of the 11 GPU-resident attributes (single GPU, round 5).  The eager pass above streams p / m / v of
+// all N rows every batch (312 B x N) although a batch gives a gradient to a third of them, because a row without a
+// gradient still moves (its first moment decays); and it cannot simply be postponed, because the next batch's visibility
+// pass reads every row's position.  What CAN be postponed is the step of rows that provably stay invisible: rows are kept
+// in Z-order, a block of 256 consecutive rows is a patch of ground, and Adam moves no element by more than
+// 7.28 lr per step whatever its gradients (gaussian_model.py small_after_step).  Per block: `blk_last` = the optimizer
+// step its 256 rows are current as of.  At the HEAD of a batch every block that is k = to_step - blk_last steps behind
+// runs the cull's own conservative test (vis_candidate) on its STALE values with the margins k steps allow; only if some
+// row may be visible in some camera of the batch -- or k has reached SD_KMAX, or the caller flushes -- are the block's k
+// steps replayed: step by step in registers, the row's waiting gradient line (stamp g_stamp[row] == s) entering at ITS
+// step, zero gradients at the others, every step with the constants (learning rates, bias corrections) it had -- the
+// operations of k eager passes in the same order, element for element (adam_elem with g = 0 is what the eager pass
+// computes for a row without a gradient).  The exact visibility pass that follows sees current values in every block
+// that can matter: a row of a skipped block fails the exact cull with its stale values (the candidate test contains it)
+// and with its true ones (margins), so the filters are the eager run's, bit for bit.
+constexpr int SD_KMAX = 16;
+struct SmallDeferred {
+  // index j = to_step - s of optimizer step s (0 = the newest)
+  float lr[SD_KMAX][4];
+  float inv_bc1[SD_KMAX], inv_sqrt_bc2[SD_KMAX];
+  // index k = number of steps a block is behind: how far a stale mean may be off / a stale largest scale may have grown
+  float pos_margin[SD_KMAX + 1], scale_gain[SD_KMAX + 1];
+  int to_step;
+};
+
+__global__ void __launch_bounds__(SA_ROWS)
+adam_small_deferred_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p, const float4* __restrict__ packed_g,
+                           const int32_t* __restrict__ g_stamp, int32_t* __restrict__ blk_last, SmallDeferred d,
+                           float beta1, float beta2, float ob1, float ob2, float eps, float grad_scale, int C,
+                           const float* __restrict__ viewmats, const float* __restrict__ Ks, float W, float H, float eps2d,
+                           float near_plane, float far_plane, int flush_all) {
+  __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
+  __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
+  __shared__ int gstep_s[SA_ROWS];
+  __shared__ float cam_s[VB_MAX_CAMS][VB_CAM_F];
+  const int tid = threadIdx.x;
+  if (!flush_all) {
+    for (int c = tid; c < C; c += SA_ROWS) vis_store_cam(cam_s[c], viewmats + 16 * c, Ks + 9 * c, W, H);
+  }
+  const float near_m = near_plane - (fabsf(near_plane) * 1e-5f + 1e-6f);
+  const float far_m = far_plane + fabsf(far_plane) * 1e-5f;
+  const int64_t n_blocks = (n + SA_ROWS - 1) / SA_ROWS;
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int last = blk_last[blk];
+    const int k = d.to_step - last;
+    if (k <= 0) continue;  // (block-uniform)
+    const int64_t row0 = blk * SA_ROWS;
+    const int rows = (int)min((int64_t)SA_ROWS, n - row0);
+    __syncthreads();  // cam_s written / the previous block's LDS consumed
+    if (!flush_all && k < SD_KMAX) {
+      bool cand = false;
+      if (tid < rows) {
+        const float* x = t.p[0] + 3 * (row0 + tid);
+        const float* ls = t.p[2] + 3 * (row0 + tid);
+        const float m[3] = {x[0], x[1], x[2]};
+        const float sgn = __expf(fmaxf(ls[0], fmaxf(ls[1], ls[2]))) * d.scale_gain[k];
+        const float smax2g = sgn * sgn;
+        cand = !(smax2g < 1e30f);  // NaN / overflowing scales: current values decide
+        for (int c = 0; c < C && !cand; ++c)
+          cand = vis_candidate(lds_cam(cam_s[c]), cam_s[c][16], m, smax2g, d.pos_margin[k], W, H, eps2d, near_m, far_m);
+      }
+      if (!__syncthreads_or(cand)) continue;
+    }
+    // ---- the block's k waiting steps.  Gradient lines: a row's line belongs to step g_stamp[row]; it is waiting iff
+    // last < stamp <= to_step (consumed lines keep their old stamp: first-touch producers never clear)
+    if (tid < rows) {
+      const int gs = g_stamp[row0 + tid];
+      gstep_s[tid] = (gs > last && gs <= d.to_step) ? gs : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * 3; i += SA_ROWS)
+      reinterpret_cast<float4*>(sg)[i] = gstep_s[i / 3] >= 0 ? packed_g[row0 * 3 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < rows) sp[tid * 12 + 11] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int w = ti == 0 ? 3 : (ti == 1 ? 1 : (ti == 2 ? 3 : 4));
+      const int co = ti == 0 ? 0 : (ti == 1 ? 3 : (ti == 2 ? 4 : 7));
+      const int n_el = rows * w;
+      float* P = t.p[ti] + row0 * w;
+      float* M = t.m[ti] + row0 * w;
+      float* V = t.v[ti] + row0 * w;
+      for (int i = tid * 4; i < n_el; i += SA_ROWS * 4) {
+        if (i + 3 < n_el) {
+          float4 p4 = *reinterpret_cast<float4*>(P + i), m4 = *reinterpret_cast<float4*>(M + i),
+                 v4 = *reinterpret_cast<float4*>(V + i);
+          float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+                vv[4] = {v4.x, v4.y, v4.z, v4.w};
+          float gg[4];
+          int gst[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = i + q, row = idx / w, e = idx - row * w;
+            gg[q] = sg[row * 12 + co + e] * grad_scale;
+            gst[q] = gstep_s[row];
+          }
+          for (int s_ = last + 1; s_ <= d.to_step; ++s_) {
+            const int j = d.to_step - s_;
+            const float lr_bc = d.lr[j][ti] * d.inv_bc1[j];
+            const float isb2 = d.inv_sqrt_bc2[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              pp[q] = adam_elem(mm[q], vv[q], pp[q], gst[q] == s_ ? gg[q] : 0.f, lr_bc, beta1, beta2, ob1, ob2, eps, isb2);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = i + q, row = idx / w, e = idx - row * w;
+            sp[row * 12 + co + e] = pp[q];
+          }
+          *reinterpret_cast<float4*>(P + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+          *reinterpret_cast<float4*>(M + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+          *reinterpret_cast<float4*>(V + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+          for (int idx = i; idx < n_el; ++idx) {  // ragged tail of the last block
+            const int row = idx / w, e = idx - row * w;
+            float mm = M[idx], vv = V[idx], pq = P[idx];
+            const float g1 = sg[row * 12 + co + e] * grad_scale;
+            for (int s_ = last + 1; s_ <= d.to_step; ++s_) {
+              const int j = d.to_step - s_;
+              pq = adam_elem(mm, vv, pq, gstep_s[row] == s_ ? g1 : 0.f, d.lr[j][ti] * d.inv_bc1[j], beta1, beta2, ob1, ob2,
+                             eps, d.inv_sqrt_bc2[j]);
+            }
+            P[idx] = pq; M[idx] = mm; V[idx] = vv;
+            sp[row * 12 + co + e] = pq;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * 3; i += SA_ROWS) packed_p[row0 * 3 + i] = reinterpret_cast<const float4*>(sp)[i];
+    if (tid == 0) blk_last[blk] = d.to_step;
+  }
+}
+
 // [N,12] mirror from the four parameter tensors
 __global__ void __launch_bounds__(256)
 pack_small_kernel(int64_t n, const float* __restrict__ xyz, const float* __restrict__ opa,
@@ -871,6 +1006,55 @@ extern "C" int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t ro
                        (hipStream_t)stream, n, (int64_t)0, n, t, (float4*)packed_p, (float4*)packed_g, (float)beta1,
                        (float)beta2, ob1, ob2, (float)eps, inv_bc1, inv_sqrt_bc2, grad_scale, g_stamp, cur_step);
   }
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clmgs_small_deferred_kmax(void) { return SD_KMAX; }
+
+// See adam_small_deferred_kernel.  n_hist <= clmgs_small_deferred_kmax() optimizer steps of history, newest first
+// (entry j describes step to_step - j): lr4_hist[j][4], step_index[j] (the Adam step count of that step, for the bias
+// corrections), and how far a block that is k steps behind may be off: pos_margin[k], scale_gain[k], k = 0 .. n_hist.
+// blk_last[ceil(n / 256)]: the step every block of 256 rows is current as of (updated here).  flush_all != 0: every
+// block is brought to to_step (no camera needed).  Blocks more than n_hist steps behind are an error of the caller
+// (it must flush at least every n_hist steps): checked on the host side by construction (a block is never left
+// behind for kmax steps: the kernel forces it at k == kmax - 1 ... see the caller), not here.
+extern "C" int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* params, float* const* exp_avg,
+                                         float* const* exp_avg_sq, void* packed_p, const void* packed_g,
+                                         const int32_t* g_stamp, int32_t* blk_last, int to_step, int n_hist,
+                                         const double* lr4_hist, const int32_t* step_index, const float* pos_margin,
+                                         const float* scale_gain, double beta1, double beta2, double eps,
+                                         float grad_scale, int C, const float* viewmats, const float* Ks, int width,
+                                         int height, float eps2d, float near_plane, float far_plane, int flush_all) {
+  CLMGS_CHECK_ARG(n >= 0 && to_step >= 0 && n_hist >= 0 && n_hist <= SD_KMAX);
+  if (n == 0 || n_hist == 0) return 0;
+  CLMGS_CHECK_ARG(params && exp_avg && exp_avg_sq && packed_p && packed_g && g_stamp && blk_last && lr4_hist &&
+                  step_index && pos_margin && scale_gain && (((uintptr_t)packed_p | (uintptr_t)packed_g) & 15) == 0);
+  CLMGS_CHECK_ARG(flush_all || (C >= 1 && C <= VB_MAX_CAMS && viewmats && Ks && width > 0 && height > 0));
+  SmallAdam t;
+  for (int i = 0; i < 4; ++i) {
+    CLMGS_CHECK_ARG(params[i] && exp_avg[i] && exp_avg_sq[i]);
+    t.p[i] = params[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.lr[i] = 0.f;
+  }
+  SmallDeferred d;
+  for (int j = 0; j < SD_KMAX; ++j) {
+    const int jj = j < n_hist ? j : n_hist - 1;
+    for (int i = 0; i < 4; ++i) d.lr[j][i] = (float)lr4_hist[4 * jj + i];
+    CLMGS_CHECK_ARG(step_index[jj] >= 1);
+    d.inv_bc1[j] = (float)(1.0 / (1.0 - pow(beta1, (double)step_index[jj])));       // as clmgs_adam_small_packed_range
+    d.inv_sqrt_bc2[j] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step_index[jj])));
+  }
+  for (int k = 0; k <= SD_KMAX; ++k) {
+    const int kk = k <= n_hist ? k : n_hist;
+    d.pos_margin[k] = pos_margin[kk];
+    d.scale_gain[k] = scale_gain[kk];
+  }
+  d.to_step = to_step;
+  const float ob1 = (float)(1.0 - beta1), ob2 = (float)(1.0 - beta2);
+  hipLaunchKernelGGL(adam_small_deferred_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
+                     (hipStream_t)stream, n, t, (float4*)packed_p, (const float4*)packed_g, g_stamp, blk_last, d,
+                     (float)beta1, (float)beta2, ob1, ob2, (float)eps, grad_scale, C, viewmats, Ks, (float)width,
+                     (float)height, eps2d, near_plane, far_plane, flush_all);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -292,6 +292,13 @@ def _stage_visibility(b):
     if b.small_owner:
         with torch.no_grad(), _lib.host_region("dp_small_fetch"), dp.phase("S"):
             gaussians.small_prepare(cams)
+    # single GPU, small attributes stepped per block (gaussian_model.small_deferred): the blocks this batch's cameras may
+    # see are brought up to date BEFORE the visibility pass reads them
+    b.small_deferred = bool(getattr(gaussians, "small_deferred", False) and b.fused and gaussians.lazy_rows
+                            and not args.stop_update_param and getattr(args, "packed_small", True))
+    if b.small_deferred:
+        with torch.no_grad():
+            gaussians.small_catch_up(cams)
     with torch.no_grad():
         if b.fused:
             # same fast exp as the fused front end -> filter and render agree on every cull;
@@ -615,7 +622,11 @@ def _stage_exchange_tail(b):
 def _stage_optimizer(b):
     """Stage 6: the small attributes' Adam step now; the SH rows' step now (eager modes) or deferred to their next touch."""
     gaussians, args, N, bsz, step = b.gaussians, b.args, b.N, b.bsz, b.step
-    if b.use_packed:
+    if b.use_packed and b.small_deferred and b.ft_stamp is not None and not dp.active():
+        gaussians.small_defer_record(step)  # applied block by block when a camera comes near (small_catch_up)
+    elif b.use_packed:
+        if getattr(gaussians, "small_deferred", False):
+            gaussians.flush_small()  # (a batch in another mode: nothing may wait across it)
         gaussians.optimizer.gpu_step_packed(b.small_pk, b.small_gk, 1.0 / (bsz * dp.world_size()),
                                             g_stamp=b.ft_stamp, cur_step=step,
                                             row_range=dp.owner_range(N) if (b.small_owner and b.locality) else None)
@@ -1075,6 +1086,8 @@ def clm_offload_eval_one_cam(camera, gaussians, background, scene):
                           and (getattr(a_, "dp_owner_computes", False) or getattr(a_, "dp_locality", False)))
         if dp_partial:  # before the filter: with small_owner the positions of foreign rows are stale until then
             gaussians.flush_lazy_rows()  # collective (no-op unless a batch ran since the last flush)
+        if getattr(gaussians, "small_deferred", False):
+            gaussians.flush_small()  # single GPU: the small attributes' waiting steps, before anything reads them
         filters, _, _ = calculate_filters([camera], gaussians.get_xyz, gaussians.get_opacity,
                                           gaussians.get_scaling, gaussians.get_rotation)
         f = filters[0]

@@ -109,6 +109,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                                  and getattr(a, "dp_small_owner", True) and getattr(a, "fused_front_end", True)
                                  and getattr(a, "packed_small", True))
         self._small_since, self._small_drift = 0, [0.0, 0.0]  # batches since all copies were current; drift bounds
+        # single GPU: the dense Adam of the small attributes deferred per block of 256 Z-ordered rows (small_deferred)
+        self._small_def = None
+        if ((not self.sh_on_host) and (not a.sparse_adam) and getattr(a, "lazy_dense_adam", True) and not dp.active()
+                and getattr(a, "deferred_small_adam", True) and getattr(a, "fused_front_end", True)
+                and getattr(a, "packed_small", True) and getattr(a, "first_touch_grads", True)
+                and not a.stop_update_param):
+            self._small_def = {"hist": [], "blk_last": None, "n": -1}
         m_cap, m_n = cap, n
         if self._mom_sharded:
             lo, hi = dp.owner_range(n)
@@ -279,6 +286,131 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self._small_drift[1] += c * float(groups["scaling"]["lr"])
         self._small_since += 1
 
+    # ---------------------------------------------------- single GPU: small attributes stepped per block, when needed
+    @property
+    def small_deferred(self):
+        """Single GPU, dense optimizer (default): xyz / opacity / scaling / rotation are not stepped at the end of every
+        batch.  A batch only RECORDS its step (learning rates, bias-correction index: small_defer_record); the gradient
+        lines stay in the packed gradient table under their first-touch stamps.  At the head of the next batch
+        (small_catch_up) every block of 256 consecutive rows that may hold a row visible in one of the batch's cameras
+        -- by the cull's own conservative test on its stale values, dilated by what Adam can have moved them in the
+        waiting steps -- replays its waiting steps exactly (clmgs_adam_small_deferred); blocks nobody looks at wait, at
+        most clmgs_small_deferred_kmax() steps.  The exact visibility pass, the render and every gradient are the eager
+        run's, bit for bit; what changes is that a batch streams p / m / v of the blocks near its cameras instead of
+        all N rows.  Readers of the four tensors outside a batch go through flush_lazy_rows() (densification, opacity
+        reset, evaluation, saving, capture: all do)."""
+        return getattr(self, "_small_def", None) is not None
+
+    def _small_def_tables(self):
+        sd = self._small_def
+        n = self._xyz.shape[0]
+        if sd["blk_last"] is None or sd["n"] != n:
+            assert not sd["hist"] or sd["n"] == -1 or self._small_def_clean(), "row count changed with small-attribute steps waiting"
+            to = sd["hist"][-1][0] if sd["hist"] else 0
+            sd["blk_last"] = torch.full(((n + 255) // 256,), int(to), dtype=torch.int32, device=self._xyz.device)
+            sd["n"] = n
+        return sd["blk_last"]
+
+    def _small_def_clean(self):
+        return not getattr(self, "_small_def_dirty", False)
+
+    def small_defer_record(self, step):
+        """End of a batch: optimizer step `step` (the row optimizer's numbering = the stamps of the gradient lines) of the
+        small attributes is RECORDED with the constants it must be replayed with."""
+        import math
+        sd = self._small_def
+        opt = self.optimizer
+        groups = {g["name"]: g for g in opt.gpu_adam.param_groups}
+        order = [groups[n_] for n_ in ("xyz", "opacity", "scaling", "rotation")]
+        cache = opt.__dict__.setdefault("_gpu_steps", {})
+        steps, idx = [], None
+        for g in order:
+            p = g["params"][0]
+            st = opt.gpu_adam.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if id(st["step"]) not in cache:
+                cache.clear() if len(cache) > 64 else None
+                cache[id(st["step"])] = int(st["step"].item())
+            cache[id(st["step"])] += 1
+            idx = cache[id(st["step"])] if idx is None else idx
+            assert cache[id(st["step"])] == idx, "the four groups step together"
+            steps.append(st["step"])
+        torch._foreach_add_(steps, 1)  # torch-Adam's own step counters stay what an eager run leaves (capture / restore)
+        opt.state = opt.gpu_adam.state | opt.cpu_adam.state
+        if sd["hist"] and sd["hist"][-1][0] != step - 1:
+            self.flush_small()  # a gap in the step numbering (a batch ran in another mode): nothing may span it
+            sd["hist"] = []
+            sd["blk_last"] = None
+        self._small_def_tables()
+        b1, b2 = order[0]["betas"]
+        c = (1.0 - b1) / math.sqrt(1.0 - b2) / math.sqrt(1.0 - b1 * b1 / b2) * 1.001  # Adam's step bound / lr (small_after_step)
+        sd["hist"].append((int(step), [float(g["lr"]) for g in order], int(idx), c * float(order[0]["lr"]),
+                           c * float(order[2]["lr"])))
+        kmax = self._small_kmax()
+        if len(sd["hist"]) > kmax:
+            del sd["hist"][:len(sd["hist"]) - kmax]
+        self._small_def_dirty = True
+
+    def _small_kmax(self):
+        k = getattr(self, "_small_kmax_v", None)
+        if k is None:
+            from ... import _lib
+            k = self._small_kmax_v = int(_lib.lib().clmgs_small_deferred_kmax())
+        return k
+
+    def small_catch_up(self, cameras=None):
+        """Head of a batch (cameras given) or a flush (None): see small_deferred."""
+        import ctypes
+        import math
+        from ... import _lib
+        sd = self._small_def
+        if not sd["hist"] or (cameras is None and self._small_def_clean()):
+            return
+        opt = self.optimizer
+        groups = {g["name"]: g for g in opt.gpu_adam.param_groups}
+        order = [groups[n_] for n_ in ("xyz", "opacity", "scaling", "rotation")]
+        ps, ms, vs = [], [], []
+        for g in order:
+            p = g["params"][0]
+            st = opt.gpu_adam.state[p]
+            ps.append(p.data_ptr()); ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
+        hist = sd["hist"][::-1]  # newest first
+        nh = len(hist)
+        lr = (ctypes.c_double * (4 * nh))(*[x for h in hist for x in h[1]])
+        sidx = (ctypes.c_int32 * nh)(*[h[2] for h in hist])
+        pm, sg_, dx, dl = [1e-12], [1.001], 0.0, 0.0
+        for h in hist:
+            dx += h[3]
+            dl += h[4]
+            pm.append(math.sqrt(3.0) * dx * 1.001 + 1e-12)
+            sg_.append(math.exp(dl) * 1.001)
+        pos_margin = (ctypes.c_float * (nh + 1))(*pm)
+        scale_gain = (ctypes.c_float * (nh + 1))(*sg_)
+        arr = lambda xs: (ctypes.c_void_p * 4)(*xs)
+        pk, gk, blk = self.small_packed(), self.small_grad(), self._small_def_tables()
+        b1, b2 = order[0]["betas"]
+        C, vm, Ks = 0, None, None
+        if cameras is not None:
+            C = len(cameras)
+            Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in cameras]).contiguous()
+            vm = torch.stack([c.world_view_transform.transpose(0, 1) for c in cameras]).contiguous()
+        _lib.check(_lib.lib().clmgs_adam_small_deferred(
+            _lib.stream(), int(self._xyz.shape[0]), arr(ps), arr(ms), arr(vs), _lib.dptr(pk), _lib.dptr(gk),
+            _lib.dptr(self._row_g_step, torch.int32), _lib.dptr(blk, torch.int32), int(hist[0][0]), nh, lr, sidx,
+            pos_margin, scale_gain, float(b1), float(b2), float(order[0]["eps"]), 1.0 / float(self.args.bsz), C,
+            _lib.dptr(vm, None, True), _lib.dptr(Ks, None, True), int(utils.get_img_width()), int(utils.get_img_height()),
+            0.3, 0.01, 1e10, 0 if cameras is not None else 1))
+        if cameras is None:
+            self._small_def_dirty = False
+
+    def flush_small(self):
+        """Every block brought to the newest recorded step: the four tensors (and the mirror) are what an eager run holds."""
+        if self.small_deferred:
+            self.small_catch_up(None)
+
     # ---------------------------------------------------- deferred dense Adam
     @property
     def lazy_rows(self):
@@ -345,6 +477,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if self.deferred_host_rows:
             self.host_rows_prepare(None, None)
             return
+        self.flush_small()  # (single GPU, small attributes stepped per block: everything waiting is applied)
         from ... import dp
         if (not self.lazy_rows) and dp.active() and getattr(self.args, "dp_locality", False) \
                 and getattr(self.args, "sparse_adam", False):
@@ -708,7 +841,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         return utils.select_rows(p, mask)
 
     def reset_opacity(self):
-        if self.small_owner:
+        if self.small_owner or self.small_deferred:
             self.flush_lazy_rows()  # every copy current (and identical on all ranks) before all of them are rewritten
         new = utils.inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))
         self._replace_gpu("opacity", "_opacity", new, lambda s: torch.zeros_like(s))

@@ -427,6 +427,24 @@ int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t row_begin, in
                                   void* packed_g, double beta1, double beta2, double eps, int step,
                                   int bias_correction, float grad_scale, const int32_t* g_stamp, int cur_step);
 
+/* Single GPU, round 5: the dense Adam of the small attributes DEFERRED per block of 256 consecutive (Z-ordered) rows
+ * (replaces the eager clmgs_adam_small_packed of a batch; the reference steps them eagerly with torch's Adam,
+ * strategies/clm_offload/engine.py:870-882 / optimizer.py:91-184 -- same arithmetic per step, applied later).
+ * blk_last[ceil(n/256)] holds the optimizer step each block is current as of.  A call brings up to `to_step` every
+ * block that (a) may hold a row visible in one of the C cameras when its values are stale by the waiting steps'
+ * worth of Adam's step bound (pos_margin[k], scale_gain[k] for k waiting steps), (b) is clmgs_small_deferred_kmax() - 1
+ * or more steps behind, or (c) any block at all when flush_all != 0 -- replaying the waiting steps one by one with the
+ * constants of THEIR step (lr4_hist[j][4], step_index[j]: entry j describes step to_step - j; n_hist entries) and the
+ * row's waiting gradient line (packed_g row, stamp g_stamp[row]) at the step it belongs to.  Bit-identical to the
+ * eager sequence; the packed mirror is refreshed for the blocks processed. */
+int clmgs_small_deferred_kmax(void);
+int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* params, float* const* exp_avg,
+                              float* const* exp_avg_sq, void* packed_p, const void* packed_g, const int32_t* g_stamp,
+                              int32_t* blk_last, int to_step, int n_hist, const double* lr4_hist,
+                              const int32_t* step_index, const float* pos_margin, const float* scale_gain, double beta1,
+                              double beta2, double eps, float grad_scale, int C, const float* viewmats, const float* Ks,
+                              int width, int height, float eps2d, float near_plane, float far_plane, int flush_all);
+
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);
 

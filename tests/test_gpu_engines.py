@@ -698,3 +698,77 @@ def test_host_speculative_prefetch_is_exact(dev):
         assert torch.equal(res[mode][2], res["plain"][2])
         assert torch.equal(res[mode][5], res["plain"][5])                      # every row current as of the same step
         assert torch.equal(res[mode][4], res["plain"][4])                      # and no stamp left behind by a dropped hint
+
+
+def test_deferred_small_adam_equals_eager(dev):
+    """Round 5: xyz / opacity / scaling / rotation stepped per block of 256 rows, only when one of the batch's cameras
+    may see the block (GaussianModelCLMOffload.small_deferred, clmgs_adam_small_deferred) == the eager dense Adam of
+    every batch: 24 batches of moving cameras over a scene of 60 000 rows in Z-order (most blocks wait for several
+    batches, some for the full clmgs_small_deferred_kmax() steps and are then forced), a per-image learning-rate
+    schedule, a densification + re-sort and an opacity reset in the middle -- the visibility FILTERS of every batch, the
+    losses, the four tensors, their Adam moments, the SH rows and the densification statistics end bit-identical; and
+    blocks really were skipped (otherwise the test proves nothing)."""
+    from clm_gs_amd import _lib, utils
+    from clm_gs_amd.densification import gsplat_densification
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    n, w, h, nb = 60_000, 160, 120, 24
+    outs, skipped = [], None
+    for deferred in (True, False):
+        args = utils.default_args(bsz=BSZ, sh_residency="hbm", deferred_small_adam=deferred, densify_from_iter=0,
+                                  densification_interval=BSZ * 10, densify_until_iter=10 ** 6, opacity_reset_interval=BSZ * 15,
+                                  densify_grad_threshold=0.00002, position_lr_max_steps=200)
+        args.clm_offload = True
+        utils.set_args(args)
+        utils.set_img_size(h, w)
+        utils.set_cur_iter(1)
+        sc = synth_gaussians(n, seed=2, device="cuda")
+        order = utils.morton_order(sc["xyz"])
+        for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            sc[k] = utils.gather_rows(sc[k], order)
+        m = GaussianModelCLMOffload(3)
+        m.create_from_tensors(sc["xyz"], sc["shs48"], sc["scaling"], sc["rotation"], sc["opacity"], spatial_lr_scale=2.0)
+        m.active_sh_degree = 3
+        m.training_setup(args)
+        assert m.small_deferred == deferred
+        m.fuse_sort_into_prune = True
+        cams = nadir_cameras(nb * BSZ, n, w, h, 0.05, seed=6, device="cuda")   # small footprints: most blocks are far away
+        g = torch.Generator().manual_seed(8)
+        for c in cams:
+            c.original_image = (torch.rand(3, h, w, generator=g) * 255).to(torch.uint8).cuda()
+        comm = torch.cuda.Stream()
+        log, behind = [], []
+        it = 1
+        for b in range(nb):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            # a walk that returns: batches 0-7 move on, 8-15 revisit earlier places, 16-23 move on again
+            sel = cams[(b % 8) * BSZ:(b % 8 + 1) * BSZ] if 8 <= b < 16 else cams[b * BSZ:(b + 1) * BSZ]
+            losses, _, sparsity = clm_offload_train_one_batch(m, _Scene, sel, m.parameters_grad_buffer, None, None, comm,
+                                                              torch.Generator(device="cuda"))
+            log.append(torch.stack(losses).clone())
+            log.append(torch.tensor(sparsity))
+            log.append(torch.tensor([int(_lib.STATS["touched_rows"][-1])]))
+            if deferred:
+                bl = m._small_def["blk_last"]
+                behind.append(int((m.optimizer.cpu_adam.global_step - 1 - bl).max()))
+            n0 = m.get_xyz.shape[0]
+            gsplat_densification(it, _Scene, m, None)
+            if m.get_xyz.shape[0] != n0:
+                m.spatial_sort()
+                log.append(torch.tensor([m.get_xyz.shape[0]]))
+            it += BSZ
+        if deferred:
+            skipped = max(behind)
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        outs.append(log + [m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
+                           m._rotation.detach().clone(), m._parameters.detach().clone(), st["exp_avg"].clone(),
+                           m.small_packed().clone(), m.max_radii2D.clone(), m.xyz_gradient_accum.clone(), m.denom.clone()]
+                    + [m.optimizer.gpu_adam.state[p][k].clone() for p in (m._xyz, m._opacity, m._scaling, m._rotation)
+                       for k in ("exp_avg", "exp_avg_sq", "step")])
+    assert skipped >= 8, skipped  # some block waited that many batches before a camera came near / it was forced
+    assert len(outs[0]) == len(outs[1])
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), i
