@@ -23,10 +23,12 @@ def gsplat_densification(iteration, scene, gaussians, batched_screenspace_pkg=No
             iteration, gbsz, args.densification_interval, 0):
         assert not args.stop_update_param
         gaussians.optimizer.zero_grad(set_to_none=True)
-        if getattr(gaussians, "small_owner", False) or getattr(gaussians, "small_deferred", False):
+        if getattr(gaussians, "small_owner", False):
             # camera-DP with the small attributes at their owners: scales / opacities / positions of foreign rows are
             # stale until the replicas are completed -- the clone / split / prune masks are computed from them
             gaussians.flush_lazy_rows()
+        if getattr(gaussians, "small_deferred", False):
+            gaussians.flush_small()  # single GPU, small attributes stepped per block: the same, for the waiting steps
         dp.allreduce_densify_stats(gaussians)  # camera-DP: sum / sum / max over ranks
         timers.start("densify_and_prune")
         size_threshold = 20 if iteration > args.opacity_reset_interval else None

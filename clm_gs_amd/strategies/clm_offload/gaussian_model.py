@@ -301,12 +301,15 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         reset, evaluation, saving, capture: all do)."""
         return getattr(self, "_small_def", None) is not None
 
-    def _small_def_tables(self):
+    def _small_def_tables(self, current_as_of=None):
+        """blk_last: the step every block of 256 rows is current as of.  (Re)made -- all blocks current as of the newest
+        recorded step, or of `current_as_of` when nothing is recorded yet (a fresh or restored model) -- whenever the
+        row count has changed; every structural change flushes first, so nothing can be waiting then."""
         sd = self._small_def
         n = self._xyz.shape[0]
         if sd["blk_last"] is None or sd["n"] != n:
-            assert not sd["hist"] or sd["n"] == -1 or self._small_def_clean(), "row count changed with small-attribute steps waiting"
-            to = sd["hist"][-1][0] if sd["hist"] else 0
+            assert self._small_def_clean(), "row count changed with small-attribute steps waiting"
+            to = sd["hist"][-1][0] if sd["hist"] else int(current_as_of or 0)
             sd["blk_last"] = torch.full(((n + 255) // 256,), int(to), dtype=torch.int32, device=self._xyz.device)
             sd["n"] = n
         return sd["blk_last"]
@@ -344,7 +347,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             self.flush_small()  # a gap in the step numbering (a batch ran in another mode): nothing may span it
             sd["hist"] = []
             sd["blk_last"] = None
-        self._small_def_tables()
+        self._small_def_tables(current_as_of=step - 1)  # (nothing recorded yet: every row is current up to the step before)
         b1, b2 = order[0]["betas"]
         c = (1.0 - b1) / math.sqrt(1.0 - b2) / math.sqrt(1.0 - b1 * b1 / b2) * 1.001  # Adam's step bound / lr (small_after_step)
         sd["hist"].append((int(step), [float(g["lr"]) for g in order], int(idx), c * float(order[0]["lr"]),
@@ -841,7 +844,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         return utils.select_rows(p, mask)
 
     def reset_opacity(self):
-        if self.small_owner or self.small_deferred:
+        if self.small_owner:
             self.flush_lazy_rows()  # every copy current (and identical on all ranks) before all of them are rewritten
+        self.flush_small()  # (single GPU, small attributes stepped per block: the opacities must be current)
         new = utils.inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.ones_like(self._opacity) * 0.01))
         self._replace_gpu("opacity", "_opacity", new, lambda s: torch.zeros_like(s))

@@ -715,6 +715,7 @@ def test_deferred_small_adam_equals_eager(dev):
     n, w, h, nb = 60_000, 160, 120, 24
     outs, skipped = [], None
     for deferred in (True, False):
+        torch.manual_seed(0)  # densify_and_split draws from the global generator: both runs must draw the same numbers
         args = utils.default_args(bsz=BSZ, sh_residency="hbm", deferred_small_adam=deferred, densify_from_iter=0,
                                   densification_interval=BSZ * 10, densify_until_iter=10 ** 6, opacity_reset_interval=BSZ * 15,
                                   densify_grad_threshold=0.00002, position_lr_max_steps=200)
