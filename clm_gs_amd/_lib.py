@@ -38,6 +38,11 @@ SIGNATURES = {
     "clmgs_isect2_sort_temp_bytes": (_sz, [_i64]),
     "clmgs_isect2_emit_sort": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "clmgs_isect2_emit_sort_dev": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "clmgs_isect3_front_temp_bytes": (_sz, [_i, _i]),
+    "clmgs_isect3_front": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz]),
+    "clmgs_isect3_bin_temp_bytes": (_sz, [_i64, _i]),
+    "clmgs_isect3_bin": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "clmgs_isect3_bin_dev": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_rasterize_fwd_dev": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_rasterize_bwd_dev": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "clmgs_rasterize_pack_bytes": (_sz, [_i, _i]),
@@ -120,7 +125,8 @@ class _Namespace:
     pass
 
 
-_NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_small_deferred_kmax", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
+_NO_STREAM = {"clmgs_version", "clmgs_loss_slots", "clmgs_small_deferred_kmax", "clmgs_isect3_front_temp_bytes",
+              "clmgs_isect3_bin_temp_bytes", "clmgs_last_error", "clmgs_isect_count_temp_bytes",
               "clmgs_isect_sort_temp_bytes", "clmgs_host_groups_temp_bytes", "clmgs_isect2_order_temp_bytes", "clmgs_isect2_sort_temp_bytes", "clmgs_visibility_select_temp_bytes", "clmgs_rasterize_pack_bytes", "clmgs_rasterize_partials_bytes", "clmgs_host_adam_rows", "clmgs_host_pool_start", "clmgs_host_usable_cpus", "clmgs_host_rows_prepare", "clmgs_tsp_tour",
               "clmgs_pinned_alloc", "clmgs_pinned_free", "clmgs_debug_counters", "clmgs_device_errors"}
 

@@ -13,7 +13,8 @@ import torch
 
 from . import _lib, utils
 from ._lib import check, dptr
-from .gsplat import _record_counts, bucket_size, empty_bucketed, isect2_begin, isect2_counts, isect2_finish
+from .gsplat import (_record_counts, bucket_size, empty_bucketed, isect2_begin, isect2_counts, isect2_finish, isect3_begin,
+                     isect3_finish)
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 TILE = 16
@@ -169,8 +170,11 @@ def camera_front(gaussians, camera, this_filter, sh_rows, sh_by_filter, backgrou
             0.3, 0.01, 1e10, float(getattr(args, "radius_clip", 0.0)), dptr(radii), dptr(means2d),
             dptr(depths), None, None, None, dptr(packed),  # conics/colours/opacities live in `packed`
             dptr(sh_index, I32, True)))
-        p.isect = isect2_begin(means2d, radii, depths, TILE, tw, th, want_slots=True,
-                               packed=packed if getattr(args, "exact_tile_cull", True) else None)
+        # binning route: "tile" (default, csrc/isect3.hip: no global sort) | "sort" (csrc/isect.hip: depth sort + tile sort);
+        # identical lists (tests/test_gpu_ops.py)
+        begin = isect3_begin if getattr(args, "binning", "tile") == "tile" else isect2_begin
+        p.isect = begin(means2d, radii, depths, TILE, tw, th, want_slots=True,
+                        packed=packed if getattr(args, "exact_tile_cull", True) else None)
         p.aux = p.aux + (means2d, depths)
         p.means2d = means2d  # [1,V,2] pixel centres (parity checks read them; kept alive through p.aux)
     return p
@@ -194,7 +198,8 @@ def camera_forward_finish(gaussians, p, exact=False):
     cap = None if (exact or V == 0) else _capacity_for(_cap_key(gaussians, W, H), args)
     with torch.cuda.stream(s_front):
         with _lib.host_region("fwd_isect"):
-            p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = isect2_finish(p.isect, capacity=cap)
+            finish = isect3_finish if p.isect.route == "tile" else isect2_finish
+            p.fids, p.offsets, _, (p.emit_slot, p.row_cum) = finish(p.isect, capacity=cap)
         if cap is None:
             p.isect, p.n_dev = None, None
             if V:

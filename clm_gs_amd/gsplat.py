@@ -284,7 +284,7 @@ def _pinned_totals_slot():
 class _Isect2:
     """State between isect2_begin and isect2_finish (one camera's binning in flight)."""
     __slots__ = ("args", "V", "dev", "depths", "order", "cum", "boxes", "totals", "host", "event",
-                 "offsets", "temp", "means2d", "radii", "packed", "row_cum")
+                 "offsets", "temp", "means2d", "radii", "packed", "row_cum", "route")
 
 
 @torch.no_grad()
@@ -296,6 +296,7 @@ def isect2_begin(means2d, radii, depths, tile_size, tile_width, tile_height, wan
     the event -- unlike a `.tolist()`, which waits for everything enqueued on the stream so far."""
     L = _lib.lib()
     c = _Isect2()
+    c.route = "sort"
     c.args = (int(tile_size), int(tile_width), int(tile_height), bool(want_isect_ids), bool(want_slots))
     V = c.V = radii.numel()
     dev = c.dev = radii.device
@@ -377,6 +378,71 @@ def isect2_finish(c, capacity=None):
                                            dptr(c.cum), dptr(c.boxes), tile_width, tile_height, dptr(fids),
                                            dptr(c.offsets), dptr(ids, I64, True), dptr(emit_slot, I32, True),
                                            dptr(temp2), sb, dptr(c.row_cum, I64, True)))
+    return (fids, c.offsets, ids, (emit_slot, c.row_cum)) if want_slots else (fids, c.offsets, ids)
+
+
+# ---- tile-major binning (csrc/isect3.hip): the same lists without a global sort; same two-phase calling pattern
+@torch.no_grad()
+def isect3_begin(means2d, radii, depths, tile_size, tile_width, tile_height, want_isect_ids=False,
+                 want_slots=False, packed=None):
+    """First half of the tile-major binning (clmgs_isect3_front): per-row tile boxes / masks, tile counters, row_cum and
+    the totals on the CURRENT stream, then the asynchronous readback of the totals -- the calling pattern (and the
+    state object) of isect2_begin; isect2_counts reads the totals of either."""
+    L = _lib.lib()
+    c = _Isect2()
+    c.route = "tile"
+    c.args = (int(tile_size), int(tile_width), int(tile_height), bool(want_isect_ids), bool(want_slots))
+    V = c.V = radii.numel()
+    dev = c.dev = radii.device
+    c.means2d, c.radii, c.depths = means2d.contiguous(), radii.contiguous(), depths.contiguous()
+    c.packed = packed
+    c.offsets = torch.empty((1, tile_height, tile_width), dtype=I32, device=dev)
+    c.event = None
+    c.order = c.cum = c.boxes = None
+    if V == 0:
+        return c
+    c.totals = torch.empty((2,), dtype=I64, device=dev)
+    c.row_cum = empty_bucketed(V, (), I64, dev)
+    tb = L.clmgs_isect3_front_temp_bytes(V, int(tile_width) * int(tile_height))
+    c.temp = empty_bucketed(tb, (), torch.uint8, dev)
+    check(L.clmgs_isect3_front(stream(), V, dptr(c.means2d, F32), dptr(c.radii, I32), c.args[0], c.args[1], c.args[2],
+                               dptr(packed, F32, True), dptr(c.totals), dptr(c.row_cum), dptr(c.temp), tb))
+    c.host = _pinned_totals_slot()
+    c.host.copy_(c.totals, non_blocking=True)
+    c.event = torch.cuda.Event()
+    c.event.record(torch.cuda.current_stream())
+    return c
+
+
+@torch.no_grad()
+def isect3_finish(c, capacity=None):
+    """Second half (clmgs_isect3_bin / _bin_dev): tile scan, scatter, per-tile sort.  Same contract as isect2_finish."""
+    L = _lib.lib()
+    tile_size, tile_width, tile_height, want_isect_ids, want_slots = c.args
+    dev, V = c.dev, c.V
+    if V == 0:
+        c.offsets.zero_()
+        e = torch.empty(0, dtype=I32, device=dev)
+        res = (e, c.offsets, (torch.empty(0, dtype=I64, device=dev) if want_isect_ids else None))
+        return res + ((e, torch.empty(0, dtype=I64, device=dev)),) if want_slots else res
+    if capacity is None:
+        n_isects, n_ref = isect2_counts(c)
+        _record_counts(n_isects, n_ref)
+    else:
+        n_isects = int(capacity)
+    fids = empty_bucketed(n_isects, (), I32, dev)
+    ids = empty_bucketed(n_isects, (), I64, dev) if want_isect_ids else None
+    sb = L.clmgs_isect3_bin_temp_bytes(n_isects, tile_width * tile_height)
+    temp2 = empty_bucketed(sb, (), torch.uint8, dev)
+    emit_slot = empty_bucketed(n_isects, (), I32, dev) if want_slots else None
+    if capacity is None:
+        check(L.clmgs_isect3_bin(stream(), V, n_isects, dptr(c.depths), tile_width, tile_height, dptr(c.row_cum),
+                                 dptr(c.temp), dptr(fids), dptr(c.offsets), dptr(ids, I64, True),
+                                 dptr(emit_slot, I32, True), dptr(temp2), sb))
+    else:
+        check(L.clmgs_isect3_bin_dev(stream(), V, n_isects, dptr(c.totals), dptr(c.depths), tile_width, tile_height,
+                                     dptr(c.row_cum), dptr(c.temp), dptr(fids), dptr(c.offsets), dptr(ids, I64, True),
+                                     dptr(emit_slot, I32, True), dptr(temp2), sb))
     return (fids, c.offsets, ids, (emit_slot, c.row_cum)) if want_slots else (fids, c.offsets, ids)
 
 

@@ -54,6 +54,8 @@ def default_args(**over):
         dp_small_owner=True,    # ... and xyz / opacity / scaling / rotation stepped by the owner of a row range only (no step F)
         dp_small_refresh=8,     # ... batches between two all-gathers of the owned small-attribute ranges (bounds the staleness)
         dp_small_max_log_gain=0.7,  # ... or earlier, once the bound on the growth of a stale scale exceeds exp(this)
+        binning="tile",  # per-camera tile binning: "tile" = per-tile counters + scatter + one LDS sort per tile (isect3.hip,
+                         # 7 launches); "sort" = depth sort of the rows + stable sort on the tile id (isect.hip, 23 launches)
         deferred_small_adam=True,  # single GPU, dense optimizer: xyz / opacity / scaling / rotation are stepped per block of 256
                                    # Z-ordered rows when a batch's cameras may see it (GaussianModelCLMOffload.small_deferred)
         allocator_reservoir=True,  # trainer: one block per stream pool allocated and freed before the first batch

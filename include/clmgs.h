@@ -174,6 +174,31 @@ int clmgs_isect2_emit_sort_dev(void* stream, int V, int64_t capacity, const int6
                                const uint64_t* boxes, int tile_width, int tile_height,
                                int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids,
                                int32_t* emit_slot, void* temp, size_t temp_bytes, const int64_t* row_cum);
+
+/* Tile-major binning (round 5; the engine's default route): the same lists as clmgs_isect2_order_count +
+ * clmgs_isect2_emit_sort -- gsplat.isect_tiles + isect_offset_encode of strategies/base_engine.py:175-186, sorted by
+ * (tile, depth bits, row index) -- built without a global sort: per-tile counters, an exclusive scan (= offsets), a
+ * scatter of 16 B records into the tiles' segments and one LDS sort per tile (csrc/isect3.hip).  7 launches instead of 23.
+ *  - clmgs_isect3_front: per-row tile boxes / exact tile masks (packed != NULL), tile counters, row_cum[V] (inclusive
+ *    emitted counts in ROW order = the slot ranges of clmgs_rasterize_bwd's slot mode), totals[2] on the device =
+ *    {intersections to emit, un-culled count}.  `temp` (clmgs_isect3_front_temp_bytes) must stay alive until _bin ran.
+ *  - clmgs_isect3_bin: offsets[tile_w*tile_h], flatten_ids[I], emit_slot[I] (optional), isect_ids[I] (optional) from the
+ *    front half's temp; n_isects = totals[0] read back by the caller.
+ *  - clmgs_isect3_bin_dev: device-count form (see clmgs_isect2_emit_sort_dev): buffers and launches sized for
+ *    `capacity`, the true count read on the device; above the capacity the lists are memory-safe but incomplete and
+ *    the caller redoes the camera. */
+size_t clmgs_isect3_front_temp_bytes(int V, int n_tiles);
+int clmgs_isect3_front(void* stream, int V, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
+                       int tile_height, const void* packed, int64_t* totals, int64_t* row_cum, void* temp,
+                       size_t temp_bytes);
+size_t clmgs_isect3_bin_temp_bytes(int64_t n_isects, int n_tiles);
+int clmgs_isect3_bin(void* stream, int V, int64_t n_isects, const float* depths, int tile_width, int tile_height,
+                     const int64_t* row_cum, const void* front_temp, int32_t* flatten_ids, int32_t* offsets,
+                     int64_t* isect_ids, int32_t* emit_slot, void* temp, size_t temp_bytes);
+int clmgs_isect3_bin_dev(void* stream, int V, int64_t capacity, const int64_t* n_isects_dev, const float* depths,
+                         int tile_width, int tile_height, const int64_t* row_cum, const void* front_temp,
+                         int32_t* flatten_ids, int32_t* offsets, int64_t* isect_ids, int32_t* emit_slot, void* temp,
+                         size_t temp_bytes);
 int clmgs_rasterize_fwd_dev(void* stream, int C, int N, int64_t capacity, const int64_t* n_isects_dev,
                             const float* backgrounds, int width, int height, int tile_size,
                             int tile_width, int tile_height, const int32_t* offsets,

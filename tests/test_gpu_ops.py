@@ -1071,3 +1071,89 @@ def test_visibility_candidates_kernel_brackets_its_numpy_restatement(dev):
         assert not np.any(inner & ~got), (d, gain, int(np.sum(inner & ~got)))
         assert not np.any(got & ~outer), (d, gain, int(np.sum(got & ~outer)))
         assert 0 < inner.sum() < n
+
+
+def _tile_major_lists(G, m2, radii, d, tw, th, n, pk, cap_slack):
+    c = G.isect3_begin(m2, radii, d, 16, tw, th, want_isect_ids=True, want_slots=True, packed=pk)
+    torch.cuda.synchronize()
+    tot = c.totals.clone()
+    cap = None if cap_slack is None else max(1, int(int(tot[0]) * cap_slack))
+    fids, off, ids, (slot, row_cum) = G.isect3_finish(c, capacity=cap)
+    torch.cuda.synchronize()
+    I = int(tot[0])
+    return [tot, row_cum[:n].clone(), fids[:I].clone(), off.clone(), ids[:I].clone(), slot[:I].clone()]
+
+
+@pytest.mark.parametrize("n,wh", [(3000, (150, 101)), (180_000, (640, 480))])
+def test_tile_major_binning_equals_two_level_sort(dev, n, wh):
+    """Round 5: the tile-major route (csrc/isect3.hip: per-tile counters, scatter, one LDS sort per tile by (depth bits,
+    row index) -- the engine's default) produces the lists of the two-level route (csrc/isect.hip: depth sort of the rows
+    + stable sort on the tile id) element for element: totals, row_cum, flatten_ids, offsets, isect_ids, emit_slot; exact
+    form and device-count form with room to spare; with and without exact tile culling; with exact depth ties."""
+    from clm_gs_amd import _lib, gsplat as G
+    from clm_gs_amd._lib import check, dptr, stream
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    L = _lib.lib()
+    w, h = wh
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    sc = synth_gaussians(n, seed=11, device="cuda")
+    cam = nadir_cameras(1, n, w, h, 0.9, seed=2, device="cuda")[0]
+    vm = cam.world_view_transform.t().contiguous()[None]
+    K = cam.K[None]
+    quats = torch.nn.functional.normalize(sc["rotation"])
+    radii, m2, d, cn, _ = G.fully_fused_projection(sc["xyz"], None, quats, torch.exp(sc["scaling"]), vm, K, w, h)
+    d = d.clone()
+    d[0, : n // 50] = d[0, 0]  # exact depth ties: broken by row index in both routes
+    packed = torch.empty((n, 16), device=dev)
+    colors = torch.rand(1, n, 3, device=dev)
+    opac = torch.sigmoid(sc["opacity"]).reshape(1, -1).contiguous()
+    fids0, off0, _ = G.isect_tiles_two_level(m2, radii, d, 16, tw, th)
+    out, al, last = torch.empty((h, w, 3), device=dev), torch.empty((h, w), device=dev), torch.empty((h, w), dtype=torch.int32, device=dev)
+    check(L.clmgs_rasterize_fwd(stream(), 1, n, fids0.numel(), dptr(m2), dptr(cn), dptr(colors), dptr(opac), None, w, h, 16, tw,
+                                th, dptr(off0), dptr(fids0), dptr(packed), dptr(out), dptr(al), dptr(last)))  # fills `packed`
+    names = ("totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot")
+    for pk in (None, packed):
+        ref = _binning_lists(G, m2, radii, d, tw, th, n, pk, None)
+        want = [ref[3], ref[4], ref[5], ref[6], ref[7], ref[8]]
+        assert int(want[0][0]) > (100_000 if n > 100_000 else 100)
+        for slack in (None, 1.0, 1.3):
+            got = _tile_major_lists(G, m2, radii, d, tw, th, n, pk, slack)
+            for nm, a, b in zip(names, got, want):
+                assert torch.equal(a, b), (nm, pk is not None, slack)
+        # a capacity below the count: memory-safe, every stored id a valid row, offsets monotone and within the capacity
+        c = G.isect3_begin(m2, radii, d, 16, tw, th, want_slots=True, packed=pk)
+        cap = int(int(want[0][0]) * 0.6)
+        fids, off, _, (slot, _) = G.isect3_finish(c, capacity=cap)
+        torch.cuda.synchronize()
+        assert int(fids.min()) >= 0 and int(fids.max()) < n and int(off.max()) <= cap
+        o = off.reshape(-1)
+        assert bool((o[1:] >= o[:-1]).all())
+
+
+def test_tile_major_binning_long_lists_and_whole_image_boxes(dev):
+    """The tile-major route where its special paths run: tiles with more than 1 024 entries (the 256-thread LDS sort),
+    one tile with more than 8 192 (the sort in global memory), rows whose box covers the whole image (expanded by a
+    whole workgroup), empty tiles, rows that emit nothing, exact depth ties -- against the two-level route."""
+    from clm_gs_amd import gsplat as G
+    n, w, h = 70_000, 640, 480
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    g = torch.Generator().manual_seed(4)
+    m2 = (torch.rand(1, n, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])).to(dev)   # everything in one quadrant
+    radii = torch.randint(1, 30, (1, n), generator=g, dtype=torch.int32)
+    m2[0, :12_000] = torch.tensor([100.0, 100.0], device=dev) + torch.rand(12_000, 2, generator=g).to(dev) * 4.0  # one tile, > 8192
+    radii[0, :12_000] = 1
+    m2[0, 12_000:16_000] = torch.tensor([300.0, 40.0], device=dev) + torch.rand(4_000, 2, generator=g).to(dev) * 4.0  # > 1024
+    radii[0, 12_000:16_000] = 1
+    radii[0, torch.randperm(n, generator=g)[:30]] = 3000       # the whole image
+    radii[0, torch.randperm(n, generator=g)[: n // 6]] = 0      # culled
+    radii = radii.to(dev)
+    d = (torch.rand(1, n, generator=g) * 50 + 1).to(dev)
+    d[0, :3000] = 7.0
+    ref = _binning_lists(G, m2, radii, d, tw, th, n, None, None)
+    want = [ref[3], ref[4], ref[5], ref[6], ref[7], ref[8]]
+    cnt = torch.bincount((ref[7] >> 32).to(torch.int64), minlength=tw * th)
+    assert int(cnt.max()) > 8192 and int((cnt > 1024).sum()) >= 2 and int((cnt <= 256).sum()) > 0
+    for slack in (None, 1.0):
+        got = _tile_major_lists(G, m2, radii, d, tw, th, n, None, slack)
+        for nm, a, b in zip(("totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot"), got, want):
+            assert torch.equal(a, b), (nm, slack)
