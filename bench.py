@@ -521,6 +521,13 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
                               # re-allocating all four tables at 1.5x
                               prealloc_capacity=int(N * 1.05) // 16 * 16)
     args.clm_offload = True
+    for kv in a.opt:  # the engine options of the command line apply to this leg too (A/B runs)
+        k, v = kv.split("=", 1)
+        cur = getattr(args, k)
+        if isinstance(cur, bool):
+            setattr(args, k, v.lower() in ("1", "true", "yes"))
+        else:
+            setattr(args, k, type(cur)(v))
     utils.set_args(args)
     utils.set_img_size(H, W)
     scene = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
@@ -570,7 +577,8 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
            "what": "clm_gs_amd.trainer.training on a fresh model of the bench scene: shuffled epochs over the run's cameras, "
                    "LR schedule, engine call per batch, a densify_and_prune (+ Z-order re-sort in the same compaction) every 100 "
                    "images as the reference schedules it and one opacity reset INSIDE the End2endTimer, evaluation outside it; "
-                   "none of bench.py's aids (no priming renders; the allocator warm-up is the trainer's own, inside the clock: "
+                   "none of bench.py's aids (no priming renders; the allocator reservation is the trainer's own SETUP step, done before "
+                   "the end-to-end clock starts like the reference's --prealloc_capacity buffers, its wall time reported as "
                    "host_seconds_by_phase.reserve); loss lines written one batch late (defer_loss_log) so the host never "
                    "drains the device between batches"}
     del g

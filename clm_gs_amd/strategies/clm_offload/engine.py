@@ -254,7 +254,7 @@ def reserve_working_set(gaussians, n_cameras_in_flight=2):
     -> bytes reserved per pool."""
     W, H = int(utils.get_img_width()), int(utils.get_img_height())
     P, N = W * H, int(gaussians._xyz.shape[0])
-    I = int(1.3 * P)
+    I = int(1.0 * P)
     V = min(N, max(1, N // 6))
     k = int(n_cameras_in_flight)
     sts = _pipeline_streams(gaussians)
@@ -265,7 +265,7 @@ def reserve_working_set(gaussians, n_cameras_in_flight=2):
         # default stream: filters and touched-row lists of a batch, and the temporaries of a densification -- masks,
         # selections, the Z-order keys and their sort, and the per-row tensors (parameters + moments 132 B, packed mirror /
         # gradient / statistics tables 112 B per row), which are re-created BEFORE their predecessors are freed
-        "default": (torch.cuda.current_stream(), 320 * N + 64 * V * 4),
+        "default": (torch.cuda.current_stream(), 240 * N + 64 * V * 4),
     }
     out = {}
     for name, (st, nbytes) in plan.items():
