@@ -374,16 +374,28 @@ adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __re
   float lr[VEC];
   vload<VEC>(col_lr + k, lr);
   int64_t row_next = row_of<IdxT>(rows, (int64_t)r);
+  // the row id is requested TWO iterations ahead and the row's stamps one iteration ahead: when the row's turn comes it
+  // is already known whether a gradient waits, so the gradient line (192 B of the 1 344 B a row costs) is requested,
+  // with everything else, only for the rows that have one (round 5; a batch finds a waiting gradient on the rows the
+  // batch before it touched too -- about a third of them)
+  int a_next = last_step[row_next];
+  int gs_next = g_step ? g_step[row_next] : 0;
+  int64_t row_next2 = (r + r_stride < n_rows) ? row_of<IdxT>(rows, (int64_t)(r + r_stride)) : row_next;
   for (; r < n_rows; r += r_stride) {
     const int64_t row = row_next;
-    if (r + r_stride < n_rows) row_next = row_of<IdxT>(rows, (int64_t)(r + r_stride));
+    int a = a_next;
+    const int gs = gs_next;
+    row_next = row_next2;
+    if (r + r_stride < n_rows) {
+      a_next = last_step[row_next];
+      gs_next = g_step ? g_step[row_next] : 0;
+      if (r + 2 * r_stride < n_rows) row_next2 = row_of<IdxT>(rows, (int64_t)(r + 2 * r_stride));
+    }
     const int64_t o = row * 48 + k;
     float mm[VEC], vv[VEC], pp[VEC], gg[VEC];
-    int a = last_step[row];
-    const int gs = g_step ? g_step[row] : 0;
-    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp);
-    if (g) vload<VEC>(g + o, gg);
     const bool pending = gs > a && gs <= to_step;
+    vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp);
+    if (pending) vload<VEC>(g + o, gg);
     if (to_step - a <= 0) continue;
     if (!pending) {
       bool any_state = false;

@@ -392,10 +392,9 @@ __device__ __forceinline__ void i3_write_out(int tile, int s, int len, const uns
   }
 }
 
-// One wavefront per tile, lists of LO < len <= CAP entries sorted in CAP x 12 B of LDS.  Three instances: (0, 256] -- 3 KB of
-// LDS, so a CU holds all the waves it can (the network is a chain of 36 dependent LDS round trips per wave: latency, which
-// only other waves hide) --, (256, 512] and (512, 1024].  Lists longer than 1 024 are put on the work list of the 256-thread
-// kernel (by the last instance).
+// One wavefront per tile, lists of LO < len <= CAP entries sorted in CAP x 12 B of LDS by the bitonic network.  Two
+// instances: (256, 512] and (512, 1024] (lists of up to 256 entries: the rank sort below).  Lists longer than 1 024 are put
+// on the work list of the 256-thread kernel (by the last instance).
 template <int LO, int CAP>
 __global__ void __launch_bounds__(64)
 isect3_sort_small_kernel(int n_tiles, const int32_t* __restrict__ offsets, int64_t n, const int64_t* __restrict__ n_dev,
@@ -419,6 +418,76 @@ isect3_sort_small_kernel(int n_tiles, const int32_t* __restrict__ offsets, int64
   }
   bitonic_sort_kv<64>(keys, vals, len, tid, [] { __syncthreads(); });
   i3_write_out(tile, s, len, keys, vals, tid, 64, flatten_ids, emit_slot, isect_ids);
+}
+
+// Lists of at most 256 entries (almost every tile of a 4K camera of the slab scene: 149 entries on average): RANK sort.
+// Every lane keeps up to four records in registers; the keys go to LDS once, and every lane counts, for each of its
+// records, the keys of the tile that are smaller -- one broadcast LDS read (all lanes, one address) and two VALU
+// operations per (key, record).  The count IS the record's place (the keys are distinct), so the outputs are written
+// straight to it: no network of dependent LDS round trips (the bitonic instance of this class took 185 us per camera,
+// LDS-bandwidth bound: 36 steps x 128 compare-exchanges x ~32 B), 2 KB of LDS, len^2 / 64 x ~2.3 instructions.
+template <int E>
+__device__ __forceinline__ void rank_sort_tile(unsigned long long* keys, int tile, int s, int len, int tid,
+                                               const int4* __restrict__ recs, int32_t* __restrict__ flatten_ids,
+                                               int32_t* __restrict__ emit_slot, int64_t* __restrict__ isect_ids) {
+  unsigned long long key[E];
+  int32_t slot[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int q = tid + 64 * r;
+    key[r] = ~0ull; slot[r] = 0;
+    if (q < len) {
+      const int4 rc = recs[s + q];
+      key[r] = ((unsigned long long)(uint32_t)rc.x << 32) | (unsigned long long)(uint32_t)rc.y;
+      slot[r] = rc.z;
+      keys[q] = key[r];
+    }
+  }
+  __syncthreads();
+  int cnt[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) cnt[r] = 0;
+  int j = 0;
+  for (; j + 4 <= len; j += 4) {
+    const unsigned long long k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+      cnt[r] += (int)(k0 < key[r]) + (int)(k1 < key[r]) + (int)(k2 < key[r]) + (int)(k3 < key[r]);
+  }
+  for (; j < len; ++j) {
+    const unsigned long long k0 = keys[j];
+#pragma unroll
+    for (int r = 0; r < E; ++r) cnt[r] += (int)(k0 < key[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if (tid + 64 * r < len) {
+      const int o = s + cnt[r];
+      flatten_ids[o] = (int32_t)(key[r] & 0xFFFFFFFFull);
+      if (emit_slot) emit_slot[o] = slot[r];
+      if (isect_ids) isect_ids[o] = ((int64_t)tile << 32) | (int64_t)(key[r] >> 32);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+isect3_sort_rank_kernel(int n_tiles, const int32_t* __restrict__ offsets, int64_t n, const int64_t* __restrict__ n_dev,
+                        const int4* __restrict__ recs, int32_t* __restrict__ flatten_ids,
+                        int32_t* __restrict__ emit_slot, int64_t* __restrict__ isect_ids) {
+  constexpr int CAP = 256;
+  __shared__ unsigned long long keys[CAP];
+  if (n_dev) n = min(n, *n_dev);
+  const int tile = (int)xcd_remap(blockIdx.x, (unsigned)n_tiles);
+  const int tid = threadIdx.x;
+  const int s = offsets[tile];
+  const int e = (tile == n_tiles - 1) ? (int)n : offsets[tile + 1];
+  const int len = e - s;
+  if (len <= 0 || len > CAP) return;
+  // records per lane by list length (wave-uniform): a list of 149 entries pays for three records per lane, not four
+  if (len <= 64) rank_sort_tile<1>(keys, tile, s, len, tid, recs, flatten_ids, emit_slot, isect_ids);
+  else if (len <= 128) rank_sort_tile<2>(keys, tile, s, len, tid, recs, flatten_ids, emit_slot, isect_ids);
+  else if (len <= 192) rank_sort_tile<3>(keys, tile, s, len, tid, recs, flatten_ids, emit_slot, isect_ids);
+  else rank_sort_tile<4>(keys, tile, s, len, tid, recs, flatten_ids, emit_slot, isect_ids);
 }
 
 // tiles with more than I3_SMALL entries (deep lists: heavy-tailed scenes, degenerate inputs), from the work list: one
@@ -551,8 +620,8 @@ static int isect3_bin_impl(void* stream, int V, int64_t n_isects, const int64_t*
                      offsets, cursor, big_count, slice_tot);
   hipLaunchKernelGGL(isect3_scatter_kernel, dim3(i3_chunks(V)), dim3(256), 0, s, V, box_by_row, depths, row_cum,
                      tile_width, cursor, n_isects, n_dev, recs);
-  hipLaunchKernelGGL((isect3_sort_small_kernel<0, 256>), dim3(n_tiles), dim3(64), 0, s, n_tiles, (const int32_t*)offsets,
-                     n_isects, n_dev, (const int4*)recs, flatten_ids, emit_slot, isect_ids, big_count, big_list);
+  hipLaunchKernelGGL(isect3_sort_rank_kernel, dim3(n_tiles), dim3(64), 0, s, n_tiles, (const int32_t*)offsets, n_isects,
+                     n_dev, (const int4*)recs, flatten_ids, emit_slot, isect_ids);
   hipLaunchKernelGGL((isect3_sort_small_kernel<256, 512>), dim3(n_tiles), dim3(64), 0, s, n_tiles, (const int32_t*)offsets,
                      n_isects, n_dev, (const int4*)recs, flatten_ids, emit_slot, isect_ids, big_count, big_list);
   hipLaunchKernelGGL((isect3_sort_small_kernel<512, I3_SMALL>), dim3(n_tiles), dim3(64), 0, s, n_tiles,

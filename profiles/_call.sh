@@ -1,9 +1,10 @@
 set -x
-O=gpurun_out/r05p; mkdir -p $O
-B="--steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-heavy-leg --no-kernel-timing --gt resident --prime-seconds 3"
-for rep in 1 2; do for o in "binning=tile" "binning=sort" "deferred_small_adam=false"; do
-timeout 300 python bench.py $B --opt $o 2>/dev/null | python -c "
+O=gpurun_out/r05q; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_engines.py tests/test_gpu_golden_engine.py -q -x 2>&1 | tail -5
+bash profiles/solo_trace.sh r05q > /dev/null 2>&1; grep -E "isect3|adam" gpurun_out/r4/solo_kernel_stats_r05q.csv | cut -c1-200
+B="--steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-trainer-leg --no-heavy-leg --gt resident --prime-seconds 5"
+for rep in 1 2; do
+timeout 300 python bench.py $B 2>/dev/null | python -c "
 import sys,json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); t=d['trainer']
-print('$o', d['value'], 'trainer', t['trainer_img_s'], t['host_seconds_by_phase'], t['device_mallocs'], t['trainer_peak_gpu_bytes'])"
-done; done
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['measured']['loss_last'], {k.replace('clmgs_',''):round(v,3) for k,v in d['kernels_solo_ms'].items()})"
+done
