@@ -23,6 +23,7 @@ SIGNATURES = {
     "clmgs_projection_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "clmgs_visibility_select_temp_bytes": (_sz, [_i, _i]),
     "clmgs_visibility_select_count": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _sz, _vp]),
+    "clmgs_visibility_select_count_blocks": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _sz, _vp, _vp]),
     "clmgs_visibility_select_emit": (_i, [_vp, _i, _i, _vp, _vp]),
     "clmgs_visibility_raw": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "clmgs_projection_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -82,7 +83,7 @@ SIGNATURES = {
     "clmgs_adam_small_packed_range": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _i, _f, _vp, _i]),
     "clmgs_small_deferred_kmax": (_i, []),
     "clmgs_adam_small_deferred": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _d,
-                                       _f, _i, _vp, _vp, _i, _i, _f, _f, _f, _i]),
+                                       _f, _i, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp]),
     "clmgs_debug_counters": (_i, [_vp, _i]),
     "clmgs_device_errors": (_i, [_vp, _i]),
     "clmgs_pinned_alloc": (_vp, [_sz]),

@@ -595,7 +595,7 @@ adam_small_deferred_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p
                            const int32_t* __restrict__ g_stamp, int32_t* __restrict__ blk_last, SmallDeferred d,
                            float beta1, float beta2, float ob1, float ob2, float eps, float grad_scale, int C,
                            const float* __restrict__ viewmats, const float* __restrict__ Ks, float W, float H, float eps2d,
-                           float near_plane, float far_plane, int flush_all) {
+                           float near_plane, float far_plane, int flush_all, uint8_t* __restrict__ blk_flag) {
   __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
   __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
   __shared__ int gstep_s[SA_ROWS];
@@ -610,23 +610,28 @@ adam_small_deferred_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p
   for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const int last = blk_last[blk];
     const int k = d.to_step - last;
-    if (k <= 0) continue;  // (block-uniform)
+    if (k <= 0 && (flush_all || !blk_flag)) continue;  // (block-uniform)
     const int64_t row0 = blk * SA_ROWS;
     const int rows = (int)min((int64_t)SA_ROWS, n - row0);
     __syncthreads();  // cam_s written / the previous block's LDS consumed
-    if (!flush_all && k < SD_KMAX) {
+    if (!flush_all) {
+      // the candidate test: may a row of this block pass the cull of one of the batch's cameras, its values being stale by
+      // k steps?  Also handed to the exact visibility pass that follows (blk_flag: it skips the blocks that cannot)
+      const int kk = min(max(k, 0), SD_KMAX);
       bool cand = false;
       if (tid < rows) {
         const float* x = t.p[0] + 3 * (row0 + tid);
         const float* ls = t.p[2] + 3 * (row0 + tid);
         const float m[3] = {x[0], x[1], x[2]};
-        const float sgn = __expf(fmaxf(ls[0], fmaxf(ls[1], ls[2]))) * d.scale_gain[k];
+        const float sgn = __expf(fmaxf(ls[0], fmaxf(ls[1], ls[2]))) * d.scale_gain[kk];
         const float smax2g = sgn * sgn;
         cand = !(smax2g < 1e30f);  // NaN / overflowing scales: current values decide
         for (int c = 0; c < C && !cand; ++c)
-          cand = vis_candidate(lds_cam(cam_s[c]), cam_s[c][16], m, smax2g, d.pos_margin[k], W, H, eps2d, near_m, far_m);
+          cand = vis_candidate(lds_cam(cam_s[c]), cam_s[c][16], m, smax2g, d.pos_margin[kk], W, H, eps2d, near_m, far_m);
       }
-      if (!__syncthreads_or(cand)) continue;
+      const bool any = __syncthreads_or(cand);
+      if (blk_flag && tid == 0) blk_flag[blk] = any ? 1 : 0;
+      if (k <= 0 || (!any && k < SD_KMAX)) continue;
     }
     // ---- the block's k waiting steps.  Gradient lines: a row's line belongs to step g_stamp[row]; it is waiting iff
     // last < stamp <= to_step (consumed lines keep their old stamp: first-touch producers never clear)
@@ -1037,9 +1042,15 @@ extern "C" int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* 
                                          const double* lr4_hist, const int32_t* step_index, const float* pos_margin,
                                          const float* scale_gain, double beta1, double beta2, double eps,
                                          float grad_scale, int C, const float* viewmats, const float* Ks, int width,
-                                         int height, float eps2d, float near_plane, float far_plane, int flush_all) {
+                                         int height, float eps2d, float near_plane, float far_plane, int flush_all,
+                                         uint8_t* blk_flag) {
   CLMGS_CHECK_ARG(n >= 0 && to_step >= 0 && n_hist >= 0 && n_hist <= SD_KMAX);
-  if (n == 0 || n_hist == 0) return 0;
+  CLMGS_CHECK_ARG(!blk_flag || !flush_all);
+  if (n == 0) return 0;
+  if (n_hist == 0) {  // nothing recorded yet: nothing waits, and nothing is known about visibility
+    if (blk_flag) CLMGS_HIP(hipMemsetAsync(blk_flag, 1, (size_t)((n + SA_ROWS - 1) / SA_ROWS), (hipStream_t)stream));
+    return 0;
+  }
   CLMGS_CHECK_ARG(params && exp_avg && exp_avg_sq && packed_p && packed_g && g_stamp && blk_last && lr4_hist &&
                   step_index && pos_margin && scale_gain && (((uintptr_t)packed_p | (uintptr_t)packed_g) & 15) == 0);
   CLMGS_CHECK_ARG(flush_all || (C >= 1 && C <= VB_MAX_CAMS && viewmats && Ks && width > 0 && height > 0));
@@ -1066,7 +1077,7 @@ extern "C" int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* 
   hipLaunchKernelGGL(adam_small_deferred_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
                      (hipStream_t)stream, n, t, (float4*)packed_p, (const float4*)packed_g, g_stamp, blk_last, d,
                      (float)beta1, (float)beta2, ob1, ob2, (float)eps, grad_scale, C, viewmats, Ks, (float)width,
-                     (float)height, eps2d, near_plane, far_plane, flush_all);
+                     (float)height, eps2d, near_plane, far_plane, flush_all, blk_flag);
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

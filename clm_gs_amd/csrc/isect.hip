@@ -1073,7 +1073,11 @@ visibility_bits_kernel(int C, int N, int W64, const float* __restrict__ means,
                        const float* __restrict__ quats_raw, const float* __restrict__ log_scales,
                        const float* __restrict__ viewmats, const float* __restrict__ Ks, float W, float H,
                        float eps2d, float near_plane, float far_plane, float radius_clip,
-                       unsigned long long* __restrict__ bits, int64_t* __restrict__ counts) {
+                       unsigned long long* __restrict__ bits, int64_t* __restrict__ counts,
+                       const uint8_t* __restrict__ blk_flag) {
+  // blk_flag != NULL: one byte per block of 256 rows; 0 = the caller KNOWS that no row of the block passes the cull in any
+  // camera (clmgs_adam_small_deferred's candidate test, a superset of this one): the block's words are zeros, its rows
+  // are not read
   __shared__ float cam_s[VB_MAX_CAMS][VB_CAM_F];
   __shared__ float row_s[256][10];  // mean, raw quaternion, scales of the block's rows
   __shared__ unsigned short cand[256 * VB_CH];  // row | camera-in-group << 8
@@ -1103,7 +1107,8 @@ visibility_bits_kernel(int C, int N, int W64, const float* __restrict__ means,
   float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](int rbn) {
     const int n = rbn * 256 + tid;
-    const int nn = (rbn < n_rb && n < N) ? n : 0;
+    const bool live_n = rbn < n_rb && (!blk_flag || blk_flag[rbn]);
+    const int nn = (live_n && n < N) ? n : 0;
     nm0 = means[3 * nn]; nm1 = means[3 * nn + 1]; nm2 = means[3 * nn + 2];
     nq = *reinterpret_cast<const float4*>(quats_raw + 4 * nn);
     nl0 = log_scales[3 * nn]; nl1 = log_scales[3 * nn + 1]; nl2 = log_scales[3 * nn + 2];
@@ -1116,6 +1121,17 @@ visibility_bits_kernel(int C, int N, int W64, const float* __restrict__ means,
     const float4 q4 = nq;
     const float s0 = __expf(nl0), s1 = __expf(nl1), s2 = __expf(nl2);
     fetch(rb + gridDim.x);
+    if (blk_flag && !blk_flag[rb]) {  // (block-uniform)
+      if (tid < (C + 1) * 4) {
+        const int c = tid >> 2, w = rb * 4 + (tid & 3);
+        if (w < W64) { bits[(size_t)c * W64 + w] = 0ull; counts[(size_t)c * W64 + w] = 0; }
+      }
+      for (int q = tid + 256; q < (C + 1) * 4; q += 256) {  // (more than 63 cameras)
+        const int c = q >> 2, w = rb * 4 + (q & 3);
+        if (w < W64) { bits[(size_t)c * W64 + w] = 0ull; counts[(size_t)c * W64 + w] = 0; }
+      }
+      continue;
+    }
     const float smax = fmaxf(s0, fmaxf(s1, s2));
     const float smax2 = smax * smax;
     // degenerate rows (zero / non-finite quaternion, NaN scale) make the exact projection return
@@ -1244,12 +1260,31 @@ extern "C" size_t clmgs_visibility_select_temp_bytes(int C, int N) {
   return 2 * align_up(words * 8, 256) + max(scan_scratch_bytes((int64_t)words), ctrl) + 256;
 }
 
+extern "C" int clmgs_visibility_select_count_blocks(void* stream, int C, int N, const float* means,
+                                                    const float* quats_raw, const float* log_scales,
+                                                    const float* viewmats, const float* Ks, int width, int height,
+                                                    float eps2d, float near_plane, float far_plane,
+                                                    float radius_clip, void* temp, size_t temp_bytes,
+                                                    int64_t* cum_totals, const uint8_t* block_flags);
+
 extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const float* means,
                                              const float* quats_raw, const float* log_scales,
                                              const float* viewmats, const float* Ks, int width,
                                              int height, float eps2d, float near_plane,
                                              float far_plane, float radius_clip, void* temp,
                                              size_t temp_bytes, int64_t* cum_totals) {
+  return clmgs_visibility_select_count_blocks(stream, C, N, means, quats_raw, log_scales, viewmats, Ks, width, height,
+                                              eps2d, near_plane, far_plane, radius_clip, temp, temp_bytes, cum_totals,
+                                              nullptr);
+}
+
+// block_flags != NULL: one byte per 256 rows, 0 = no row of the block can pass the cull (see visibility_bits_kernel)
+extern "C" int clmgs_visibility_select_count_blocks(void* stream, int C, int N, const float* means,
+                                                    const float* quats_raw, const float* log_scales,
+                                                    const float* viewmats, const float* Ks, int width, int height,
+                                                    float eps2d, float near_plane, float far_plane,
+                                                    float radius_clip, void* temp, size_t temp_bytes,
+                                                    int64_t* cum_totals, const uint8_t* block_flags) {
   CLMGS_CHECK_ARG(C >= 1 && C <= 64 && N >= 1 && width > 0 && height > 0);  // bsz <= 64 (engine.py)
   CLMGS_CHECK_ARG(means && quats_raw && log_scales && viewmats && Ks && temp && cum_totals);
   CLMGS_CHECK_ARG(temp_bytes >= clmgs_visibility_select_temp_bytes(C, N));
@@ -1262,7 +1297,7 @@ extern "C" int clmgs_visibility_select_count(void* stream, int C, int N, const f
   int64_t* scratch = (int64_t*)base;
   hipLaunchKernelGGL(visibility_bits_kernel, dim3(min(ceil_div((int64_t)W64 * 64, 256), 256 * 8)),
                      dim3(256), 0, s, C, N, W64, means, quats_raw, log_scales, viewmats, Ks,
-                     (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, bits, counts);
+                     (float)width, (float)height, eps2d, near_plane, far_plane, radius_clip, bits, counts, block_flags);
   CLMGS_LAUNCH_CHECK();
   int rc;
 #ifdef CLMGS_PROFILE_BUILD

@@ -117,7 +117,7 @@ def visibility_radii(means, quats, scales, viewmats, Ks, width, height, eps2d=0.
 
 
 def visibility_select(means, quats_raw, log_scales, viewmats, Ks, width, height, eps2d=0.3,
-                      near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+                      near_plane=0.01, far_plane=1e10, radius_clip=0.0, block_flags=None):
     """The batch's visibility filters selected on the GPU: same cull as visibility_radii(raw=True)
     but without the radii[C,N] round trip and torch.nonzero -- one ballot word per (camera, 64
     Gaussians), a scan, and an emit pass.  -> (filters: tuple of C int64 index tensors (ascending),
@@ -130,10 +130,11 @@ def visibility_select(means, quats_raw, log_scales, viewmats, Ks, width, height,
     tb = L.clmgs_visibility_select_temp_bytes(C, N)
     temp = torch.empty((tb,), dtype=torch.uint8, device=dev)
     cum = torch.empty((C + 1,), dtype=I64, device=dev)
-    check(L.clmgs_visibility_select_count(
+    # block_flags (uint8 per 256 rows, 0 = no row of the block can be visible: clmgs_adam_small_deferred's candidate test)
+    check(L.clmgs_visibility_select_count_blocks(
         stream(), C, N, dptr(means, F32), dptr(quats_raw, F32), dptr(log_scales, F32), dptr(viewmats, F32),
         dptr(Ks, F32), int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
-        float(radius_clip), dptr(temp), tb, dptr(cum)))
+        float(radius_clip), dptr(temp), tb, dptr(cum), dptr(block_flags, torch.uint8, True)))
     _t0 = time.perf_counter()
     ends = cum.tolist()  # the one host sync of the filter stage
     _lib.STATS["host_wait_s"] += time.perf_counter() - _t0

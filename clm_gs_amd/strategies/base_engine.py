@@ -13,7 +13,7 @@ LAMBDA_DSSIM = 0.2
 TILE_SIZE = 16
 
 
-def select_filters(batched_cameras, xyz_gpu, scaling_raw_gpu, rotation_raw_gpu):
+def select_filters(batched_cameras, xyz_gpu, scaling_raw_gpu, rotation_raw_gpu, block_flags=None):
     """calculate_filters on the stored (raw) parameters, selected entirely on the GPU
     (gsplat.visibility_select) -> (filters, touched_rows): the same index sets as calculate_filters
     plus the union over the batch's cameras."""
@@ -24,7 +24,7 @@ def select_filters(batched_cameras, xyz_gpu, scaling_raw_gpu, rotation_raw_gpu):
         viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in batched_cameras])
         filters, touched_rows = visibility_select(
             xyz_gpu, rotation_raw_gpu, scaling_raw_gpu, viewmats, Ks, int(utils.get_img_width()),
-            int(utils.get_img_height()), radius_clip=args.radius_clip)
+            int(utils.get_img_height()), radius_clip=args.radius_clip, block_flags=block_flags)
     assert all(f.numel() > 0 for f in filters), (
         "every camera must see at least one gaussian (base_engine.py:64-67)")
     return filters, touched_rows

@@ -296,16 +296,17 @@ def _stage_visibility(b):
     # see are brought up to date BEFORE the visibility pass reads them
     b.small_deferred = bool(getattr(gaussians, "small_deferred", False) and b.fused and gaussians.lazy_rows
                             and not args.stop_update_param and getattr(args, "packed_small", True))
+    blk_flags = None
     if b.small_deferred:
         with torch.no_grad():
-            gaussians.small_catch_up(cams)
+            blk_flags = gaussians.small_catch_up(cams)  # (also: which blocks of 256 rows can hold a visible row at all)
     with torch.no_grad():
         if b.fused:
             # same fast exp as the fused front end -> filter and render agree on every cull;
             # filters AND the union of touched rows are selected on the GPU in one pass
             with _lib.host_region("select_filters"):
                 b.filters, b.touched_rows = select_filters(cams, gaussians._xyz.detach(), gaussians._scaling.detach(),
-                                                           gaussians._rotation.detach())
+                                                           gaussians._rotation.detach(), block_flags=blk_flags)
         else:
             b.filters, _, _ = calculate_filters(cams, gaussians.get_xyz, gaussians.get_opacity,
                                                 gaussians.get_scaling, gaussians.get_rotation)

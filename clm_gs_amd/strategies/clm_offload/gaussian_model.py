@@ -371,7 +371,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         from ... import _lib
         sd = self._small_def
         if not sd["hist"] or (cameras is None and self._small_def_clean()):
-            return
+            return None
         opt = self.optimizer
         groups = {g["name"]: g for g in opt.gpu_adam.param_groups}
         order = [groups[n_] for n_ in ("xyz", "opacity", "scaling", "rotation")]
@@ -395,9 +395,12 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         arr = lambda xs: (ctypes.c_void_p * 4)(*xs)
         pk, gk, blk = self.small_packed(), self.small_grad(), self._small_def_tables()
         b1, b2 = order[0]["betas"]
-        C, vm, Ks = 0, None, None
+        C, vm, Ks, flags = 0, None, None, None
         if cameras is not None:
             C = len(cameras)
+            flags = sd.get("blk_flag")
+            if flags is None or flags.shape[0] != blk.shape[0]:
+                flags = sd["blk_flag"] = torch.empty((blk.shape[0],), dtype=torch.uint8, device=blk.device)
             Ks = torch.stack([c.create_k_on_gpu() if getattr(c, "K", None) is None else c.K for c in cameras]).contiguous()
             vm = torch.stack([c.world_view_transform.transpose(0, 1) for c in cameras]).contiguous()
         _lib.check(_lib.lib().clmgs_adam_small_deferred(
@@ -405,9 +408,10 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             _lib.dptr(self._row_g_step, torch.int32), _lib.dptr(blk, torch.int32), int(hist[0][0]), nh, lr, sidx,
             pos_margin, scale_gain, float(b1), float(b2), float(order[0]["eps"]), 1.0 / float(self.args.bsz), C,
             _lib.dptr(vm, None, True), _lib.dptr(Ks, None, True), int(utils.get_img_width()), int(utils.get_img_height()),
-            0.3, 0.01, 1e10, 0 if cameras is not None else 1))
+            0.3, 0.01, 1e10, 0 if cameras is not None else 1, _lib.dptr(flags, torch.uint8, True)))
         if cameras is None:
             self._small_def_dirty = False
+        return flags
 
     def flush_small(self):
         """Every block brought to the newest recorded step: the four tensors (and the mirror) are what an eager run holds."""

@@ -63,6 +63,14 @@ int clmgs_visibility_select_count(void* stream, int C, int N, const float* means
                                   const float* viewmats, const float* Ks, int width, int height,
                                   float eps2d, float near_plane, float far_plane, float radius_clip,
                                   void* temp, size_t temp_bytes, int64_t* cum_totals);
+/* The same with what the caller already knows about blocks of 256 consecutive rows: block_flags[ceil(N/256)], 0 = no row
+ * of the block passes the cull in any camera (clmgs_adam_small_deferred computes such flags with a superset test).  The
+ * flagged-off blocks are not read; the result is the unflagged call's, bit for bit.  NULL: as above. */
+int clmgs_visibility_select_count_blocks(void* stream, int C, int N, const float* means, const float* quats_raw,
+                                         const float* log_scales, const float* viewmats, const float* Ks, int width,
+                                         int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                         void* temp, size_t temp_bytes, int64_t* cum_totals,
+                                         const uint8_t* block_flags);
 int clmgs_visibility_select_emit(void* stream, int C, int N, const void* temp, int64_t* out);
 /* VJP of the above.  v_means[N,3], v_quats[N,4], v_scales[N,3] are overwritten
  * with the sum over the C cameras. */
@@ -468,7 +476,9 @@ int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* params, flo
                               int32_t* blk_last, int to_step, int n_hist, const double* lr4_hist,
                               const int32_t* step_index, const float* pos_margin, const float* scale_gain, double beta1,
                               double beta2, double eps, float grad_scale, int C, const float* viewmats, const float* Ks,
-                              int width, int height, float eps2d, float near_plane, float far_plane, int flush_all);
+                              int width, int height, float eps2d, float near_plane, float far_plane, int flush_all,
+                              uint8_t* blk_flag /* optional [ceil(n/256)] out: 0 = no row of the block can be visible in
+                              any of the C cameras; input of clmgs_visibility_select_count_blocks */);
 
 /* Profiling aid: counters of the CLMGS_BWD_DEBUG=3 variant of the backward tile kernel. */
 int clmgs_debug_counters(unsigned long long* out16, int reset);

@@ -1,7 +1,6 @@
 set -x
-O=gpurun_out/r05q; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_engines.py tests/test_gpu_golden_engine.py -q -x 2>&1 | tail -5
-bash profiles/solo_trace.sh r05q > /dev/null 2>&1; grep -E "isect3|adam" gpurun_out/r4/solo_kernel_stats_r05q.csv | cut -c1-200
+O=gpurun_out/r05r; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_engines.py tests/test_gpu_golden_engine.py tests/test_gpu_fullsize.py -q -x 2>&1 | tail -5
 B="--steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-trainer-leg --no-heavy-leg --gt resident --prime-seconds 5"
 for rep in 1 2; do
 timeout 300 python bench.py $B 2>/dev/null | python -c "
