@@ -262,6 +262,13 @@ adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
 // (bias corrections come from a running product in float instead of a double pow: ~1e-7 relative).
 // Steps older than max_replay are folded analytically (m *= b1^d, v *= b2^d): their parameter
 // increments are below half an ulp of p by then.
+// beta^x for the bias corrections of the deferred steps: v_exp_f32(x * v_log_f32(beta)) -- three instructions; libm's powf
+// is ~80 and was called four to six times per thread (round 5: the kernel issued ~1 G wave instructions per batch,
+// a third of its run time at the issue peak).  Relative error ~1e-6 at the step counts where 1 - beta^x is not yet 1.
+__device__ __forceinline__ float pow_beta(float beta, float x) {
+  return __builtin_amdgcn_exp2f(x * __builtin_amdgcn_logf(beta));
+}
+
 template <typename IdxT, int VEC>
 __global__ void __launch_bounds__(256)
 adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -306,7 +313,7 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
       const int missed = to - from;
       if (missed <= 0) return;
       const int n = min(missed, max_replay);
-      float pw1 = powf(beta1, (float)(from + 1)), pw2 = powf(beta2, (float)(from + 1));
+      float pw1 = pow_beta(beta1, (float)(from + 1)), pw2 = pow_beta(beta2, (float)(from + 1));
       for (int j = 0; j < n; ++j) {
         float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
         if (bias_correction) {
@@ -323,7 +330,7 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
       }
       if (missed > n) {
         const int d = missed - n;
-        const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
+        const float f1 = pow_beta(beta1, (float)d), f2 = pow_beta(beta2, (float)d);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
       }
@@ -332,8 +339,8 @@ adam_catch_up_kernel(float* __restrict__ p, float* __restrict__ m, float* __rest
       replay(a, gs - 1);
       float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
       if (bias_correction) {
-        inv_bc1 = 1.f / (1.f - powf(beta1, (float)gs));
-        inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(beta2, (float)gs));
+        inv_bc1 = 1.f / (1.f - pow_beta(beta1, (float)gs));
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - pow_beta(beta2, (float)gs));
       }
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
@@ -407,7 +414,7 @@ adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __re
       const int missed = to - from;
       if (missed <= 0) return;
       const int n = min(missed, max_replay);
-      float pw1 = powf(beta1, (float)(from + 1)), pw2 = powf(beta2, (float)(from + 1));
+      float pw1 = pow_beta(beta1, (float)(from + 1)), pw2 = pow_beta(beta2, (float)(from + 1));
       for (int j = 0; j < n; ++j) {
         float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
         if (bias_correction) {
@@ -424,7 +431,7 @@ adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __re
       }
       if (missed > n) {
         const int d = missed - n;
-        const float f1 = powf(beta1, (float)d), f2 = powf(beta2, (float)d);
+        const float f1 = pow_beta(beta1, (float)d), f2 = pow_beta(beta2, (float)d);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) { mm[c] *= f1; vv[c] *= f2; }
       }
@@ -433,8 +440,8 @@ adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __re
       replay(a, gs - 1);
       float inv_bc1 = 1.f, inv_sqrt_bc2 = 1.f;
       if (bias_correction) {
-        inv_bc1 = 1.f / (1.f - powf(beta1, (float)gs));
-        inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(beta2, (float)gs));
+        inv_bc1 = 1.f / (1.f - pow_beta(beta1, (float)gs));
+        inv_sqrt_bc2 = 1.f / sqrtf(1.f - pow_beta(beta2, (float)gs));
       }
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
