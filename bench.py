@@ -168,6 +168,8 @@ def parse():
                     help="skip the third leg: clm_gs_amd.trainer.training on the bench scene (densify + opacity reset inside the "
                          "end-to-end clock) -> trainer_img_s / trainer_peak_gpu_bytes")
     ap.add_argument("--trainer-images", type=int, default=400)
+    ap.add_argument("--trainer-trace", action="store_true",
+                    help="diagnosis: drain the device after every trainer iteration / model method and report where time and hipMallocs go")
     ap.add_argument("--trainer-grad-threshold", type=float, default=0.0002)
     ap.add_argument("--no-preflight", action="store_true",
                     help="--gpus > 1: skip the camera-DP pre-flight (clm_gs_amd/dp_preflight.py: the exchange's collectives, the "
@@ -545,6 +547,47 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
     class _Scene:
         cameras_extent = extent
     log, phases = io.StringIO(), {}
+    trace = None
+    if a.trainer_trace:
+        # diagnosis (NOT the reported figure: it drains the device after every iteration and around every model method):
+        # true time per iteration, device mallocs and reserved bytes after it, and the structural methods one by one
+        trace = {"iter": [], "methods": {}}
+        t_last = [time.perf_counter()]
+        seen = {(sg["address"], sg["total_size"]) for sg in torch.cuda.memory_snapshot()}
+        trace["new_segments"] = []
+        n_alloc = [torch.cuda.memory_stats()["num_device_alloc"]]
+
+        def hook(it):
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            st = torch.cuda.memory_stats()
+            if st["num_device_alloc"] != n_alloc[0]:  # which pool / stream asked the device for memory, and how much
+                n_alloc[0] = st["num_device_alloc"]
+                for sg in torch.cuda.memory_snapshot():
+                    key = (sg["address"], sg["total_size"])
+                    if key not in seen:
+                        seen.add(key)
+                        trace["new_segments"].append([it, sg["total_size"], sg["segment_type"], sg["stream"],
+                                                      max((b["size"] for b in sg["blocks"]), default=0)])
+            trace["iter"].append([it, round(1e3 * (now - t_last[0]), 2), int(st["num_device_alloc"]),
+                                  round(st["reserved_bytes.all.current"] / 1e9, 2), round(st["allocated_bytes.all.peak"] / 1e9, 2)])
+            t_last[0] = time.perf_counter()
+        phases["iter_hook"] = hook
+
+        def timed(name, fn):
+            def wrap(*aa, **kk):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                r = fn(*aa, **kk)
+                torch.cuda.synchronize()
+                st = torch.cuda.memory_stats()
+                trace["methods"].setdefault(name, []).append([round(1e3 * (time.perf_counter() - t_), 2), int(st["num_device_alloc"])])
+                return r
+            return wrap
+        for name in ("flush_lazy_rows", "flush_small", "densify_and_clone", "densify_and_split", "prune_points", "permute_rows",
+                     "reset_opacity", "densify_and_prune", "spatial_sort", "_append_rows", "_regather_row_tables"):
+            if hasattr(g, name):
+                setattr(g, name, timed(name, getattr(g, name)))
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     timer = trainer.training(g, _Scene, cams, [], log, iterations=n_img, test_iterations=(n_img,), phase_times=phases)
@@ -581,6 +624,12 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
                    "the end-to-end clock starts like the reference's --prealloc_capacity buffers, its wall time reported as "
                    "host_seconds_by_phase.reserve); loss lines written one batch late (defer_loss_log) so the host never "
                    "drains the device between batches"}
+    if trace is not None:
+        steady = sorted(x[1] for x in trace["iter"])
+        out["trace"] = {"median_iteration_ms": steady[len(steady) // 2],
+                        "slow_iterations": [x for x in trace["iter"] if x[1] > 1.5 * steady[len(steady) // 2]],
+                        "first_iterations": trace["iter"][:4], "last_iteration": trace["iter"][-1],
+                        "methods_ms_mallocs": trace["methods"], "new_segments": trace["new_segments"], "mallocs_at_start": int(ms0.get("num_device_alloc", 0))}
     del g
     gc.collect()
     torch.cuda.empty_cache()
@@ -636,7 +685,7 @@ def heavy_leg(a):
             "loss_first_last": [j["measured"]["loss_first"], j["measured"]["loss_last"]],
             "roofline_frac": (j.get("roofline") or {}).get("frac"), "roofline_frac_solo": (j.get("roofline") or {}).get("frac_solo"),
             "tile_kernels_solo_ms": {k: solo.get(k) for k in ("clmgs_rasterize_fwd", "clmgs_rasterize_bwd")},
-            "binning_solo_ms": {k: solo.get(k) for k in ("clmgs_isect2_order_count", "clmgs_isect2_emit_sort")},
+            "binning_solo_ms": {k: v for k, v in solo.items() if "isect" in k},
             "wall_s": round(time.perf_counter() - t0, 1)}
 
 

@@ -73,6 +73,8 @@ SIGNATURES = {
     "clmgs_memcpy_async": (_i, [_vp, _vp, _vp, _sz, _i]),
     "clmgs_host_rows_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _d, _d, _d, _i, _i, _i, _f, _i, _vp, _i]),
     "clmgs_densify_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "clmgs_morton_order_temp_bytes": (_sz, [_i64]),
+    "clmgs_morton_order": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _sz]),
     "clmgs_tsp_tour": (_i, [_i, _vp, _vp]),
     "clmgs_knn3_mean_dist2": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
     "clmgs_host_groups_temp_bytes": (_sz, [_i64]),

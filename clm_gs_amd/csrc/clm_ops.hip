@@ -855,6 +855,69 @@ extern "C" int clmgs_host_groups(void* stream, int64_t n, const int64_t* touched
   return 0;
 }
 
+// ---- storage order of the rows: Z-order (Morton) curve of (x, y), 16 bits per axis (clm_gs_amd/utils.py morton_order)
+// code = spread(qx) | spread(qy) << 1,  q = rint((double(p) - lo) / max(hi - lo, 1e-30) * 65535)  -- the IEEE double
+// operations of the torch form, one pass instead of ~25 elementwise passes over [N] int64 / double temporaries -- then
+// the stable LSD radix sort of radix.h on (code, row) pairs and the row ids widened to int64.
+__device__ __forceinline__ uint32_t spread16(uint32_t v) {
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+morton_keys_kernel(int64_t n, const float* __restrict__ xyz, const double* __restrict__ lohi,
+                   uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  const double lx = lohi[0], ly = lohi[1];
+  const double dx = fmax(lohi[2] - lx, 1e-30), dy = fmax(lohi[3] - ly, 1e-30);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double qx = rint(((double)xyz[3 * i] - lx) / dx * 65535.0);
+    const double qy = rint(((double)xyz[3 * i + 1] - ly) / dy * 65535.0);
+    const uint32_t ix = (uint32_t)(long long)qx & 0xFFFFu, iy = (uint32_t)(long long)qy & 0xFFFFu;
+    keys[i] = spread16(ix) | (spread16(iy) << 1);
+    vals[i] = (int32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+widen_i32_kernel(int64_t n, const int32_t* __restrict__ src, int64_t* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (int64_t)src[i];
+}
+
+extern "C" size_t clmgs_morton_order_temp_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return 5 * align_up((size_t)n * 4, 256) + radix_table_bytes(n) + 256;
+}
+
+extern "C" int clmgs_morton_order(void* stream, int64_t n, const float* xyz, const double* lo_hi, int64_t* order,
+                                  void* temp, size_t temp_bytes) {
+  CLMGS_CHECK_ARG(n >= 0);
+  if (n == 0) return 0;
+  CLMGS_CHECK_ARG(n < ((int64_t)1 << 31) && xyz && lo_hi && order && temp);
+  CLMGS_CHECK_ARG(temp_bytes >= clmgs_morton_order_temp_bytes(n));
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)temp;
+  const size_t a4 = align_up((size_t)n * 4, 256);
+  uint32_t* ka = (uint32_t*)base; base += a4;
+  uint32_t* kb = (uint32_t*)base; base += a4;
+  int32_t* va = (int32_t*)base; base += a4;
+  int32_t* vb = (int32_t*)base; base += a4;
+  int32_t* vf = (int32_t*)base; base += a4;
+  uint32_t* table = (uint32_t*)base;
+  const int grid = (int)min(ceil_div(n, 256), (int64_t)256 * 16);
+  hipLaunchKernelGGL(morton_keys_kernel, dim3(grid), dim3(256), 0, s, n, xyz, lo_hi, ka, va);
+  CLMGS_LAUNCH_CHECK();
+  uint32_t* sorted = nullptr;
+  int rc = radix_sort_pairs<uint32_t, int32_t>(s, n, ka, kb, va, vb, vf, 0, 32, table, &sorted);
+  if (rc) return rc;
+  hipLaunchKernelGGL(widen_i32_kernel, dim3(grid), dim3(256), 0, s, n, vf, order);
+  CLMGS_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int clmgs_extract_ffs(void* stream, const void* bitmap, int elem_bytes, int64_t N,
                                  uint8_t* ffs) {
   CLMGS_CHECK_ARG(N >= 0);
@@ -927,7 +990,7 @@ extern "C" int clmgs_adam_catch_up(void* stream, float* p, float* m, float* v,
   CLMGS_CHECK_ARG(p && m && v && last_step && col_lr && ((g != nullptr) == (g_step != nullptr)));
   const bool v4 = (cols % 4 == 0) &&
                   (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)col_lr | (uintptr_t)g) & 15) == 0;
-  if (v4 && cols == 48 && n_rows < ((int64_t)1 << 27) && !getenv("CLMGS_CATCH_UP_GENERIC")) {  // (12 n < 2^32)
+  if (v4 && cols == 48 && n_rows < ((int64_t)1 << 27)) {  // (12 n < 2^32)
     int grid48 = (int)min(ceil_div(n_rows * 12, 256), (int64_t)4095);
     grid48 = (grid48 + 2) / 3 * 3;
 #define CLMGS_CATCH_UP48(I)                                                                          \

@@ -259,9 +259,12 @@ def reserve_working_set(gaussians, n_cameras_in_flight=2):
     k = int(n_cameras_in_flight)
     sts = _pipeline_streams(gaussians)
     plan = {
-        "front": (sts["mem"][0], k * (20 * P + 56 * I + 96 * V)),      # image / alpha / last ids, lists + sort space, records
+        # (the lists grow with the model: 1.25x head room, or the growth of iteration ~370 of the bench leg asks the device)
+        "front": (sts["mem"][0], k * (20 * P + 70 * I + 96 * V)),      # image / alpha / last ids, lists + sort space, records
         "mem": (sts["mem"][1], k * 48 * P + (1 << 20)),                 # SSIM derivative maps + the loss cotangent
-        "raster": (sts["raster"][0], k * 64 * I),                       # one partial-gradient line per intersection
+        # one partial-gradient line per intersection; a camera's buffer lives until its row sums are taken (preprocess_bwd,
+        # on the other stream type): up to 2 k buffers are alive at once
+        "raster": (sts["raster"][0], 2 * k * 64 * int(0.8 * I)),
         # default stream: filters and touched-row lists of a batch, and the temporaries of a densification -- masks,
         # selections, the Z-order keys and their sort, and the per-row tensors (parameters + moments 132 B, packed mirror /
         # gradient / statistics tables 112 B per row), which are re-created BEFORE their predecessors are freed

@@ -25,6 +25,20 @@ from ..base_gaussian_model import BaseGaussianModel
 _ROW_BUFFERS = ("parameters_buffer", "parameters_grad_buffer", "_exp_avg_buffer", "_exp_avg_sq_buffer")
 
 
+def _gather_f32(t, idx):
+    """t[idx] (int64 row ids on the GPU) for a per-row float32 tensor [N] / [N,c], by the library's row mover: one launch
+    per tensor (utils.take_rows goes through torch's advanced indexing in chunks of 2^23 indices -- its defect beyond 2^26
+    -- with a temporary per chunk: ~8 launches per tensor, and a structural change moves fifteen such tensors)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and idx.dtype == torch.int64):
+        return utils.take_rows(t, idx).contiguous()
+    from ... import clm_kernels
+    m = idx.numel()
+    out = torch.empty((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if m:
+        clm_kernels._rows("clmgs_rows_gather", out.view(m, -1), t.view(t.shape[0], -1), None, idx.contiguous(), 0)
+    return out
+
+
 def dp_range(n):
     from ... import dp
     return dp.owner_range(n)
@@ -158,7 +172,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         n = self._xyz.shape[0]
         pk = getattr(self, "_small_pk", None)
         if pk is None or pk.shape[0] != n or getattr(self, "_small_key", None) != key:
-            pk = torch.empty((n, 12), dtype=torch.float32, device=self._xyz.device)
+            pk = self._row_mirror("pk", 12, n)
             t = [p.detach().contiguous() for p in self._small_tensors()]
             _lib.check(_lib.lib().clmgs_pack_small(_lib.stream(), n, *[_lib.dptr(x) for x in t], _lib.dptr(pk)))
             self._small_pk, self._small_key = pk, key
@@ -169,8 +183,23 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         n = self._xyz.shape[0]
         g = getattr(self, "_small_gk", None)
         if g is None or g.shape[0] != n:
-            g = self._small_gk = torch.zeros((n, 12), dtype=torch.float32, device=self._xyz.device)
+            g = self._small_gk = self._row_mirror("gk", 12, n)
+            g.zero_()
         return g
+
+    def _row_mirror(self, name, cols, n):
+        """[:n] of a persistent [capacity, cols] table: the per-row side tables (packed mirror, packed gradients,
+        statistics deltas) are sized like the row tables -- prealloc_capacity head room -- so that a densification, which
+        changes n by a fraction of a percent, re-uses them.  (Allocated at exactly n rows they were re-allocated after
+        every densification and the old blocks, a few rows too small for their successors, stayed cached: 2.7 GB of
+        reserved memory more per densification at 28 M rows, bench.py --trainer-trace.)"""
+        bufs = self.__dict__.setdefault("_mirrors", {})
+        buf = bufs.get(name)
+        if buf is None or buf.shape[0] < n or buf.device != self._xyz.device:
+            cap = max(n, int(getattr(self, "parameters_buffer", torch.empty(0)).shape[0]))
+            bufs[name] = buf = None  # (the old table is released before its successor is requested)
+            buf = bufs[name] = torch.empty((cap, cols), dtype=torch.float32, device=self._xyz.device)
+        return buf[:n]
 
     def invalidate_small_packed(self):
         self._small_key = None
@@ -183,7 +212,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         d = getattr(self, "_stats_d", None)
         if d is None or d.shape[0] != n:
             self.merge_stats()
-            d = self._stats_d = torch.zeros((n, 4), dtype=torch.float32, device=self._xyz.device)
+            d = self._stats_d = self._row_mirror("stats", 4, n)
+            d.zero_()
         self._stats_dirty = True
         return d
 
@@ -789,9 +819,9 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         else:
             idx = torch.nonzero(keep).flatten()
             if resort and m:
-                idx = utils.take_rows(idx, utils.morton_order(utils.take_rows(self._xyz.detach(), idx)))
+                idx = utils.take_rows(idx, utils.morton_order(_gather_f32(self._xyz.detach(), idx)))
             self._regather_row_tables(idx, m)
-            pick = lambda t: utils.take_rows(t, idx).contiguous()
+            pick = lambda t: _gather_f32(t, idx)
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
             self._replace_gpu(name, attr, pick(cur), pick)
@@ -823,19 +853,21 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                 buf[:n].copy_(utils.gather_rows(buf[:n], order_rows))  # out of place, one table at a time
         else:
             self._regather_row_tables(order.to(torch.int64), n)
+        order64 = order.to(torch.int64)
+        pick = lambda t: _gather_f32(t.contiguous(), order64)  # (host / non-float tensors: utils.take_rows)
         for name, attr in self._GPU_GROUPS:
             cur = getattr(self, attr).detach()
             if self.optimizer is not None:
-                self._replace_gpu(name, attr, utils.gather_rows(cur, order), lambda s: utils.gather_rows(s, order))
+                self._replace_gpu(name, attr, pick(cur), pick)
             else:
-                setattr(self, attr, nn.Parameter(utils.gather_rows(cur, order).requires_grad_(True)))
+                setattr(self, attr, nn.Parameter(pick(cur).requires_grad_(True)))
         if self.optimizer is not None:
             self._rebind_row_state(n)
-            self.xyz_gradient_accum = utils.gather_rows(self.xyz_gradient_accum, order)
-            self.denom = utils.gather_rows(self.denom, order)
+            self.xyz_gradient_accum = pick(self.xyz_gradient_accum)
+            self.denom = pick(self.denom)
         else:
             self._bind_rows(n)
-        self.max_radii2D = utils.gather_rows(self.max_radii2D, order)
+        self.max_radii2D = pick(self.max_radii2D)
         self.invalidate_small_packed()
 
     def _shs48_rows(self, mask):

@@ -135,12 +135,68 @@ class _LossLog:
             self.pending = None
 
 
+def _warm_structural_ops(device, n=70_000):
+    """The torch operators of a densification (masks, selections, concatenations, the split's sampling, the Z-order
+    keys) run ONCE on small tensors.  ROCm loads device code lazily, at the first launch out of each code object: the
+    first densify_and_prune of a process paid 110-130 ms for that on top of its 30 ms of work (bench.py --trainer-trace),
+    inside the end-to-end clock.  SETUP, like the allocator reservation below; private generator (the global random
+    stream and the model's split generator are not touched), nothing of the model is read or written."""
+    from .utils import build_rotation, inverse_sigmoid, morton_order, select_rows, take_rows
+    with torch.no_grad():
+        gen = torch.Generator(device=device)
+        gen.manual_seed(0)
+        acc = torch.rand((n, 1), device=device, generator=gen)
+        den = (torch.rand((n, 1), device=device, generator=gen) > 0.3).float()
+        mr = torch.zeros((n,), device=device)
+        d4 = torch.rand((n, 4), device=device, generator=gen)
+        mr = torch.maximum(mr, d4[:, 0]); acc = acc + d4[:, 1:2]; den = den + d4[:, 2:3]; d4.zero_()
+        grads = acc / den
+        grads[grads.isnan()] = 0.0
+        xyz = torch.randn((n, 3), device=device, generator=gen)
+        scal = torch.randn((n, 3), device=device, generator=gen) - 3.0
+        rot = torch.randn((n, 4), device=device, generator=gen)
+        opa = torch.randn((n, 1), device=device, generator=gen)
+        shs = torch.rand((n, 48), device=device, generator=gen)
+        sel = torch.norm(grads, dim=-1) >= 0.5
+        sel &= torch.max(torch.exp(scal), dim=1).values <= 0.06
+        k = int(sel.sum())
+        new = [select_rows(t, sel) for t in (xyz, shs, opa, scal, rot)]
+        cat = [torch.cat((t, e), dim=0) for t, e in zip((xyz, shs, opa, scal, rot), new)]
+        mom = torch.cat((torch.zeros_like(xyz), torch.zeros_like(new[0])), dim=0)
+        padded = torch.zeros((n + k,), device=device)
+        padded[:n] = grads.squeeze()
+        sel2 = padded >= 0.5
+        sel2 &= torch.max(torch.exp(cat[3]), dim=1).values > 0.06
+        stds = select_rows(torch.exp(cat[3]), sel2).repeat(2, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=gen)
+        rots = build_rotation(select_rows(cat[4], sel2)).repeat(2, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + select_rows(cat[0], sel2).repeat(2, 1)
+        new_scal = torch.log(select_rows(torch.exp(cat[3]), sel2).repeat(2, 1) / 1.6)
+        prune = torch.cat((sel2, torch.zeros(2 * int(sel2.sum()), device=device, dtype=torch.bool)))
+        xyz2 = torch.cat((cat[0], new_xyz), dim=0)
+        opa2 = torch.cat((cat[2], select_rows(cat[2], sel2).repeat(2, 1)), dim=0)
+        scal2 = torch.cat((cat[3], new_scal), dim=0)
+        mask = (torch.sigmoid(opa2) < 0.005).squeeze()
+        mask = torch.logical_or(mask, torch.exp(scal2).max(dim=1).values > 0.1)
+        mask = torch.logical_or(mask, prune)
+        keep = ~mask
+        m = int(keep.sum())
+        idx = torch.nonzero(keep).flatten()
+        idx = take_rows(idx, morton_order(take_rows(xyz2, idx)))
+        stamps = torch.zeros((xyz2.shape[0],), dtype=torch.int32, device=device)
+        stamps[:m] = 7
+        new_opa = inverse_sigmoid(torch.min(torch.sigmoid(opa2), torch.ones_like(opa2) * 0.01))
+        _ = (torch.zeros_like(new_opa), mom, mr, idx, stamps)
+    torch.cuda.synchronize()
+
+
 def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations=None,
              test_iterations=(), background=None, shuffle_seed=0, phase_times=None):
     """Runs `iterations` images of training; returns the End2endTimer.
     `phase_times` (optional dict): host wall time per phase inside the end-to-end clock is accumulated into it
     ("engine" = enqueueing the batches, "densify" = gsplat_densification incl. the device work it waits for,
-    "resort" = the Z-order re-sort after a densification, "log" = waiting for loss values, "final_sync").
+    "resort" = the Z-order re-sort after a densification, "log" = waiting for loss values, "final_sync"); a callable under
+    "iter_hook" is removed from the dict and called with the image counter after every iteration (diagnosis).
 
     Camera-DP: when a process group is up every rank runs this same loop over the
     same shuffled order, takes cameras rank::ranks of each GLOBAL batch (bsz x ranks images), and
@@ -219,6 +275,7 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
     defer = bool(getattr(args, "defer_loss_log", True))
     loss_log = _LossLog(log_file, defer)
     pt = phase_times if phase_times is not None else {}
+    iter_hook = pt.pop("iter_hook", None)  # diagnosis only (bench.py --trainer-trace): called after every iteration
 
     def _acc(key, t_start):
         pt[key] = pt.get(key, 0.0) + time.perf_counter() - t_start
@@ -233,6 +290,10 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
         pt["reserved_bytes"] = float(sum(reserve_working_set(gaussians).values()))
         torch.cuda.synchronize()
         _acc("reserve", _t)
+        if not args.disable_auto_densification and getattr(args, "warm_structural_ops", True):
+            _t = time.perf_counter()
+            _warm_structural_ops(gaussians._xyz.device)
+            _acc("warm_ops", _t)
     timer = End2endTimer()
     timer.start()
     next_batch = None
@@ -317,6 +378,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             gaussians.optimizer.zero_grad(set_to_none=True)
         if not defer:
             torch.cuda.synchronize()
+        if iter_hook is not None:
+            iter_hook(iteration)
     _t = time.perf_counter()
     loss_log.flush()
     timer.stop()

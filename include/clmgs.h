@@ -406,6 +406,14 @@ int clmgs_densify_stats(void* stream, int64_t n, const int64_t* filter, const fl
                         float* max_radii2D,
                         float* xyz_gradient_accum, float* denom);
 
+/* ---- storage order of the rows (no reference counterpart; clm_gs_amd/utils.py morton_order, trainer / densification):
+ * order[i] = the row that comes i-th along the Z-order curve of (x, y), 16 bits per axis, ties in row order (stable):
+ * code = spread(qx) | spread(qy) << 1 with q = rint((double(p) - lo) / max(hi - lo, 1e-30) * 65535); lo_hi (device) =
+ * lo_x lo_y hi_x hi_y as doubles.  xyz [n,3] f32, order [n] i64, temp: clmgs_morton_order_temp_bytes(n); n < 2^31. */
+size_t clmgs_morton_order_temp_bytes(int64_t n);
+int clmgs_morton_order(void* stream, int64_t n, const float* xyz, const double* lo_hi, int64_t* order, void* temp,
+                       size_t temp_bytes);
+
 /* ---- fast_tsp.find_tour  (clm_offload/engine.py:179): open-tour heuristic on an n x n
  * integer distance matrix (greedy nearest neighbour + 2-opt until no improvement). */
 int clmgs_tsp_tour(int n, const int64_t* dist, int32_t* tour);

@@ -1,8 +1,7 @@
-set -x
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_engines.py tests/test_gpu_golden_engine.py tests/test_abi.py -q 2>&1 | tail -5
-B="--steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-trainer-leg --no-heavy-leg --gt resident --prime-seconds 5"
-for rep in 1 2; do
-timeout 300 python bench.py $B 2>/dev/null | python -c "
-import sys,json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['measured']['loss_last'], {k.replace('clmgs_',''):round(v,3) for k,v in d['kernels_solo_ms'].items() if 'adam' in k}, {k.replace('clmgs_',''):v['avg_ms'] for k,v in d['kernels'].items() if 'adam' in k})"
-done
+#!/bin/bash
+O=gpurun_out/r05t; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "morton or row_mover" > $O/pytest_a.log 2>&1; tail -3 $O/pytest_a.log
+timeout 900 python -m pytest tests/test_gpu_engines.py tests/test_gpu_golden_engine.py -q -x > $O/pytest_b.log 2>&1; tail -3 $O/pytest_b.log
+timeout 400 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-host-leg --no-heavy-leg --no-kernel-timing --trainer-trace > $O/trace.log 2>&1
+timeout 400 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-host-leg --no-heavy-leg --no-kernel-timing > $O/plain.log 2>&1
+tail -c 200 $O/plain.log

@@ -1157,3 +1157,42 @@ def test_tile_major_binning_long_lists_and_whole_image_boxes(dev):
         got = _tile_major_lists(G, m2, radii, d, tw, th, n, None, slack)
         for nm, a, b in zip(("totals", "row_cum", "flatten_ids", "offsets", "isect_ids", "emit_slot"), got, want):
             assert torch.equal(a, b), (nm, slack)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 257, 100_003, 3_000_001])
+def test_library_morton_order_equals_the_torch_form(dev, n):
+    """clmgs_morton_order (one pass of IEEE double arithmetic + the stable radix sort) is the SAME permutation as
+    utils.morton_order_torch -- on clustered points with many equal codes (ties keep the row order), exact duplicates,
+    coordinates on the quantisation half-way points and a degenerate axis."""
+    from clm_gs_amd import utils
+    g = torch.Generator().manual_seed(n)
+    xyz = torch.randn(n, 3, generator=g) * torch.tensor([40.0, 3.0, 1.0])
+    if n > 1000:
+        xyz[: n // 4, :2] = (xyz[: n // 4, :2] * 0.01).round() / 0.01           # many equal codes
+        xyz[n // 4: n // 2] = xyz[: n // 2 - n // 4].clone()                             # exact duplicates
+        lo, hi = xyz[:, 0].min().double(), xyz[:, 0].max().double()
+        k = torch.arange(0, 2000, dtype=torch.float64)
+        xyz[-2000:, 0] = (lo + (hi - lo) * (k + 0.5) / 65535.0).float()           # (near) half-way between two cells
+    xyz = xyz.to(dev)
+    for t in (xyz, torch.cat((xyz[:, :1], torch.full_like(xyz[:, :1], 2.5), xyz[:, 2:]), dim=1)):  # (y constant)
+        a = utils.morton_order(t)
+        b = utils.morton_order_torch(t)
+        assert a.dtype == torch.int64 and a.shape == b.shape
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_row_mover_picks_per_row_tensors_like_indexing(dev):
+    """The pick of a structural change (gaussian_model._gather_f32: clmgs_rows_gather on [N], [N,1], [N,3], [N,4]
+    float tensors, int64 ids) equals plain indexing."""
+    from clm_gs_amd.strategies.clm_offload.gaussian_model import _gather_f32
+    g = torch.Generator().manual_seed(3)
+    n = 200_001
+    idx = torch.randperm(n, generator=g)[: n - 777].to(dev)
+    for shape in ((n,), (n, 1), (n, 3), (n, 4), (n, 12)):
+        t = torch.randn(shape, generator=g).to(dev)
+        out = _gather_f32(t, idx)
+        assert out.shape == (idx.numel(),) + tuple(shape[1:]) and out.is_contiguous()
+        assert torch.equal(out, t[idx])
+    assert _gather_f32(torch.randn(n, 3).to(dev), idx[:0]).shape == (0, 3)
