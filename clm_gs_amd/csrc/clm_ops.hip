@@ -401,9 +401,11 @@ adam_catch_up48_kernel(float* __restrict__ p, float* __restrict__ m, float* __re
     const int64_t o = row * 48 + k;
     float mm[VEC], vv[VEC], pp[VEC], gg[VEC];
     const bool pending = gs > a && gs <= to_step;
+    // a row that is already current -- an earlier camera's list of the same batch held it too (the engine brings the
+    // rows up to date camera by camera) -- costs its stamps only
+    if (to_step - a <= 0) continue;
     vload<VEC>(m + o, mm); vload<VEC>(v + o, vv); vload<VEC>(p + o, pp);
     if (pending) vload<VEC>(g + o, gg);
-    if (to_step - a <= 0) continue;
     if (!pending) {
       bool any_state = false;
 #pragma unroll

@@ -60,6 +60,8 @@ def default_args(**over):
                                    # Z-ordered rows when a batch's cameras may see it (GaussianModelCLMOffload.small_deferred)
         allocator_reservoir=True,  # trainer: one block per stream pool allocated and freed before the first batch
                                    # (engine.reserve_working_set): the caching allocator splits it instead of calling hipMalloc
+        split_catch_up=True,    # camera pipeline: the deferred SH-row steps run camera by camera on a side stream; the first
+                                # camera starts after its own rows' pass instead of the whole batch's
         warm_structural_ops=True,  # trainer: the torch operators of a densification run once on small tensors before the
                                    # end-to-end clock (lazily loaded device code: 110-130 ms inside the first densification)
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)

@@ -773,3 +773,66 @@ def test_deferred_small_adam_equals_eager(dev):
     assert len(outs[0]) == len(outs[1])
     for i, (a, b) in enumerate(zip(*outs)):
         assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), i
+
+
+def test_split_catch_up_equals_single_pass(dev):
+    """Round 5: the deferred SH-row steps of a batch run camera by camera on a side stream (engine `split_catch_up`: the
+    first camera waits for its own rows only) == one pass over the union of the touched rows: 12 batches of four
+    overlapping cameras (rows shared by 2-4 cameras of a batch, rows that wait several batches), a densification +
+    re-sort in the middle -- losses, SH rows, their moments and stamps, the small tensors: all bit-identical."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.densification import gsplat_densification
+    from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_train_one_batch
+    from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
+    n, w, h, nb = 40_000, 160, 120, 12
+    outs = []
+    for split in (True, False):
+        torch.manual_seed(0)
+        args = utils.default_args(bsz=BSZ, sh_residency="hbm", split_catch_up=split, densify_from_iter=0,
+                                  densification_interval=BSZ * 6, densify_until_iter=10 ** 6, opacity_reset_interval=10 ** 6,
+                                  densify_grad_threshold=0.00002)
+        args.clm_offload = True
+        utils.set_args(args)
+        utils.set_img_size(h, w)
+        utils.set_cur_iter(1)
+        sc = synth_gaussians(n, seed=4, device="cuda")
+        order = utils.morton_order(sc["xyz"])
+        for k in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            sc[k] = utils.gather_rows(sc[k], order)
+        m = GaussianModelCLMOffload(3)
+        m.create_from_tensors(sc["xyz"], sc["shs48"], sc["scaling"], sc["rotation"], sc["opacity"], spatial_lr_scale=2.0)
+        m.active_sh_degree = 3
+        m.training_setup(args)
+        m.fuse_sort_into_prune = True
+        cams = nadir_cameras(nb * BSZ, n, w, h, 0.35, seed=9, device="cuda")   # large footprints: cameras of a batch overlap
+        g = torch.Generator().manual_seed(8)
+        for c in cams:
+            c.original_image = (torch.rand(3, h, w, generator=g) * 255).to(torch.uint8).cuda()
+        comm = torch.cuda.Stream()
+        log, shared = [], 0
+        it = 1
+        for b in range(nb):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            sel = cams[b * BSZ:(b + 1) * BSZ]
+            losses, _, sparsity = clm_offload_train_one_batch(m, _Scene, sel, m.parameters_grad_buffer, None, None, comm,
+                                                              torch.Generator(device="cuda"))
+            log.append(torch.stack(losses).clone())
+            log.append(torch.tensor(sparsity))
+            n0 = m.get_xyz.shape[0]
+            gsplat_densification(it, _Scene, m, None)
+            if m.get_xyz.shape[0] != n0:
+                m.spatial_sort()
+            it += BSZ
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        torch.cuda.synchronize()
+        log += [m._row_last_step[:m.get_xyz.shape[0]].clone(), m._row_g_step[:m.get_xyz.shape[0]].clone()]  # (before the flush)
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        outs.append(log + [m._parameters.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                           m._xyz.detach().clone(), m._opacity.detach().clone(), m._scaling.detach().clone(),
+                           m._rotation.detach().clone()])
+    assert len(outs[0]) == len(outs[1])
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), i
+    assert float(torch.stack([x for x in outs[0][1:2 * nb:2]]).sum()) > 0
