@@ -1014,6 +1014,12 @@ def main():
     train_ok = loss_last <= 1.05 * loss_first
     tr = _lib.STATS.get("touched_rows", [])[:a.steps]
     touched_avg = sum(tr) / max(1, len(tr)) if tr else float(N)
+    # deferred small-attribute Adam: the share of the blocks of 256 rows the LAST batch's candidate test flagged (stepped,
+    # and read by the exact visibility pass); None in the modes that step every row every batch
+    small_flagged = None
+    _sd = getattr(gaussians, "_small_def", None)
+    if _sd and _sd.get("blk_flag") is not None:
+        small_flagged = round(float(_sd["blk_flag"].float().mean()), 4)
     isects = _lib.STATS["n_isects"][:n_images] if a.strategy == "clm_offload" else _lib.STATS["n_isects"]
     I_avg = sum(isects) / max(1, len(isects))
     emitted = _lib.STATS["n_emitted"][:n_images] if a.strategy == "clm_offload" else _lib.STATS["n_emitted"]
@@ -1212,6 +1218,7 @@ def main():
         "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
                      "I_emitted_avg": round(I_emitted, 1), "I_emitted_first_last": [emitted[0], emitted[-1]] if emitted else None,
                      "touched_rows_per_batch": round(touched_avg, 1),
+                     "small_blocks_flagged_fraction": small_flagged,
                      "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
                      "loss_per_batch": [round(sum(loss_vals[i:i + bsz]) / bsz, 5) for i in range(0, len(loss_vals), bsz)]},
         "training_check": {"ok": bool(train_ok), "rule": "mean loss of the last 2 batches <= 1.05 x mean loss of the first 2 "

@@ -1,7 +1,8 @@
 """Where a densification at full size spends its time (python profiles/densify_probe.py [n_gaussians]): the bench scene,
 a few training batches for the statistics, then gsplat_densification + spatial_sort with a device synchronisation
 around every model method (flush_lazy_rows, densify_and_clone, densify_and_split, prune_points, permute_rows,
-reset_opacity) -- twice, so that the second round shows the cost with a warm allocator."""
+reset_opacity) -- twice, so that the second round shows the cost with a warm allocator and loaded device code; the model is
+set up as trainer.training sets it up (row tables with 5 % head room, the re-sort fused into the prune)."""
 import json
 import sys
 import time
@@ -16,7 +17,7 @@ from clm_gs_amd.synthetic import nadir_cameras, perturbed_copy, synth_gaussians
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 28_000_000
 W, H, bsz = 4608, 3456, 4
 args = utils.default_args(bsz=bsz, sh_residency="hbm", densify_from_iter=0, densification_interval=16,
-                          densify_until_iter=10_000, opacity_reset_interval=32)
+                          densify_until_iter=10_000, opacity_reset_interval=32, prealloc_capacity=int(N * 1.05) // 16 * 16)
 args.clm_offload = True
 utils.set_args(args)
 utils.set_img_size(H, W)
@@ -32,6 +33,7 @@ del sc
 m.active_sh_degree = 3
 m.training_setup(args)
 m.spatial_sort()
+m.fuse_sort_into_prune = True  # as trainer.training sets it: the prune's compaction also re-sorts
 
 
 class _Scene:
@@ -53,8 +55,8 @@ def timed(name, fn):
     return wrap
 
 
-for name in ("flush_lazy_rows", "densify_and_clone", "densify_and_split", "prune_points", "permute_rows", "reset_opacity",
-             "densify_and_prune", "spatial_sort"):
+for name in ("flush_lazy_rows", "flush_small", "densify_and_clone", "densify_and_split", "prune_points", "permute_rows",
+             "reset_opacity", "densify_and_prune", "spatial_sort", "_regather_row_tables", "_append_rows"):
     setattr(m, name, timed(name, getattr(m, name)))
 from clm_gs_amd.densification import gsplat_densification
 it = 1

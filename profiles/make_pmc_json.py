@@ -17,6 +17,9 @@ GROUPS = {
     "clmgs_preprocess_bwd": ["preprocess_bwd_kernel"],
     "clmgs_adam_rows": ["adam_rows_kernel"],
     "clmgs_adam_catch_up": ["adam_catch_up"],
+    "clmgs_adam_small_deferred": ["adam_small_deferred_kernel"],
+    "clmgs_isect3_front": ["isect3_rows_kernel", "isect3_rows_finish_kernel"],
+    "clmgs_isect3_bin": ["isect3_tile_scan_kernel", "isect3_scatter_kernel", "isect3_sort_"],
 }
 
 
@@ -55,6 +58,6 @@ for entry, kernels in GROUPS.items():
     vi = sum(v for k, v in sq.items() if any(x in k for x in kernels) and "unsigned long" not in k)
     if vi:
         res["rubble28m"][entry]["valu_insts"] = vi
-res["_source"] = "rocprofv3 --pmc passes of " + label + " (profiles/collect.sh)"
+res["_source"] = "rocprofv3 --pmc passes of " + label + " (profiles/collect_r05.sh)"
 json.dump(res, open(__file__.replace("make_pmc_json.py", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res["rubble28m"], indent=1))
