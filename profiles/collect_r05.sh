@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_s /tmp/prof_h /tmp/pmcF /tmp/pmcW /tmp/pmcS
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --steps 8 --warmup 3 $N --no-kernel-timing --gt resident > $O/prof_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
-python $R/profiles/kernel_stats.py "$DB" 190 > $O/kernel_stats.csv
+python $R/profiles/kernel_stats.py "$DB" 165 > $O/kernel_stats.csv
 python $R/profiles/timeline.py $DB step3 > $O/timeline_step.txt 2>&1
 python $R/profiles/timeline_streams.py $DB step3 > $O/timeline_streams.txt 2>&1
 cd $R
@@ -39,7 +39,7 @@ timeout 400 python bench.py --scene heavy --steps 10 --warmup 3 $N > $O/bench_28
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_h -o st -- python $R/bench.py --scene heavy --steps 6 --warmup 2 $N --no-kernel-timing --gt resident > $O/prof_h.log 2>&1
 DB=$(find /tmp/prof_h -name "*.db" | head -1)
-python $R/profiles/kernel_stats.py "$DB" 240 > $O/kernel_stats_heavy.csv
+python $R/profiles/kernel_stats.py "$DB" 200 > $O/kernel_stats_heavy.csv
 cd $R
 # 7. the other BASELINE.json configurations
 timeout 400 python bench.py --config rubble10m --steps 10 --warmup 3 $N > $O/bench_rubble10m_clm.log 2>&1
