@@ -459,7 +459,9 @@ def _stage_exchange_head(b):
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
-        if b.pipelined and bsz >= 2 and getattr(args, "split_catch_up", True) and b.filters is not None:
+        if (b.pipelined and bsz >= 2 and getattr(args, "split_catch_up", True) and b.filters is not None
+                and not dp.active()):  # (all-reduce camera-DP: rows only OTHER ranks touch must consume their waiting
+            #                            gradient before this batch's sum lands on them -- the pass needs the global set)
             # CAMERA BY CAMERA (round 5; enqueued by _cameras_pipelined on the front stream, each call right before its
             # camera's projection): the first camera's chain waits for ITS rows only (0.8 ms of the 2.7 ms pass at 28 M
             # rows), the other cameras' rows are brought up to date underneath the tile kernels of the cameras before them
