@@ -175,7 +175,7 @@ def parse():
                     help="--gpus > 1: skip the camera-DP pre-flight (clm_gs_amd/dp_preflight.py: the exchange's collectives, the "
                          "exchange itself on a seeded table and two tiny locality batches, run by one child process per rank on "
                          "the real backend; a failure or a timeout makes the run fall back to --dp-mode allreduce)")
-    ap.add_argument("--preflight-timeout", type=float, default=float(os.environ.get("CLMGS_PREFLIGHT_TIMEOUT", "150")))
+    ap.add_argument("--preflight-timeout", type=float, default=float(os.environ.get("CLMGS_PREFLIGHT_TIMEOUT", "200")))
     ap.add_argument("--no-allreduce-leg", action="store_true",
                     help="--gpus > 1 with the locality / owner exchange: skip the second, short leg that runs the plain "
                          "all-reduce camera-DP (north_star's design) on a fresh model -> dp.allreduce_leg")
@@ -509,6 +509,9 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
     n_img = int(a.trainer_images)
     gc.collect()
     torch.cuda.empty_cache()
+    # what the earlier legs of this process still hold (ground-truth images of the run's cameras, 4.8 GB at 100 x 4K, and
+    # whatever their objects have not released): part of max_memory_allocated below, not of the training run's own need
+    held_before = int(torch.cuda.memory_allocated())
     for c in cams:  # the loop takes cameras whose ground truth is on the GPU (trainer.training docstring)
         if c.original_image is None:
             c.original_image = c.image_host.to("cuda")
@@ -605,6 +608,7 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
            "iterations_logged": int(m.group(2)) if m else None,
            "trainer_img_s": float(m.group(3)) if m else None,
            "trainer_peak_gpu_bytes": int(torch.cuda.max_memory_allocated()),
+           "allocated_before_leg_bytes": held_before,
            "max_memory_usage_GB_logged": float(mem[-1]) if mem else None,
            "wall_s_incl_eval": round(wall, 3),
            "n_gaussians_before_after": [N, n_after],

@@ -224,6 +224,8 @@ def morton_order(xyz, bits=16):
     ~10 ms of elementwise passes and a 64-bit sort, inside every densification of a training run."""
     xyz = xyz.detach()
     n = xyz.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=xyz.device)
     if xyz.is_cuda and bits == 16 and 0 < n < 2 ** 31 and xyz.dtype == torch.float32:
         from . import _lib
         with torch.no_grad():

@@ -1196,3 +1196,38 @@ def test_row_mover_picks_per_row_tensors_like_indexing(dev):
         assert out.shape == (idx.numel(),) + tuple(shape[1:]) and out.is_contiguous()
         assert torch.equal(out, t[idx])
     assert _gather_f32(torch.randn(n, 3).to(dev), idx[:0]).shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_tile_major_binning_with_nothing_on_the_image(dev):
+    """Edge cases of the tile-major route: every row culled (radius 0), every row off screen, and no rows at all --
+    empty lists, all-zero offsets, row_cum of zeros; in the exact form and in the device-count form (capacity 1)."""
+    from clm_gs_amd import gsplat as G
+    w, h, n = 100, 70, 300
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    depths = torch.ones((1, n), device=dev)
+    cases = [(torch.full((1, n, 2), 30.0, device=dev), torch.zeros((1, n), dtype=torch.int32, device=dev)),      # culled
+             (torch.full((1, n, 2), -900.0, device=dev), torch.full((1, n), 5, dtype=torch.int32, device=dev))]  # off screen
+    for m2, radii in cases:
+        for cap in (None, 1):
+            c = G.isect3_begin(m2, radii, depths, 16, tw, th, want_isect_ids=True, want_slots=True)
+            fids, off, ids, (slot, row_cum) = G.isect3_finish(c, capacity=cap)
+            torch.cuda.synchronize()
+            assert int(c.totals[0]) == 0
+            assert int(off.abs().sum()) == 0 and off.shape == (1, th, tw)
+            assert int(row_cum[:n].abs().sum()) == 0
+            if cap is None:
+                assert fids.numel() == 0 and slot.numel() == 0
+    e = torch.empty((1, 0), device=dev)
+    c = G.isect3_begin(torch.empty((1, 0, 2), device=dev), torch.empty((1, 0), dtype=torch.int32, device=dev), e, 16, tw, th,
+                       want_isect_ids=True, want_slots=True)
+    fids, off, ids, (slot, row_cum) = G.isect3_finish(c)
+    assert fids.numel() == 0 and int(off.abs().sum()) == 0 and ids.numel() == 0 and slot.numel() == 0
+
+
+@pytest.mark.gpu
+def test_morton_order_of_no_rows_and_of_one_point_many_times(dev):
+    from clm_gs_amd import utils
+    assert utils.morton_order(torch.empty((0, 3), device=dev)).numel() == 0
+    same = torch.full((1000, 3), 3.25, device=dev)          # hi == lo on both axes: every code 0, the identity (stable)
+    assert torch.equal(utils.morton_order(same), torch.arange(1000, device=dev))
