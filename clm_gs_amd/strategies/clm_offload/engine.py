@@ -468,7 +468,8 @@ def _stage_exchange_head(b):
             b.split_catch = True
             s_front = _pipeline_streams(gaussians)["mem"][0]
             s_front.wait_stream(b.default_stream)
-            if b.filters[0].numel():  # (the first call is issued here, ahead of the host work of the camera stage)
+            b.first_catch_done = bool(getattr(args, "early_first_catch_up", True))
+            if b.first_catch_done and b.filters[0].numel():  # (issued here, ahead of the host work of the camera stage)
                 with torch.cuda.stream(s_front):
                     gaussians.catch_up_rows(b.filters[0], to_step=step - 1)
         else:
@@ -535,7 +536,7 @@ def _cameras_pipelined(b):
     for k in range(bsz):
         if b.dp_split:  # parameters of this camera's border rows have landed (part 0: camera 0, part 1: the rest)
             s_front.wait_event(b.dp_ev_b0 if k == 0 else b.dp_ev_b1)
-        if b.split_catch and k:  # this camera's rows are brought up to date (camera 0: _stage_exchange_head)
+        if b.split_catch and (k or not b.first_catch_done):  # (camera 0: usually done by _stage_exchange_head)
             catch(k)
         with _lib.host_region("camera_front"):
             cur_pass = camera_front(gaussians, b.cameras[k], b.filters[k], b.params.data, 1, b.background,

@@ -62,6 +62,7 @@ def default_args(**over):
                                    # (engine.reserve_working_set): the caching allocator splits it instead of calling hipMalloc
         split_catch_up=True,    # camera pipeline: the deferred SH-row steps run camera by camera on a side stream; the first
                                 # camera starts after its own rows' pass instead of the whole batch's
+        early_first_catch_up=True,  # ... and the first camera's call is issued before the host work of the camera stage
         warm_structural_ops=True,  # trainer: the torch operators of a densification run once on small tensors before the
                                    # end-to-end clock (lazily loaded device code: 110-130 ms inside the first densification)
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
