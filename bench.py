@@ -180,6 +180,8 @@ def parse():
                     help="--gpus > 1 with the locality / owner exchange: skip the second, short leg that runs the plain "
                          "all-reduce camera-DP (north_star's design) on a fresh model -> dp.allreduce_leg")
     ap.add_argument("--allreduce-steps", type=int, default=6)
+    ap.add_argument("--allreduce-timeout", type=float, default=float(os.environ.get("CLMGS_ALLREDUCE_LEG_TIMEOUT", "180")),
+                    help="watchdog of the all-reduce leg: after this many seconds rank 0 prints the line without the leg")
     ap.add_argument("--no-heavy-leg", action="store_true",
                     help="skip the extra short single-GPU leg on the heavy-tailed scene (--scene heavy, I/V ~ 11) -> value_heavy")
     ap.add_argument("--heavy-steps", type=int, default=8)
@@ -1033,11 +1035,230 @@ def main():
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
 
     dist_backend = torch.distributed.get_backend() if grouped else None
+    def _finish(allreduce_leg, clean=True):
+        """Everything after the timed work: the process group is left (clean=False: the watchdog of the all-reduce leg
+        calls this from its own thread while the main thread may be stuck in a collective), rank 0 assembles and prints
+        the ONE line."""
+        nonlocal gaussians
+        if grouped and clean:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if rank != 0:
+            return
+        value = n_images * world / dt
+        kernels = {}
+        for name, (calls, ms) in timing.items():
+            if name in ALGO_BYTES and calls:
+                avg_ms = ms / calls
+                b = ALGO_BYTES[name](n_rows, V_avg, I_avg, P, T)
+                kernels[name] = {"calls": calls, "avg_ms": round(avg_ms, 4),
+                                 "algo_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
+                                 "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
+            elif calls:
+                kernels[name] = {"calls": calls, "avg_ms": round(ms / calls, 4),
+                                 "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
+        roofline = None
+        if kernels:
+            dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["calls"] * kernels[k]["avg_ms"])
+            ach = kernels[dom]["algo_GBps"]
+            traffic, traffic_src, valu = None, None, None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(a.config, {}).get(dom, {}).get("traffic")
+                    valu = tj.get(a.config, {}).get(dom, {}).get("valu_insts")
+                    traffic_src = ("NOT measured in this run: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc "
+                                   "FETCH_SIZE / WRITE_SIZE passes, profiles/collect.sh")) + ")") if traffic is not None else None
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": traffic_src,
+                        # the same figure on the list this build actually walks (after exact per-tile culling) --
+                        # `frac` charges the reference's unculled intersection count, the work the algorithm defines
+                        "algo_bytes_per_launch_processed": ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T),
+                        "frac_processed": round(ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T)
+                                                / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "algo_bytes_per_launch": ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T),
+                        "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "avg_launch_ms_solo": round(solo[dom], 4) if dom in solo else None,
+                        "frac_solo": round(ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T) / (solo[dom] * 1e-3) / 1e9
+                                           / HBM_PEAK_GBS, 5) if dom in solo else None,
+                        "compute": ({"unit": "G wave-instr/s (VALU)", "peak": VALU_PEAK_G,
+                                     "peak_theoretical": 1229.0,  # 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
+                                     "valu_insts_per_launch": valu,
+                                     "achieved": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9, 1),
+                                     "frac": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / VALU_PEAK_G, 4),
+                                     "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
+                                     "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
+                                     "frac_solo_of_theoretical": round(valu / (solo[dom] * 1e-3) / 1e9 / 1229.0, 4) if dom in solo else None,
+                                     "ceiling_at_kernel_occupancy": VALU_CEILING_5_WAVES_G,
+                                     "frac_solo_of_ceiling": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_CEILING_5_WAVES_G, 4)
+                                     if dom in solo else None,
+                                     "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
+                                             "durations from this run; peak = plain-FMA issue rate at 8 waves/SIMD, ceiling = "
+                                             "the same at the kernel's 5 waves/SIMD (profiles/r02_ilp_probe.jsonl) -- the "
+                                             "kernel's exp / rcp / DPP / permlane instructions cost 1.5-3 issue slots each: "
+                                             "weighted by those costs it needs 1.22x its instruction count in slots "
+                                             "(DESIGN.md section 3)"}
+                                    if valu else None),
+                        "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
+                        "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "
+                                "HBM fraction is structurally low, pairs/s reported beside it. achieved/frac use "
+                                "the launch duration inside the timed region (kernel-type streams: launches share "
+                                "the chip); *_solo = the same launch with nothing co-running (extra untimed batch)"}
+        # whole-image algorithmic bytes A(image) of SURVEY 8d, for the end-to-end HBM figure
+        p_pass = 6
+        A_img = 228 * n_rows + 636 * V_avg + (220 * V_avg if a.strategy == "clm_offload" else 0) + \
+            (144 + 24 * p_pass) * I_avg + 143 * P + 4 * T
+        # SURVEY 8d: Adam per batch = 28 B x 59 floats per row, row-sparse over the rows the batch touches
+        # (untouched rows have a zero gradient; this build defers their momentum decay, clm_offload hbm mode)
+        adam_rows = touched_avg if (a.strategy == "clm_offload" and a.residency == "hbm") else float(N)
+        adam_img = 1652.0 * adam_rows / bsz
+        # published numbers of BASELINE.md section 1 for exactly this (config, strategy), single GPU
+        published = {("rubble28m", "clm_offload"): 4.04, ("rubble28m", "naive_offload"): 2.45,
+                     ("rubble10m", "clm_offload"): 8.08, ("rubble10m", "no_offload"): 8.55,
+                     ("rubble10m", "naive_offload"): 4.49, ("bicycle6m", "no_offload"): 40.9,
+                     ("bicycle6m", "clm_offload"): 22.3, ("bicycle6m", "naive_offload"): 12.1}
+        ref_img_s = published.get((a.config, a.strategy)) if (world == 1 and a.residency == "hbm") else None
+        vs_baseline = round(value / ref_img_s, 3) if ref_img_s else None
+        out = {
+            "metric": "training images/s (Rubble-4K 28M Gaussians clm_offload)" if a.config == "rubble28m"
+            else f"training images/s ({a.config} {a.strategy})",
+            "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "host_ms_per_step": {"enqueue": round((t_enq - host_wait) / a.steps * 1e3, 3),
+                                 "blocked_in_size_readbacks": round(host_wait / a.steps * 1e3, 3),
+                                 "step_returns_ms": [round((t - t0) * 1e3, 2) for t in step_marks],
+                                 "device_mallocs_in_timed_region": dev_allocs, "device_frees_in_timed_region": dev_frees,
+                                 "cameras_redone_over_capacity": n_redo,
+                                 **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
+                                    if host_regions else {})},
+            "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
+            "dp": ({"mode": dp_mode, "fallback": dp_fallback, "preflight": preflight, "deal": deal_info,
+                    "replicas_equal": rep_equal,
+                    "completing_flush_ms": round(completing_flush_ms, 2) if completing_flush_ms is not None else None,
+                    "phase_ms": dp_phase_ms,
+                    "phase_ms_note": "per step, from the instrumented pass (value_instrumented): device_ms = event pairs on the "
+                                     "stream each phase is enqueued on (B0 / B1 / D0 on the exchange's side stream, i.e. under "
+                                     "rendering), host_ms = wall time of the enqueueing block incl. its host reads; plan = "
+                                     "dp.border_plan, S = small_prepare (candidates + fetch), catch_up_own = deferred row steps of "
+                                     "the rows anybody renders, B = parameter rows out, D = gradient lines home, D_apply = "
+                                     "owner-side accumulation, tail_exchange = everything the exchange adds after the last backward",
+                    "allreduce_leg": allreduce_leg,
+                    "small_attributes_at_owner": bool(getattr(gaussians, "small_owner", False)),
+                    "row_moments_sharded": bool(getattr(gaussians, "moments_sharded", False)),
+                    "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
+                    "by_collective_per_step": {k: round(v / a.steps, 1) for k, v in wire.items() if k != "total"},
+                    "note": "bytes rank 0 SENDS per batch (clm_gs_amd.dp.wire_bytes: ring model for all-reduce, exact sizes for "
+                            "all_to_all / all_gather); the timed region ends with every rank catching up the rows it owns, the "
+                            "all-gather that completes the replicas for evaluation / saving runs after it and is not counted"}
+                   if (world > 1 or under_torchrun) else None),
+            "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
+                       "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
+                       "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
+                       "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
+                       "camera_order": a.camera_order, "row_order": a.row_order, "scene": a.scene,
+                       "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb,
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+            "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
+            "gt_images": ("pinned host memory, every batch uploaded on a side stream one batch ahead (train.py:310-312)"
+                          if (a.gt == "host" or a.residency == "host") else
+                          "all resident in HBM before the timed region (bench contract); value_gt_streamed = the same K steps with "
+                          "the images in pinned host memory, uploaded per batch as the reference does (train.py:310-312)"),
+            "value_gt_streamed": round(n_images * world / dt_res, 4) if dt_res else None,
+            "peak_gpu_bytes": int(peak),
+            "peak_gpu_bytes_gt_streamed": int(peak_res) if peak_res else None,
+            "peak_gpu_bytes_note": ("sh_residency=hbm keeps the whole model + optimizer state in HBM by design (SURVEY 7: 288 GB): "
+                                    f"{944 * N / 1e9:.1f} GB of the peak are the {N} x 944 B of parameters, moments and gradient rows, "
+                                    f"{60 * N / 1e9:.1f} GB the packed small-attribute mirror / gradient / stamp tables; the rest is one "
+                                    "to two cameras' working set (stream-ordered frees) and the resident GT images of the run "
+                                    f"({len(cams)} x {3 * H * W / 1e6:.1f} MB = {len(cams) * 3 * H * W / 1e9:.1f} GB; not in the gt_streamed figure).  The reference's 13.0 GB "
+                                    "is its offloading configuration (SH rows + Adam state in host memory): compare host_resident.peak_gpu_bytes"),
+            "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
+                         "I_emitted_avg": round(I_emitted, 1), "I_emitted_first_last": [emitted[0], emitted[-1]] if emitted else None,
+                         "touched_rows_per_batch": round(touched_avg, 1),
+                         "small_blocks_flagged_fraction": small_flagged,
+                         "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
+                         "loss_per_batch": [round(sum(loss_vals[i:i + bsz]) / bsz, 5) for i in range(0, len(loss_vals), bsz)]},
+            "training_check": {"ok": bool(train_ok), "rule": "mean loss of the last 2 batches <= 1.05 x mean loss of the first 2 "
+                               "(warm-up included): the timed optimisation must not diverge"},
+            "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1), "adam_rows_per_batch": round(adam_rows, 1),
+                               "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),
+                               "frac_of_8TBps": round((A_img + adam_img) * value / world / 8e12, 5)},
+            "baseline": {"img_s": ref_img_s, "source": "BASELINE.md section 1 (reference's own testbed: 1x RTX 4090 + "
+                         "16-core host; img/s derived there from published training time / iterations)"}
+            if ref_img_s else None,
+            "roofline": roofline, "kernels": kernels,
+            # the same C-ABI calls with NOTHING co-running (one extra untimed batch on a single stream): what a call costs
+            # by itself, as opposed to its stretched duration next to the other streams' kernels
+            "kernels_solo_ms": {k: round(v, 4) for k, v in sorted(solo.items())} if solo else None,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                if cams[0].original_image is None:  # GT images live in pinned host memory (--gt host)
+                    cams[0].original_image = cams[0].image_host.to("cuda")
+                out["cpu_baseline"] = cpu_baseline(gaussians, cams[0], W, H, a.cpu_seconds)
+            except Exception as e:  # the baseline is reporting, never the product path
+                out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        if (not a.no_host_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+                and a.config in ("rubble28m", "rubble10m", "small")):
+            try:
+                del gaussians
+                out["host_resident"] = host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
+            except Exception as e:  # reported, never fatal for the headline
+                out["host_resident"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if (not a.no_trainer_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+                and a.config in ("rubble28m", "rubble10m", "small")):
+            try:
+                gaussians = None
+                out["trainer"] = trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent)
+                out["trainer_img_s"] = out["trainer"]["trainer_img_s"]
+                out["trainer_peak_gpu_bytes"] = out["trainer"]["trainer_peak_gpu_bytes"]
+                if out["trainer_img_s"]:
+                    out["trainer_vs_value"] = round(out["trainer_img_s"] / value, 4)
+            except Exception as e:  # reported, never fatal for the headline
+                out["trainer"] = {"trainer_img_s": None, "error": f"{type(e).__name__}: {e}"}
+        if (not a.no_heavy_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
+                and a.scene == "slab" and a.config in ("rubble28m", "rubble10m", "small")):
+            try:
+                gaussians = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                out["heavy"] = heavy_leg(a)
+                out["value_heavy"] = out["heavy"].get("value")
+            except Exception as e:  # reported, never fatal for the headline
+                out["heavy"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(out))
+        sys.stdout.flush()
+        if not train_ok:
+            sys.stderr.write(f"bench: training check FAILED: loss {loss_first:.5f} -> {loss_last:.5f}\n")
+            sys.exit(3)
+
     # ---- camera-DP: a second, short leg with the PLAIN all-reduce exchange (north_star's design: every rank steps every
     # row, one all-reduce of the touched rows' gradient lines per batch) on a fresh model, so that the scaling record
     # carries the simple design beside the locality one
     allreduce_leg = None
     if world > 1 and dp_mode != "allreduce" and a.strategy == "clm_offload" and not a.no_allreduce_leg:
+        # The headline has been measured; this leg is extra.  A watchdog per rank: if the leg does not finish in
+        # --allreduce-timeout seconds (a collective that never returns), rank 0 prints the line WITHOUT it and every rank
+        # leaves the process -- the run cannot be lost to its appendix.
+        import threading
+        leg_done = threading.Event()
+
+        def _bail():
+            if leg_done.is_set():
+                return
+            try:
+                _finish({"value": None, "error": f"timed out after {a.allreduce_timeout:.0f} s (watchdog)"}, clean=False)
+                sys.stdout.flush()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(float(a.allreduce_timeout), _bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             gaussians = None
             gc.unfreeze()
@@ -1083,202 +1304,9 @@ def main():
             utils.set_args(args)
         except Exception as e:  # reported, never fatal for the headline
             allreduce_leg = {"value": None, "error": f"{type(e).__name__}: {e}"}
-    if grouped:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
-    if rank != 0:
-        return
-    value = n_images * world / dt
-    kernels = {}
-    for name, (calls, ms) in timing.items():
-        if name in ALGO_BYTES and calls:
-            avg_ms = ms / calls
-            b = ALGO_BYTES[name](n_rows, V_avg, I_avg, P, T)
-            kernels[name] = {"calls": calls, "avg_ms": round(avg_ms, 4),
-                             "algo_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
-                             "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
-        elif calls:
-            kernels[name] = {"calls": calls, "avg_ms": round(ms / calls, 4),
-                             "share_of_step": round(ms / ((dt_instr or dt) * 1e3), 4)}
-    roofline = None
-    if kernels:
-        dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["calls"] * kernels[k]["avg_ms"])
-        ach = kernels[dom]["algo_GBps"]
-        traffic, traffic_src, valu = None, None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(a.config, {}).get(dom, {}).get("traffic")
-                valu = tj.get(a.config, {}).get(dom, {}).get("valu_insts")
-                traffic_src = ("NOT measured in this run: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc "
-                               "FETCH_SIZE / WRITE_SIZE passes, profiles/collect.sh")) + ")") if traffic is not None else None
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    # the same figure on the list this build actually walks (after exact per-tile culling) --
-                    # `frac` charges the reference's unculled intersection count, the work the algorithm defines
-                    "algo_bytes_per_launch_processed": ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T),
-                    "frac_processed": round(ALGO_BYTES[dom](n_rows, V_avg, I_emitted, P, T)
-                                            / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "algo_bytes_per_launch": ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T),
-                    "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "avg_launch_ms_solo": round(solo[dom], 4) if dom in solo else None,
-                    "frac_solo": round(ALGO_BYTES[dom](n_rows, V_avg, I_avg, P, T) / (solo[dom] * 1e-3) / 1e9
-                                       / HBM_PEAK_GBS, 5) if dom in solo else None,
-                    "compute": ({"unit": "G wave-instr/s (VALU)", "peak": VALU_PEAK_G,
-                                 "peak_theoretical": 1229.0,  # 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
-                                 "valu_insts_per_launch": valu,
-                                 "achieved": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9, 1),
-                                 "frac": round(valu / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / VALU_PEAK_G, 4),
-                                 "achieved_solo": round(valu / (solo[dom] * 1e-3) / 1e9, 1) if dom in solo else None,
-                                 "frac_solo": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_PEAK_G, 4) if dom in solo else None,
-                                 "frac_solo_of_theoretical": round(valu / (solo[dom] * 1e-3) / 1e9 / 1229.0, 4) if dom in solo else None,
-                                 "ceiling_at_kernel_occupancy": VALU_CEILING_5_WAVES_G,
-                                 "frac_solo_of_ceiling": round(valu / (solo[dom] * 1e-3) / 1e9 / VALU_CEILING_5_WAVES_G, 4)
-                                 if dom in solo else None,
-                                 "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
-                                         "durations from this run; peak = plain-FMA issue rate at 8 waves/SIMD, ceiling = "
-                                         "the same at the kernel's 5 waves/SIMD (profiles/r02_ilp_probe.jsonl) -- the "
-                                         "kernel's exp / rcp / DPP / permlane instructions cost 1.5-3 issue slots each: "
-                                         "weighted by those costs it needs 1.22x its instruction count in slots "
-                                         "(DESIGN.md section 3)"}
-                                if valu else None),
-                    "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
-                    "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "
-                            "HBM fraction is structurally low, pairs/s reported beside it. achieved/frac use "
-                            "the launch duration inside the timed region (kernel-type streams: launches share "
-                            "the chip); *_solo = the same launch with nothing co-running (extra untimed batch)"}
-    # whole-image algorithmic bytes A(image) of SURVEY 8d, for the end-to-end HBM figure
-    p_pass = 6
-    A_img = 228 * n_rows + 636 * V_avg + (220 * V_avg if a.strategy == "clm_offload" else 0) + \
-        (144 + 24 * p_pass) * I_avg + 143 * P + 4 * T
-    # Adam per batch = 28 B x 59 floats per row, row-sparse over the rows the batch touches
-    # (untouched rows have a zero gradient; this build defers their momentum decay, clm_offload hbm mode)
-    adam_rows = touched_avg if (a.strategy == "clm_offload" and a.residency == "hbm") else float(N)
-    adam_img = 1652.0 * adam_rows / bsz
-    # published numbers of BASELINE.md section 1 for exactly this (config, strategy), single GPU
-    published = {("rubble28m", "clm_offload"): 4.04, ("rubble28m", "naive_offload"): 2.45,
-                 ("rubble10m", "clm_offload"): 8.08, ("rubble10m", "no_offload"): 8.55,
-                 ("rubble10m", "naive_offload"): 4.49, ("bicycle6m", "no_offload"): 40.9,
-                 ("bicycle6m", "clm_offload"): 22.3, ("bicycle6m", "naive_offload"): 12.1}
-    ref_img_s = published.get((a.config, a.strategy)) if (world == 1 and a.residency == "hbm") else None
-    vs_baseline = round(value / ref_img_s, 3) if ref_img_s else None
-    out = {
-        "metric": "training images/s (Rubble-4K 28M Gaussians clm_offload)" if a.config == "rubble28m"
-        else f"training images/s ({a.config} {a.strategy})",
-        "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "host_ms_per_step": {"enqueue": round((t_enq - host_wait) / a.steps * 1e3, 3),
-                             "blocked_in_size_readbacks": round(host_wait / a.steps * 1e3, 3),
-                             "step_returns_ms": [round((t - t0) * 1e3, 2) for t in step_marks],
-                             "device_mallocs_in_timed_region": dev_allocs, "device_frees_in_timed_region": dev_frees,
-                             "cameras_redone_over_capacity": n_redo,
-                             **({"regions": {k: round(v / a.steps * 1e3, 3) for k, v in host_regions.items()}}
-                                if host_regions else {})},
-        "vs_baseline": vs_baseline, "dtype": "f32", "data": "synthetic", "dist_backend": dist_backend,
-        "dp": ({"mode": dp_mode, "fallback": dp_fallback, "preflight": preflight, "deal": deal_info,
-                "replicas_equal": rep_equal,
-                "completing_flush_ms": round(completing_flush_ms, 2) if completing_flush_ms is not None else None,
-                "phase_ms": dp_phase_ms,
-                "phase_ms_note": "per step, from the instrumented pass (value_instrumented): device_ms = event pairs on the "
-                                 "stream each phase is enqueued on (B0 / B1 / D0 on the exchange's side stream, i.e. under "
-                                 "rendering), host_ms = wall time of the enqueueing block incl. its host reads; plan = "
-                                 "dp.border_plan, S = small_prepare (candidates + fetch), catch_up_own = deferred row steps of "
-                                 "the rows anybody renders, B = parameter rows out, D = gradient lines home, D_apply = "
-                                 "owner-side accumulation, tail_exchange = everything the exchange adds after the last backward",
-                "allreduce_leg": allreduce_leg,
-                "small_attributes_at_owner": bool(getattr(gaussians, "small_owner", False)),
-                "row_moments_sharded": bool(getattr(gaussians, "moments_sharded", False)),
-                "dp_exchange_bytes_per_step": round(wire.get("total", 0) / a.steps, 1),
-                "by_collective_per_step": {k: round(v / a.steps, 1) for k, v in wire.items() if k != "total"},
-                "note": "bytes rank 0 SENDS per batch (clm_gs_amd.dp.wire_bytes: ring model for all-reduce, exact sizes for "
-                        "all_to_all / all_gather); the timed region ends with every rank catching up the rows it owns, the "
-                        "all-gather that completes the replicas for evaluation / saving runs after it and is not counted"}
-               if (world > 1 or under_torchrun) else None),
-        "config": {"workload": desc, "name": a.config, "strategy": a.strategy, "n_gaussians": N,
-                   "width": W, "height": H, "bsz_per_gpu": bsz, "global_batch": bsz * world,
-                   "sh_degree": 3, "sh_residency": a.residency if a.strategy == "clm_offload" else "hbm",
-                   "parallelism": f"camera-dp{world}", "visible_fraction_target": vis_frac,
-                   "camera_order": a.camera_order, "row_order": a.row_order, "scene": a.scene,
-                   "untimed_priming_s": a.prime_seconds, "allocator_reservoir_gb": a.allocator_reservoir_gb,
-                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
-        "value_instrumented": round(n_images * world / dt_instr, 4) if dt_instr else None,
-        "gt_images": ("pinned host memory, every batch uploaded on a side stream one batch ahead (train.py:310-312)"
-                      if (a.gt == "host" or a.residency == "host") else
-                      "all resident in HBM before the timed region (bench contract); value_gt_streamed = the same K steps with "
-                      "the images in pinned host memory, uploaded per batch as the reference does (train.py:310-312)"),
-        "value_gt_streamed": round(n_images * world / dt_res, 4) if dt_res else None,
-        "peak_gpu_bytes": int(peak),
-        "peak_gpu_bytes_gt_streamed": int(peak_res) if peak_res else None,
-        "peak_gpu_bytes_note": ("sh_residency=hbm keeps the whole model + optimizer state in HBM by design (SURVEY 7: 288 GB): "
-                                f"{944 * N / 1e9:.1f} GB of the peak are the {N} x 944 B of parameters, moments and gradient rows, "
-                                f"{60 * N / 1e9:.1f} GB the packed small-attribute mirror / gradient / stamp tables; the rest is one "
-                                "to two cameras' working set (stream-ordered frees) and the resident GT images of the run "
-                                f"({len(cams)} x {3 * H * W / 1e6:.1f} MB = {len(cams) * 3 * H * W / 1e9:.1f} GB; not in the gt_streamed figure).  The reference's 13.0 GB "
-                                "is its offloading configuration (SH rows + Adam state in host memory): compare host_resident.peak_gpu_bytes"),
-        "measured": {"V_avg": round(V_avg, 1), "I_avg": round(I_avg, 1), "I_over_V": round(I_avg / max(V_avg, 1), 3),
-                     "I_emitted_avg": round(I_emitted, 1), "I_emitted_first_last": [emitted[0], emitted[-1]] if emitted else None,
-                     "touched_rows_per_batch": round(touched_avg, 1),
-                     "small_blocks_flagged_fraction": small_flagged,
-                     "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
-                     "loss_per_batch": [round(sum(loss_vals[i:i + bsz]) / bsz, 5) for i in range(0, len(loss_vals), bsz)]},
-        "training_check": {"ok": bool(train_ok), "rule": "mean loss of the last 2 batches <= 1.05 x mean loss of the first 2 "
-                           "(warm-up included): the timed optimisation must not diverge"},
-        "end_to_end_hbm": {"algo_bytes_per_image": round(A_img + adam_img, 1), "adam_rows_per_batch": round(adam_rows, 1),
-                           "achieved_GBps": round((A_img + adam_img) * value / world / 1e9, 1),
-                           "frac_of_8TBps": round((A_img + adam_img) * value / world / 8e12, 5)},
-        "baseline": {"img_s": ref_img_s, "source": "BASELINE.md section 1 (reference's own testbed: 1x RTX 4090 + "
-                     "16-core host; img/s derived there from published training time / iterations)"}
-        if ref_img_s else None,
-        "roofline": roofline, "kernels": kernels,
-        # the same C-ABI calls with NOTHING co-running (one extra untimed batch on a single stream): what a call costs
-        # by itself, as opposed to its stretched duration next to the other streams' kernels
-        "kernels_solo_ms": {k: round(v, 4) for k, v in sorted(solo.items())} if solo else None,
-    }
-    if not a.no_cpu_baseline and world == 1:
-        try:
-            if cams[0].original_image is None:  # GT images live in pinned host memory (--gt host)
-                cams[0].original_image = cams[0].image_host.to("cuda")
-            out["cpu_baseline"] = cpu_baseline(gaussians, cams[0], W, H, a.cpu_seconds)
-        except Exception as e:  # the baseline is reporting, never the product path
-            out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"failed: {type(e).__name__}: {e}"}
-    if (not a.no_host_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
-            and a.config in ("rubble28m", "rubble10m", "small")):
-        try:
-            del gaussians
-            out["host_resident"] = host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
-        except Exception as e:  # reported, never fatal for the headline
-            out["host_resident"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-    if (not a.no_trainer_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
-            and a.config in ("rubble28m", "rubble10m", "small")):
-        try:
-            gaussians = None
-            out["trainer"] = trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent)
-            out["trainer_img_s"] = out["trainer"]["trainer_img_s"]
-            out["trainer_peak_gpu_bytes"] = out["trainer"]["trainer_peak_gpu_bytes"]
-            if out["trainer_img_s"]:
-                out["trainer_vs_value"] = round(out["trainer_img_s"] / value, 4)
-        except Exception as e:  # reported, never fatal for the headline
-            out["trainer"] = {"trainer_img_s": None, "error": f"{type(e).__name__}: {e}"}
-    if (not a.no_heavy_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
-            and a.scene == "slab" and a.config in ("rubble28m", "rubble10m", "small")):
-        try:
-            gaussians = None
-            gc.collect()
-            torch.cuda.empty_cache()
-            out["heavy"] = heavy_leg(a)
-            out["value_heavy"] = out["heavy"].get("value")
-        except Exception as e:  # reported, never fatal for the headline
-            out["heavy"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-    print(json.dumps(out))
-    sys.stdout.flush()
-    if not train_ok:
-        sys.stderr.write(f"bench: training check FAILED: loss {loss_first:.5f} -> {loss_last:.5f}\n")
-        sys.exit(3)
+        leg_done.set()
+        watchdog.cancel()
+    _finish(allreduce_leg)
 
 
 if __name__ == "__main__":

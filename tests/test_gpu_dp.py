@@ -233,6 +233,21 @@ def test_bench_falls_back_to_allreduce_when_the_preflight_fails(dev):
     assert d["preflight"]["ok"] is False and d["allreduce_leg"] is None
 
 
+def test_bench_prints_its_line_when_the_allreduce_leg_does_not_finish(dev):
+    """The all-reduce leg is an appendix of the multi-GPU line: a watchdog per rank (--allreduce-timeout, here 50 ms,
+    i.e. it fires while the leg is still building its model) makes rank 0 print the ONE line without the leg and every
+    rank leave the process -- exit code 0, the locality measurement intact."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1")
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                "--config", "small", "--prime-seconds", "0", "--allreduce-timeout", "0.05"], env=env)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["dp"]["mode"] == "locality" and j["dp"]["replicas_equal"] is True
+    assert j["dp"]["allreduce_leg"]["value"] is None and "watchdog" in j["dp"]["allreduce_leg"]["error"]
+
+
 def test_bench_refuses_more_ranks_than_gpus(dev):
     """Without the sharing hook, --gpus N on a box with fewer than N devices fails loudly (exit 2), it does not
     silently run one rank."""
