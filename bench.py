@@ -119,8 +119,8 @@ VALU_CEILING_5_WAVES_G = 900.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="rubble28m", choices=sorted(CONFIGS))
     ap.add_argument("--strategy", default="clm_offload", choices=["clm_offload", "no_offload", "naive_offload"])
     ap.add_argument("--residency", default="hbm", choices=["hbm", "host"])
