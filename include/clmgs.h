@@ -186,7 +186,8 @@ int clmgs_isect2_emit_sort_dev(void* stream, int V, int64_t capacity, const int6
 /* Tile-major binning (round 5; the engine's default route): the same lists as clmgs_isect2_order_count +
  * clmgs_isect2_emit_sort -- gsplat.isect_tiles + isect_offset_encode of strategies/base_engine.py:175-186, sorted by
  * (tile, depth bits, row index) -- built without a global sort: per-tile counters, an exclusive scan (= offsets), a
- * scatter of 16 B records into the tiles' segments and one LDS sort per tile (csrc/isect3.hip).  7 launches instead of 23.
+ * scatter of 16 B records into the tiles' segments and one LDS sort per tile (csrc/isect3.hip).  8 kernel launches and one
+ * clear instead of 23.
  *  - clmgs_isect3_front: per-row tile boxes / exact tile masks (packed != NULL), tile counters, row_cum[V] (inclusive
  *    emitted counts in ROW order = the slot ranges of clmgs_rasterize_bwd's slot mode), totals[2] on the device =
  *    {intersections to emit, un-culled count}.  `temp` (clmgs_isect3_front_temp_bytes) must stay alive until _bin ran.
