@@ -90,6 +90,26 @@ def _encode_bitmap(filters, n_gaussians, bsz):
     return bitmap
 
 
+def finish_groups(filters, n_gaussians, bsz, sparse_adam=False):
+    """For filters ALREADY in processing order: the row groups by last use (`update_ls`, engine.py:194-213), the
+    sparse_adam visibility mask (:215-222) and the retention-set sizes cnt_h / cnt_d / cnt_g (:224-235).
+    -> (groups[bsz+1] device i64, visibility_mask | None, cnt_h, cnt_d, cnt_g (python int lists), bitmap)."""
+    dev = filters[0].device
+    bitmap = _encode_bitmap(filters, n_gaussians, bsz)
+    ffs = torch.empty(n_gaussians, dtype=torch.uint8, device=dev)
+    clm_kernels.extract_ffs(bitmap, ffs)
+    # group 0: untouched; group k (k>=1): last used in micro-batch k-1  <=> ffs == bsz - (k-1)
+    groups = [torch.nonzero(ffs == 0).flatten()]
+    for mb in range(bsz):
+        groups.append(torch.nonzero(ffs == (bsz - mb)).flatten())
+    visibility_mask = (ffs != 0) if sparse_adam else None
+    cnt_d = clm_kernels.pair_overlap_count(bitmap, bsz).tolist()
+    lens = [len(f) for f in filters]
+    cnt_h = [lens[i + 1] - cnt_d[i] for i in range(bsz - 1)]
+    cnt_g = [lens[i] - cnt_d[i] for i in range(bsz - 1)]
+    return groups, visibility_mask, cnt_h, cnt_d, cnt_g, bitmap
+
+
 def order_calculation(filters, batched_cameras, n_gaussians, bsz, perm_generator, args):
     """Camera order + row groups by last use + retention-set sizes (engine.py:135-298).
 
@@ -120,19 +140,7 @@ def order_calculation(filters, batched_cameras, n_gaussians, bsz, perm_generator
     filters = [filters[i] for i in ordered_cams]
     sparsity = [len(f) / float(n_gaussians) for f in filters]
 
-    bitmap = _encode_bitmap(filters, n_gaussians, bsz)
-    ffs = torch.empty(n_gaussians, dtype=torch.uint8, device=dev)
-    clm_kernels.extract_ffs(bitmap, ffs)
-    # group 0: untouched; group k (k>=1): last used in micro-batch k-1  <=> ffs == bsz - (k-1)
-    groups = [torch.nonzero(ffs == 0).flatten()]
-    for mb in range(bsz):
-        groups.append(torch.nonzero(ffs == (bsz - mb)).flatten())
-    visibility_mask = (ffs != 0) if args.sparse_adam else None
-
-    cnt_d = clm_kernels.pair_overlap_count(bitmap, bsz).tolist()
-    lens = [len(f) for f in filters]
-    cnt_h = [lens[i + 1] - cnt_d[i] for i in range(bsz - 1)]
-    cnt_g = [lens[i] - cnt_d[i] for i in range(bsz - 1)]
+    groups, visibility_mask, cnt_h, cnt_d, cnt_g, bitmap = finish_groups(filters, n_gaussians, bsz, args.sparse_adam)
 
     # one pinned D2H copy of every index list, as int32 (engine.py:246-260)
     sizes = [g.numel() for g in groups]

@@ -180,3 +180,50 @@ def test_reference_naive_offload_run_agrees_with_reference_no_offload_run():
     never = ~(a["sparse_visibility_b0"] | a["sparse_visibility_b1"] | a["sparse_visibility_b2"])
     assert never.any() and np.array_equal(a["sparse_p_xyz"][never], b["xyz"][never])  # never visible: never stepped
     assert not np.allclose(a["sparse_m_xyz"][~seen_all], a["dense_m_xyz"][~seen_all])
+
+
+def test_large_batch_fixtures_are_self_consistent():
+    """engine_clm_offload_bsz{16,64}.npz (tests/golden/make_engine_golden_bsz.py: the reference's clm engine at bsz 16 /
+    64): the recorded order_calculation outputs obey the identities of engine.py:194-235 (partition of [0, N) by last
+    use; cnt_h + cnt_d = |F_{i+1}|, cnt_g + cnt_d = |F_i|), the oracle's packed projection selects filters of the
+    recorded sizes, the dense and the sparse_adam runs saw the same first batch, and sparse_adam left the rows no
+    camera saw untouched."""
+    for bsz, word in ((16, "int16"), (64, "int64")):
+        d = _load(f"engine_clm_offload_bsz{bsz}.npz")
+        N = d["xyz"].shape[0]
+        assert int(d["bsz"]) == bsz and str(d["bitmap_dtype"]) == word
+        W, H = int(d["W"]), int(d["H"])
+        fx = W / (2 * math.tan(float(d["fovx"]) * 0.5))
+        fy = H / (2 * math.tan(float(d["fovy"]) * 0.5))
+        K = torch.tensor([[fx, 0, W / 2.0], [0, fy, H / 2.0], [0, 0, 1]])
+        ref = O.fully_fused_projection(_t(d["xyz"]), None, torch.nn.functional.normalize(_t(d["rotation"])),
+                                       torch.exp(_t(d["scaling"])), _t(d["w2c"][:bsz]), K[None].expand(bsz, 3, 3), W, H,
+                                       packed=True)
+        sets = [set(ref[1][ref[0] == c].tolist()) for c in range(bsz)]
+        for b in range(int(d["n_batches"])):
+            order = d[f"dense_ordered_cams_b{b}"].tolist()
+            assert sorted(order) == list(range(bsz))
+            sizes = d[f"dense_fin_sizes_b{b}"]
+            assert sizes.shape == (bsz + 1,) and int(sizes.sum()) == N
+            assert np.array_equal(np.sort(d[f"dense_fin_cat_b{b}"]), np.arange(N))
+            fs = d[f"dense_filter_sizes_b{b}"]
+            ch, cd, cg = d[f"dense_cnt_h_b{b}"], d[f"dense_cnt_d_b{b}"], d[f"dense_cnt_g_b{b}"]
+            assert np.array_equal(ch + cd, fs[1:]) and np.array_equal(cg + cd, fs[:-1])
+            assert np.allclose(d[f"dense_sparsity_b{b}"], fs / float(N))
+            if b == 0:
+                assert [len(sets[i]) for i in order] == fs.tolist()
+                groups = np.split(d["dense_fin_cat_b0"], np.cumsum(sizes)[:-1])
+                later = set()
+                for k in range(bsz - 1, -1, -1):
+                    assert set(groups[k + 1].tolist()) == sets[order[k]] - later
+                    later |= sets[order[k]]
+                assert set(groups[0].tolist()) == set(range(N)) - later
+                assert cd.tolist() == [len(sets[order[i]] & sets[order[i + 1]]) for i in range(bsz - 1)]
+        assert np.allclose(d["dense_losses_b0"], d["sparse_losses_b0"], atol=0) and np.array_equal(
+            d["dense_ordered_cams_b0"], d["sparse_ordered_cams_b0"])
+        by_cam = dict(zip(d["dense_ordered_cams_b0"].tolist(), d["dense_losses_b0"].tolist()))
+        assert np.allclose([by_cam[k] for k in range(bsz)], d["pre_losses"], atol=1e-7)
+        never = ~(d["sparse_visibility_b0"] | d["sparse_visibility_b1"])
+        if never.any():
+            assert np.array_equal(d["sparse_p_parameters"][never], d["shs48"][never])
+            assert not d["sparse_m_parameters"][never].any() and not d["sparse_v_xyz"][never].any()
