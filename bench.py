@@ -185,6 +185,10 @@ def parse():
     ap.add_argument("--no-heavy-leg", action="store_true",
                     help="skip the extra short single-GPU leg on the heavy-tailed scene (--scene heavy, I/V ~ 11) -> value_heavy")
     ap.add_argument("--heavy-steps", type=int, default=8)
+    ap.add_argument("--bsz", type=int, default=0, choices=[0, 4, 8, 16, 32, 64],
+                    help="cameras per batch and GPU instead of the configuration's (the reference's release scripts run "
+                         "BigCity at bsz 64, release_scripts/bigcity.sh:73-92: `--config bigcity102m --bsz 64` is the "
+                         "single-GPU form of that row); the optimizer hyper-parameters scale with it (lr_scale_mode sqrt)")
     ap.add_argument("--opt", action="append", default=[], help="engine option override, key=value")
     return ap.parse_args()
 
@@ -451,6 +455,9 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     _lib.HOST_REGIONS = {}
     _lib.REGION_TRACE = {} if os.environ.get("CLMGS_REGION_TRACE") == "1" else None
     _lib.STATS["host_prepare_s"] = 0.0
+    from clm_gs_amd import telemetry as _tel
+    tel = _tel.Sampler()
+    tel.__enter__()
     t0 = time.perf_counter()
     for b in range(a.host_warmup, n_b):
         losses_all += list(step(b))
@@ -458,6 +465,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     g.flush_lazy_rows()  # the deferred row steps still waiting after the last batch: inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tel.__exit__(None, None, None)
     regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
     peak = torch.cuda.max_memory_allocated()
     tr = _lib.STATS.get("touched_rows", [])
@@ -487,6 +495,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
                     "peak_GBps": 57.0, "note": "peak = hipMemcpyAsync pinned<->HBM measured on this node type, EITHER direction or "
                     "both together (profiles/r02_probe_host_link.json); every touched SH row crosses once per direction per batch"},
            "loss_first": round(sum(vals[:k2]) / k2, 6), "loss_last": round(sum(vals[-k2:]) / k2, 6),
+           "clocks": tel.summary(),
            "gt_images": "pinned host, uploaded per batch (train.py:310-312)"}
     del g
     gc.collect()
@@ -594,9 +603,13 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
             if hasattr(g, name):
                 setattr(g, name, timed(name, getattr(g, name)))
     ms0 = torch.cuda.memory_stats()
+    from clm_gs_amd import telemetry as _tel
+    tel = _tel.Sampler()
+    tel.__enter__()
     t0 = time.perf_counter()
     timer = trainer.training(g, _Scene, cams, [], log, iterations=n_img, test_iterations=(n_img,), phase_times=phases)
     wall = time.perf_counter() - t0
+    tel.__exit__(None, None, None)
     ms1 = torch.cuda.memory_stats()
     text = log.getvalue()
     m = re.search(r"end2end total_time: ([0-9.]+) s, iterations: (\d+), throughput ([0-9.]+) it/s", text)
@@ -621,6 +634,7 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
            "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items() if k != "reserved_bytes"},
            "allocator_reserved_bytes": int(phases.get("reserved_bytes", 0)),
            "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+           "clocks": tel.summary(),
            "schedule": {"densify_at_images": list(range(100, n_img - 49, 100)), "opacity_reset_at_image": 3 * (n_img // 4),
                         "densify_grad_threshold": float(a.trainer_grad_threshold)},
            "what": "clm_gs_amd.trainer.training on a fresh model of the bench scene: shuffled epochs over the run's cameras, "
@@ -692,6 +706,7 @@ def heavy_leg(a):
             "roofline_frac": (j.get("roofline") or {}).get("frac"), "roofline_frac_solo": (j.get("roofline") or {}).get("frac_solo"),
             "tile_kernels_solo_ms": {k: solo.get(k) for k in ("clmgs_rasterize_fwd", "clmgs_rasterize_bwd")},
             "binning_solo_ms": {k: v for k, v in solo.items() if "isect" in k},
+            "clocks": j["measured"].get("clocks"),
             "wall_s": round(time.perf_counter() - t0, 1)}
 
 
@@ -725,6 +740,8 @@ def main():
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
 
     N, W, H, bsz, vis_frac, desc = CONFIGS[a.config]
+    if a.bsz:
+        bsz = a.bsz
     args = utils.default_args(bsz=bsz, sh_residency=a.residency)
     if a.config == "bigcity102m":  # as scripted by the reference: sparse Adam, densification off
         args.sparse_adam = True
@@ -897,6 +914,11 @@ def main():
         _lib.HOST_REGIONS = {}
     from clm_gs_amd import dp as _dpm
     _dpm.reset_wire()
+    # device telemetry of the timed region (clm_gs_amd/telemetry.py): full snapshots before / after, sclk + socket power
+    # sampled at 10 Hz by a host thread that only reads sysfs files -- nothing is enqueued on the device for it
+    from clm_gs_amd import telemetry as _tel
+    _tel_main = _tel.Sampler()
+    _tel_main.__enter__()
     # ---- the timed region: exactly K steps, NO per-kernel event instrumentation inside it
     t0 = time.perf_counter()
     step_marks = []
@@ -916,6 +938,7 @@ def main():
     t_enq = time.perf_counter() - t0  # host: enqueue work + size readbacks, before the final fence
     fence()
     dt = time.perf_counter() - t0
+    _tel_main.__exit__(None, None, None)
     _lib.check_device_errors()  # a look-back scan / sort pass of the binning chain that gave up raises here
     host_wait = _lib.STATS["host_wait_s"]
     n_redo = int(_lib.STATS.get("isect_capacity_redo", 0))
@@ -1013,6 +1036,29 @@ def main():
         args.overlap_cameras = keep_mode
         del _lib.STATS["n_isects"][n_stat:]
         del _lib.STATS["n_emitted"][n_stat:]
+    # ---- evidence, outside every timed region: the block-skipping visibility pass on the TRAINED state.  The engine culls a
+    # batch from blocks of 256 rows that a conservative test (positions dilated by the waiting steps' drift bound) lets
+    # through, after stepping only those blocks' small attributes (gaussian_model.small_catch_up); here the next batch's
+    # filters from that route are compared, index for index, with the exact pass over ALL rows after every waiting step
+    # has been applied (flush_small -> clmgs_visibility_select_count without block flags).
+    block_skip = None
+    if (a.strategy == "clm_offload" and a.residency == "hbm" and world == 1 and not grouped
+            and getattr(gaussians, "small_deferred", False) and (gaussians._small_def or {}).get("hist")):
+        from clm_gs_amd.strategies.base_engine import select_filters
+        nxt = cams[a.warmup * bsz:(a.warmup + 1) * bsz]
+        with torch.no_grad():
+            waiting = len(gaussians._small_def["hist"])
+            flags = gaussians.small_catch_up(nxt)
+            f_skip, t_skip = select_filters(nxt, gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                            gaussians._rotation.detach(), block_flags=flags)
+            gaussians.flush_small()
+            f_all, t_all = select_filters(nxt, gaussians._xyz.detach(), gaussians._scaling.detach(),
+                                          gaussians._rotation.detach())
+            eq = bool(torch.equal(t_skip, t_all) and all(torch.equal(x, y) for x, y in zip(f_skip, f_all)))
+            block_skip = {"filters_equal": eq, "recorded_steps_waiting": waiting,
+                          "blocks_flagged_fraction": round(float(flags.float().mean()), 4) if flags is not None else None,
+                          "rows_selected": [int(x.numel()) for x in f_all], "union_rows": int(t_all.numel())}
+        assert eq, "block-skipping visibility pass selected different rows than the exact pass on the trained state"
     n_images = a.steps * bsz
     k2 = min(2 * bsz, max(bsz, len(loss_vals) // 2))
     loss_first = sum(loss_vals[:k2]) / k2
@@ -1035,6 +1081,18 @@ def main():
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
 
     dist_backend = torch.distributed.get_backend() if grouped else None
+    # how the caching allocator placed the row tables the gather kernels walk (one hipMalloc each, or blocks inside
+    # larger segments): clm_gs_amd/telemetry.py tensor_alloc_info
+    alloc_info = None
+    try:
+        _tabs = {}
+        if a.strategy == "clm_offload" and getattr(gaussians, "_parameters", None) is not None and gaussians._parameters.is_cuda:
+            _st = gaussians.optimizer.cpu_adam.state[gaussians._parameters]
+            _tabs = {"sh_rows": gaussians._parameters.data, "sh_exp_avg": _st["exp_avg"], "sh_exp_avg_sq": _st["exp_avg_sq"],
+                     "sh_grad_rows": gaussians.parameters_grad_buffer, "xyz": gaussians._xyz.data}
+        alloc_info = _tel.tensor_alloc_info(_tabs) if _tabs else None
+    except Exception as e:  # reporting only
+        alloc_info = {"error": f"{type(e).__name__}: {e}"}
     def _finish(allreduce_leg, clean=True):
         """Everything after the timed work: the process group is left (clean=False: the watchdog of the all-reduce leg
         calls this from its own thread while the main thread may be stuck in a collective), rank 0 assembles and prints
@@ -1180,6 +1238,9 @@ def main():
                          "I_emitted_avg": round(I_emitted, 1), "I_emitted_first_last": [emitted[0], emitted[-1]] if emitted else None,
                          "touched_rows_per_batch": round(touched_avg, 1),
                          "small_blocks_flagged_fraction": small_flagged,
+                         "clocks": _tel_main.summary(), "alloc": alloc_info,
+                         "block_skip_filters_equal": block_skip["filters_equal"] if block_skip else None,
+                         "block_skip": block_skip,
                          "pixels": P, "tiles": T, "loss_first": round(loss_first, 6), "loss_last": round(loss_last, 6),
                          "loss_per_batch": [round(sum(loss_vals[i:i + bsz]) / bsz, 5) for i in range(0, len(loss_vals), bsz)]},
             "training_check": {"ok": bool(train_ok), "rule": "mean loss of the last 2 batches <= 1.05 x mean loss of the first 2 "

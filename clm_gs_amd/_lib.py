@@ -173,6 +173,9 @@ def check_device_errors():
     (clmgs_device_errors; synchronises the device).  Called where the host synchronises anyway."""
     bits = ctypes.c_uint32(0)
     check(lib().clmgs_device_errors(ctypes.byref(bits), 1))
+    if bits.value & 4:
+        raise ClmgsError("deferred small-attribute Adam: a block of rows was further behind than the recorded step history "
+                         "(clmgs_adam_small_deferred, device error bit 4): its parameters are wrong")
     if bits.value:
         raise ClmgsError(f"binning chain: look-back timed out on the device (bits {bits.value}: 1 = scan, 2 = sort pass); "
                          "the intersection lists built since the last check are invalid")

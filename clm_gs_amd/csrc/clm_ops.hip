@@ -12,6 +12,8 @@
 #include "radix.h"
 
 namespace clmgs {
+uint32_t* device_error_word();  // isect.hip: the library's zero-initialised device error word
+
 
 template <typename IdxT>
 __device__ __forceinline__ int64_t row_of(const void* idx, int64_t i) {
@@ -604,7 +606,8 @@ adam_small_deferred_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p
                            const int32_t* __restrict__ g_stamp, int32_t* __restrict__ blk_last, SmallDeferred d,
                            float beta1, float beta2, float ob1, float ob2, float eps, float grad_scale, int C,
                            const float* __restrict__ viewmats, const float* __restrict__ Ks, float W, float H, float eps2d,
-                           float near_plane, float far_plane, int flush_all, uint8_t* __restrict__ blk_flag) {
+                           float near_plane, float far_plane, int flush_all, uint8_t* __restrict__ blk_flag, int n_hist,
+                           uint32_t* __restrict__ dev_err) {
   __shared__ __attribute__((aligned(16))) float sg[SA_ROWS * 12];
   __shared__ __attribute__((aligned(16))) float sp[SA_ROWS * 12];
   __shared__ int gstep_s[SA_ROWS];
@@ -618,8 +621,15 @@ adam_small_deferred_kernel(int64_t n, SmallAdam t, float4* __restrict__ packed_p
   const int64_t n_blocks = (n + SA_ROWS - 1) / SA_ROWS;
   for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const int last = blk_last[blk];
-    const int k = d.to_step - last;
+    int k = d.to_step - last;
     if (k <= 0 && (flush_all || !blk_flag)) continue;  // (block-uniform)
+    if (k > n_hist) {
+      // further behind than the recorded history reaches (the caller keeps kmax steps and this kernel forces a block at
+      // k == kmax, so this cannot happen while that invariant holds): replaying with another step's constants would be
+      // silently wrong -- raise bit 2 of the device error word (clmgs_device_errors) and replay what IS recorded
+      if (tid == 0 && dev_err) atomicOr(dev_err, 4u);
+      k = n_hist;
+    }
     const int64_t row0 = blk * SA_ROWS;
     const int rows = (int)min((int64_t)SA_ROWS, n - row0);
     __syncthreads();  // cam_s written / the previous block's LDS consumed
@@ -1107,7 +1117,8 @@ extern "C" int clmgs_small_deferred_kmax(void) { return SD_KMAX; }
 // blk_last[ceil(n / 256)]: the step every block of 256 rows is current as of (updated here).  flush_all != 0: every
 // block is brought to to_step (no camera needed).  Blocks more than n_hist steps behind are an error of the caller
 // (it must flush at least every n_hist steps): checked on the host side by construction (a block is never left
-// behind for kmax steps: the kernel forces it at k == kmax - 1 ... see the caller), not here.
+// behind for more than kmax steps: the kernel forces it at k == kmax, and the caller trims its history to kmax entries);
+// the kernel itself raises bit 2 of the device error word (clmgs_device_errors) if it ever meets one.
 extern "C" int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* params, float* const* exp_avg,
                                          float* const* exp_avg_sq, void* packed_p, const void* packed_g,
                                          const int32_t* g_stamp, int32_t* blk_last, int to_step, int n_hist,
@@ -1149,7 +1160,7 @@ extern "C" int clmgs_adam_small_deferred(void* stream, int64_t n, float* const* 
   hipLaunchKernelGGL(adam_small_deferred_kernel, dim3(min(ceil_div(n, SA_ROWS), 256 * 16)), dim3(SA_ROWS), 0,
                      (hipStream_t)stream, n, t, (float4*)packed_p, (const float4*)packed_g, g_stamp, blk_last, d,
                      (float)beta1, (float)beta2, ob1, ob2, (float)eps, grad_scale, C, viewmats, Ks, (float)width,
-                     (float)height, eps2d, near_plane, far_plane, flush_all, blk_flag);
+                     (float)height, eps2d, near_plane, far_plane, flush_all, blk_flag, n_hist, device_error_word());
   CLMGS_LAUNCH_CHECK();
   return 0;
 }

@@ -27,6 +27,11 @@
 
 namespace clmgs {
 
+// Wave-uniform "some lane" / "no lane" tests straight from the compare's scalar mask.  (HIP's __any() goes through an
+// int: the i1 is materialised with v_cndmask 0/1 and compared again -- two half-rate VALU per use in the blend loops.)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wave_none(bool p) { return __builtin_amdgcn_ballot_w64(p) == 0ull; }
+
 constexpr int TILE = 16;
 constexpr int PPL = 4;        // pixels per lane (one per 8x8 quadrant)
 constexpr float ALPHA_MIN = 1.f / 255.f;
@@ -119,6 +124,26 @@ __device__ __forceinline__ int quadrant_mask(float mx, float my, float opac, flo
   if (rect_min_sigma(ca, cb, cc, rca, rcc, xa0, xa1, yb0, yb1) <= Lm) m |= 4;
   if (rect_min_sigma(ca, cb, cc, rca, rcc, xb0, xb1, yb0, yb1) <= Lm) m |= 8;
   return m;
+}
+
+// SPECIAL entries (a wave-uniform flag in the entry's meta word, computed once per entry by the staging lane): opacity
+// above 0.998, or a conic that is not positive definite with a condition number far from fp32's reach.  For every
+// OTHER entry
+//   * sigma cannot round below zero (sigma >= 0.5 lambda_min |d|^2, the rounding error of the three products is
+//     <= 3 ulp x max(a, c) |d|^2, and det > 1e-5 (a + c)^2 puts lambda_min / max(a, c) fourteen times above that),
+//     so gsplat's `sigma < 0` skip never fires, and
+//   * o x G <= o <= 0.998 < 0.999, so the alpha clamp never fires and the saturated-alpha select is the identity,
+// and the blend loops jump over those instructions with scalar branches on the flag: two compares, a v_min and a
+// v_cndmask -- all half-rate VALU on this chip -- fewer per (entry, quadrant) in the backward, a compare and a v_min in
+// the forward; same results bit for bit, one copy of the loop body.
+#ifndef CLMGS_SPECIAL_ENTRIES
+#define CLMGS_SPECIAL_ENTRIES 1
+#endif
+constexpr int META_SPECIAL = 16, META_SHIFT = 5;
+__device__ __forceinline__ int special_entry(float opac, float ca, float cb, float cc) {
+  const float tr = ca + cc;
+  const bool plain = opac <= 0.998f && ca > 0.f && cc > 0.f && (ca * cc - cb * cb) > 1e-5f * tr * tr;
+  return (CLMGS_SPECIAL_ENTRIES && plain) ? 0 : META_SPECIAL;
 }
 
 // waves/SIMD the forward is compiled for: 6 (80 VGPRs, six spilled dwords) measured 0.940 vs 0.970 ms at 5
@@ -257,6 +282,10 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
   }
 }
 
+// Wave-wide sums of the backward through LDS (1) or through the permlane-swap / DPP butterflies (0).  See the loop.
+#ifndef CLMGS_BWD_LDS_REDUCE
+#define CLMGS_BWD_LDS_REDUCE 1
+#endif
 struct TileLdsBwd {
   float4 a[64];
   float4 b[64];
@@ -264,6 +293,9 @@ struct TileLdsBwd {
   int meta[64];
   int id[64];        // Gaussian id (cam*N + g) of the compacted slot, or its emit slot (PART)
   __attribute__((aligned(16))) float acc[64][12];  // reduced per-Gaussian sums of this tile (9 used)
+#if CLMGS_BWD_LDS_REDUCE
+  __attribute__((aligned(16))) float red[8][64];   // transposed scratch of the wave-wide sums: [value][lane]
+#endif
 };
 
 // DBG: profiling-only variants (1 = skip the atomics flush, 2 = skip the reduction too, 3 = phase
@@ -402,7 +434,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
     if (mask) {
       sm.a[pos] = make_float4(A.x, A.y, A.z, A.w * CONIC_DIAG);
       sm.b[pos] = make_float4(B.x * LOG2E, B.y * CONIC_DIAG, B.z, B.w);
-      sm.c[pos] = blue; sm.meta[pos] = (lane << 4) | mask;
+      sm.c[pos] = blue; sm.meta[pos] = (lane << META_SHIFT) | special_entry(A.z, A.w, B.x, B.y) | mask;
       sm.id[pos] = PART ? pid : gid;
     }
     __syncthreads();
@@ -413,7 +445,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       const float4 RB = sm.b[t];
       const int meta = __builtin_amdgcn_readfirstlane(sm.meta[t]);
       const float rblue = sm.c[t];
-      const int gi = bh - (meta >> 4);
+      const int gi = bh - (meta >> META_SHIFT);
+      const bool special = (meta & META_SPECIAL) != 0;  // wave-uniform
       if (DBG == 3) { n_ent++; n_quad += __popc(meta & 15); }
       // moments of w = v_sigma over the tile: the five screen-space gradients are linear in them
       // (g_x = a Sx + b Sy, g_y = b Sx + c Sy, g_conic = Sxx/2, Sxy, Syy/2), applied at the flush
@@ -421,37 +454,65 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
             g_o = 0.f;
       bool any_valid = false;
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        if (meta & (1 << k)) {  // wave-uniform
-          const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
-          const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
-          const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
-          const float gex = __builtin_amdgcn_exp2f(-sigma);
-          const float oa = RA.z * gex;
-          const float alpha = fminf(0.999f, oa);
-          const bool valid = (gi <= bin[k]) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
-          if (valid) {
-            any_valid = true;
-            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp), not the 10-op IEEE divide
-            T[k] *= ra;
-            const float fac = alpha * T[k];
-            g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
-            const float cv = RB.z * vr[k] + RB.w * vg[k] + rblue * vb[k];
-            // a saturated alpha (o * G > 0.999, clamped) passes no gradient to sigma / opacity: a select,
-            // not a branch (the divergent form cost an exec save/restore and six register clears per pass)
-            const float v_alpha = (oa <= 0.999f) ? T[k] * cv - ra * Bk[k] : 0.f;
-            const float w = -oa * v_alpha;  // v_sigma
-            const float wdx = w * dx, wdy = w * dy;
-            Sx += wdx; Sy += wdy;
-            Sxx += wdx * dx; Sxy += wdx * dy; Syy += wdy * dy;
-            g_o += gex * v_alpha;
-            Bk[k] += fac * cv;
+        for (int k = 0; k < PPL; ++k) {
+          if (meta & (1 << k)) {  // wave-uniform
+            const float dx = RA.x - (px0 + (float)(8 * (k & 1)));
+            const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
+            const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
+            const float gex = __builtin_amdgcn_exp2f(-sigma);
+            const float oa = RA.z * gex;
+            // (scalar branches on `special`; the empty asm keeps them branches -- if-converted they are selects again)
+            float alpha = oa;
+            bool ok = true;
+            if (__builtin_expect(special, 0)) { asm volatile(""); alpha = fminf(0.999f, oa); ok = sigma >= 0.f; }
+            const bool valid = ok & (gi <= bin[k]) & (alpha >= ALPHA_MIN);
+            if (valid) {
+              any_valid = true;
+              const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp), not the 10-op IEEE divide
+              T[k] *= ra;
+              const float fac = alpha * T[k];
+              g_r += fac * vr[k]; g_g += fac * vg[k]; g_b += fac * vb[k];
+              const float cv = RB.z * vr[k] + RB.w * vg[k] + rblue * vb[k];
+              // a saturated alpha (o * G > 0.999, clamped; special entries only) passes no gradient to sigma / opacity
+              float v_alpha = T[k] * cv - ra * Bk[k];
+              if (__builtin_expect(special, 0)) { asm volatile(""); v_alpha = (oa <= 0.999f) ? v_alpha : 0.f; }
+              const float w = -oa * v_alpha;  // v_sigma
+              const float wdx = w * dx, wdy = w * dy;
+              Sx += wdx; Sy += wdy;
+              Sxx += wdx * dx; Sxy += wdx * dy; Syy += wdy * dy;
+              g_o += gex * v_alpha;
+              Bk[k] += fac * cv;
+            }
           }
         }
-      }
-      if (!__any(any_valid)) continue;
+      if (wave_none(any_valid)) continue;
       if (DBG == 3) n_valid++;
       if (DBG != 2) {
+#if CLMGS_BWD_LDS_REDUCE
+        // Eight of the nine wave-wide sums through LDS, transposed: lane L stores value q at red[q][L] (four
+        // ds_write2st64_b32: the two values of a pair lie 64 dwords apart); lane j = 8 q + c then loads the 8
+        // consecutive floats red[q][8c .. 8c+7] (two ds_read_b128, conflict-free), adds them (7 VALU) and three
+        // row_shr DPP adds finish value q in lane 8 q + 7.  ~12 issue slots for eight sums against ~37 for the two
+        // permlane-swap butterflies; the LDS instructions issue beside other waves' VALU.  The ninth sum (opacity)
+        // keeps its DPP chain.  One wave per workgroup: LDS operations of a wave execute in order, the fences only
+        // keep the compiler from moving the loads above the stores.
+        sm.red[0][lane] = Sx; sm.red[1][lane] = Sy; sm.red[2][lane] = Sxx; sm.red[3][lane] = Sxy;
+        sm.red[4][lane] = Syy; sm.red[5][lane] = g_r; sm.red[6][lane] = g_g; sm.red[7][lane] = g_b;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        const float4* rp = reinterpret_cast<const float4*>(&sm.red[lane >> 3][8 * (lane & 7)]);
+        const float4 r0 = rp[0], r1 = rp[1];
+        g_o = wave_sum_to_lane63(g_o);
+        float u = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
+        u = dpp_add<0x111>(u);
+        u = dpp_add<0x112>(u);
+        u = dpp_add<0x114>(u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();  // (the next entry's stores stay below this entry's loads)
+        if ((lane & 7) == 7) sm.acc[t][lane >> 3] = u;   // Sx Sy Sxx Sxy | Syy r g b | o
+        if (lane == 63) sm.acc[t][8] = g_o;
+#else
         // 9 wave-wide sums: two 4-packs on the permlane-swap butterfly + one plain DPP chain
         const float u1 = wave_sum4_rows(Sx, Sy, Sxx, Sxy);       // lanes 15/31/47/63: Sx, Sxx, Sy, Sxy
         const float u2 = wave_sum4_rows(Syy, g_r, g_g, g_b);     //                    Syy, g, r, b
@@ -464,6 +525,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           a[4 + m] = u2;
           if (lane == 63) a[8] = g_o;
         }
+#endif
       }
       touched |= (1ull << t);
     }

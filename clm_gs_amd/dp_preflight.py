@@ -17,7 +17,7 @@ kills it when it expires: a collective that hangs, aborts the process or faults 
 not the run.  bench.py then agrees on min(ok) over the ranks and falls back to the plain all-reduce exchange
 (north_star's camera-DP) when any rank's pre-flight failed -- `dp.fallback` in its JSON line says so.
 
-CLMGS_PREFLIGHT_INJECT (test hook): "raise" = the locality collective raises on rank 0, "corrupt" = rank 0's border
+CLMGS_PREFLIGHT_INJECT (test hook, only with CLMGS_TEST_HOOKS=1): "raise" = the locality collective raises on rank 0, "corrupt" = rank 0's border
 parameter rows arrive wrong, "hang" = rank 0 never returns from it.
 """
 import argparse
@@ -178,7 +178,8 @@ def child_main():
             dist.init_process_group("nccl", device_id=dev, **kw)
         else:
             dist.init_process_group(a.backend, **kw)
-        inject = os.environ.get("CLMGS_PREFLIGHT_INJECT", "")
+        # fault injection for the fallback tests: honoured only when CLMGS_TEST_HOOKS=1 is set as well (the test suite does)
+        inject = os.environ.get("CLMGS_PREFLIGHT_INJECT", "") if os.environ.get("CLMGS_TEST_HOOKS") == "1" else ""
         if inject and a.rank == 0:
             real = dist.all_to_all_single
             calls = {"n": 0}

@@ -278,12 +278,33 @@ def reserve_working_set(gaussians, n_cameras_in_flight=2):
         # gradient / statistics tables 112 B per row), which are re-created BEFORE their predecessors are freed
         "default": (torch.cuda.current_stream(), 240 * N + 64 * V * 4),
     }
+    # A convenience, never a requirement: every reservation is capped so that all of them together take at most a third
+    # of the memory that is free NOW (a model whose tables nearly fill the device simply runs without the warm-up and
+    # pays the hipMallocs it would have paid), and an out-of-memory answer skips the block instead of ending the setup.
     out = {}
+    try:
+        free_now = torch.cuda.mem_get_info(gaussians._xyz.device)[0]
+    except Exception:  # noqa: BLE001
+        free_now = None
+    total = sum(int(nb) for _, nb in plan.values())
+    shrink = 1.0 if not free_now or total <= free_now / 3 else (free_now / 3) / total
     for name, (st, nbytes) in plan.items():
-        with torch.cuda.stream(st):
-            blk = torch.empty((int(nbytes),), dtype=torch.uint8, device=gaussians._xyz.device)
-            del blk
-        out[name] = int(nbytes)
+        nbytes = int(nbytes * shrink)
+        if nbytes < (1 << 20):
+            out[name] = 0
+            continue
+        try:
+            with torch.cuda.stream(st):
+                blk = torch.empty((nbytes,), dtype=torch.uint8, device=gaussians._xyz.device)
+                # ... and the SMALL pool of the stream (requests <= 1 MB are carved from 2 MB segments of their own: the
+                # counters, count read-backs and per-camera scalars of a batch; round 5's trainer leg still made 8 such
+                # hipMallocs in its first iterations): 8 MB = four segments, held together so that four are created
+                small = [torch.empty((1 << 19,), dtype=torch.uint8, device=gaussians._xyz.device) for _ in range(16)]
+                del blk, small
+            out[name] = nbytes
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            out[name] = 0
     return out
 
 
@@ -380,8 +401,7 @@ def _stage_plan(b):
     b.params.grad = b.grad_buf
     b.row_adam.global_step += 1
     b.step = b.row_adam.global_step
-    gaussians._lazy_dirty = True   # deferred row steps will be waiting (flush_lazy_rows clears it)
-    gaussians._sorted_tag = None   # positions move: "the rows are in Z-order of their current positions" ends here
+    _mark_batch(gaussians)
     b.group = b.row_adam.param_groups[0]
     b.st = b.row_adam.state[b.params]
     b.default_stream = torch.cuda.current_stream()
@@ -394,6 +414,15 @@ def _stage_plan(b):
     # first-touch gradient stores (gaussian_model.first_touch_grads): the projection/SH backward stamps
     # `_row_g_step` itself and stores instead of accumulating on a row's first touch of this step
     b.ft_stamp = gaussians._row_g_step if (b.lazy and b.fused and gaussians.first_touch_grads) else None
+
+
+def _mark_batch(gaussians):
+    """Every engine path that advances the row optimizer's step counter calls this: deferred row steps will be waiting
+    (flush_lazy_rows clears the flag), and positions move -- "the rows are in Z-order of their current positions" ends
+    here (gaussian_model.spatial_sort keys its shortcut on the mutation counter)."""
+    gaussians._lazy_dirty = True
+    gaussians._mutations = getattr(gaussians, "_mutations", 0) + 1
+    gaussians._sorted_tag = None
 
 
 def _row_update(b, rows, zero_grad_rows=False):
@@ -1091,6 +1120,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         utils.fill_rows(visibility_mask, touched_rows, True)
     _gpu_adam_step(gaussians, args, visibility_mask)
     gaussians.invalidate_small_packed()
+    _mark_batch(gaussians)
     row_adam.global_step = step
     row_adam.state[gaussians._parameters]["step"] = step
     return losses, ordered_cams, sparsity

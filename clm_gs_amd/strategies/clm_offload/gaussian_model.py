@@ -75,6 +75,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         return self._parameters.detach().reshape(-1, 16, 3)
 
     def create_from_tensors(self, xyz, shs48, scaling, rotation, opacity, spatial_lr_scale=1.0):
+        # new tensors replace the model (first creation, load, restore): whatever the previous optimizer still had waiting
+        # belonged to the tensors that are going away -- dropped with them, never replayed onto the new ones
+        self.optimizer = None
+        self._small_def, self._small_def_dirty = None, False
+        self._lazy_dirty, self._sorted_tag = True, None
+        self._mutations = getattr(self, "_mutations", 0) + 1
+        self._small_key = None  # (the packed mirror of the small attributes is rebuilt from the new tensors)
         self.spatial_lr_scale = spatial_lr_scale
         n = xyz.shape[0]
         cap = self._capacity_for(n)
@@ -96,6 +103,17 @@ class GaussianModelCLMOffload(BaseGaussianModel):
 
     # ----------------------------------------------------------- optimiser
     def training_setup(self, training_args):
+        # a model that has trained since its last flush (restore() / a second training_setup()): the waiting steps belong
+        # to the OLD optimizer -- apply them before it is discarded, then start from clean deferral flags
+        if getattr(self, "optimizer", None) is not None:
+            if getattr(self, "_small_def", None) and not self._small_def_clean():
+                self.flush_small()
+            if self.lazy_rows and getattr(self, "_lazy_dirty", False):
+                self.flush_lazy_rows()
+        self._small_def_dirty = False
+        self._lazy_dirty = True
+        self._mutations = getattr(self, "_mutations", 0) + 1
+        self._sorted_tag = None
         self.percent_dense = training_args.percent_dense
         n = self.get_xyz.shape[0]
         self.xyz_gradient_accum = torch.zeros((n, 1), device="cuda")
@@ -631,6 +649,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self.optimizer.state = self.optimizer.gpu_adam.state | self.optimizer.cpu_adam.state
 
     def _replace_gpu(self, name, attr, new_tensor, state_fn):
+        self._mutations = getattr(self, "_mutations", 0) + 1  # (spatial_sort's "already sorted" shortcut ends here)
         opt = self.optimizer.gpu_adam
         for g in opt.param_groups:
             if g["name"] != name:
@@ -778,11 +797,16 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         from ... import clm_kernels
         idx = idx.contiguous()
         free = self.parameters_grad_buffer
+        if __debug__ and self.lazy_rows and os.environ.get("CLMGS_DEBUG_CHECKS") == "1":
+            n_ = int(self._parameters.shape[0])  # (a device read: debug runs only)
+            assert not bool((self._row_g_step[:n_] > self._row_last_step[:n_]).any()), "a gradient row still waits"
         for attr in self._full_row_buffers():
             if attr == "parameters_grad_buffer":
                 continue
             buf = getattr(self, attr)
-            assert buf.shape == free.shape
+            if buf.shape != free.shape:
+                raise RuntimeError(f"row tables of different capacity ({attr}: {tuple(buf.shape)} vs {tuple(free.shape)}): "
+                                   "the table rotation of _regather_row_tables needs equal capacities")
             if m:
                 clm_kernels._rows("clmgs_rows_gather", free[:m], buf, None, idx, 0)
             setattr(self, attr, free)
@@ -832,12 +856,17 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if self.sh_on_host and resort:
             self.spatial_sort()
         self.invalidate_small_packed()
-        self._sorted_tag = (self._xyz.data_ptr(), m) if resort else None
+        self._mutations = getattr(self, "_mutations", 0) + 1
+        self._sorted_tag = (self._mutations, m) if resort else None
 
     def spatial_sort(self):
-        if getattr(self, "_sorted_tag", None) == (self._xyz.data_ptr(), self._xyz.shape[0]):
-            return  # prune_points(resort=True) has just left the rows in this very order (the engine clears the tag)
+        # The tag is (model-mutation counter, rows): every path that moves a position or replaces a table bumps the counter
+        # (training_setup, prune / append / permute, every engine batch, load) -- an address can be reused by the caching
+        # allocator for a same-sized tensor, a counter cannot.
+        if getattr(self, "_sorted_tag", None) == (getattr(self, "_mutations", 0), self._xyz.shape[0]):
+            return  # prune_points(resort=True) has just left the rows in this very order
         super().spatial_sort()
+        self._mutations = getattr(self, "_mutations", 0) + 1
 
     def permute_rows(self, order):
         n = self._parameters.shape[0]

@@ -474,8 +474,8 @@ int clmgs_adam_small_packed_range(void* stream, int64_t n, int64_t row_begin, in
  * strategies/clm_offload/engine.py:870-882 / optimizer.py:91-184 -- same arithmetic per step, applied later).
  * blk_last[ceil(n/256)] holds the optimizer step each block is current as of.  A call brings up to `to_step` every
  * block that (a) may hold a row visible in one of the C cameras when its values are stale by the waiting steps'
- * worth of Adam's step bound (pos_margin[k], scale_gain[k] for k waiting steps), (b) is clmgs_small_deferred_kmax() - 1
- * or more steps behind, or (c) any block at all when flush_all != 0 -- replaying the waiting steps one by one with the
+ * worth of Adam's step bound (pos_margin[k], scale_gain[k] for k waiting steps), (b) is clmgs_small_deferred_kmax()
+ * steps behind, or (c) any block at all when flush_all != 0 -- replaying the waiting steps one by one with the
  * constants of THEIR step (lr4_hist[j][4], step_index[j]: entry j describes step to_step - j; n_hist entries) and the
  * row's waiting gradient line (packed_g row, stamp g_stamp[row]) at the step it belongs to.  Bit-identical to the
  * eager sequence; the packed mirror is refreshed for the blocks processed. */
@@ -495,7 +495,8 @@ int clmgs_debug_counters(unsigned long long* out16, int reset);
 /* Device error word of the single-launch scan / sort-pass kernels of the binning chain (csrc/onesweep.h: workgroups
  * of one launch hand per-chunk aggregates to each other by decoupled look-back; every poll loop is bounded).
  * *bits: 1 = a scan look-back, 2 = a sort-pass look-back gave up after its bound -- the lists of that call are
- * invalid.  Synchronises the device; `reset` clears the word.  No reference counterpart (gsplat.isect_tiles sorts
+ * invalid; 4 = clmgs_adam_small_deferred met a block further behind than the step history it was given (the caller's
+ * invariant was broken: those rows' parameters are wrong).  Synchronises the device; `reset` clears the word.  No reference counterpart (gsplat.isect_tiles sorts
  * with cub, strategies/base_engine.py:175-186); callers check it where they synchronise anyway (evaluation, saving,
  * the end of a benchmark). */
 int clmgs_device_errors(uint32_t* bits, int reset);

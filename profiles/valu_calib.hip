@@ -12,10 +12,13 @@
 constexpr int CHAINS = 8;
 constexpr int UNROLL = 16;  // instructions per chain per loop trip
 
-enum Op { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERMLANE32_SWAP, CNDMASK, LDS_B128_BCAST, FMA_WITH_SALU, MIN_CMP, PK_FMA, PK_MUL, PK_ADD, N_OPS };
+enum Op { FMA = 0, MUL_ADD, EXP, RCP, DPP_ADD, PERMLANE32_SWAP, CNDMASK, LDS_B128_BCAST, FMA_WITH_SALU, MIN_CMP, PK_FMA, PK_MUL, PK_ADD,
+          CNDMASK_SGPR, CMP_CNDMASK_VCC, CMP_CNDMASK_SGPR, CNDMASK_VCC_2SRC, MAX_F32, AND_B32, MOV_B32, MED3_F32, CMP_ONLY, N_OPS };
 static const char* NAMES[N_OPS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp(row_shr:1)",
                                    "v_permlane32_swap_b32", "v_cndmask_b32(vcc)", "ds_read_b128(broadcast)", "v_fma_f32 + 1 s_add per 2",
-                                   "v_min_f32+v_cmp_ge_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"};
+                                   "v_min_f32+v_cmp_ge_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32",
+                                   "v_cndmask_b32_e64(sgpr pair)", "v_cmp_gt_f32(vcc)+v_cndmask_b32(vcc)", "v_cmp_gt_f32_e64(sgpr)+v_cndmask_b32_e64(sgpr)",
+                                   "v_cndmask_b32(vcc) dst!=src", "v_max_f32", "v_and_b32", "v_mov_b32", "v_med3_f32", "v_cmp_gt_f32(vcc)"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned long long* cycles) {
@@ -30,6 +33,8 @@ __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned lon
   const f2 a2 = f2{0.999f, 0.998f}, b2 = f2{1e-4f, 2e-4f};
   const float a = 0.999f, b = 1e-4f;
   int sacc = 0;
+  unsigned long long smask = 0x5555555555555555ull + (unsigned long long)(trips == 123456);
+  asm volatile("s_mov_b64 vcc, %0" : : "s"(smask) : "vcc");
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int t = 0; t < trips; ++t) {
 #pragma unroll
@@ -56,6 +61,15 @@ __global__ void __launch_bounds__(256) calib(int trips, float* out, unsigned lon
         if (OP == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[c]) : "v"(a2), "v"(b2));
         if (OP == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w[c]) : "v"(a2));
         if (OP == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(w[c]) : "v"(b2));
+        if (OP == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "s"(smask));
+        if (OP == CMP_CNDMASK_VCC) { asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(v[c]), "v"(b) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(a) : "vcc"); }
+        if (OP == CMP_CNDMASK_SGPR) { unsigned long long m_; asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m_) : "v"(v[c]), "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "s"(m_)); }
+        if (OP == CNDMASK_VCC_2SRC) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(v[c]) : "v"(v[(c + 1) % CHAINS]), "v"(a));
+        if (OP == MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[c]) : "v"(a));
+        if (OP == AND_B32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[c]) : "v"(a));
+        if (OP == MOV_B32) asm volatile("v_mov_b32 %0, %1" : "=v"(v[c]) : "v"(v[(c + 1) % CHAINS]));
+        if (OP == MED3_F32) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));
+        if (OP == CMP_ONLY) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(v[c]), "v"(b) : "vcc");
         if (OP == MIN_CMP) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[c]) : "v"(a)); asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(v[c]), "v"(b) : "vcc"); }
       }
     }
@@ -84,7 +98,7 @@ void run(int waves_per_simd, float* out, unsigned long long* cyc_d) {
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   unsigned long long cyc = 0;
   CHECK(hipMemcpy(&cyc, cyc_d, sizeof(cyc), hipMemcpyDeviceToHost));
-  int per = (OP == MUL_ADD || OP == MIN_CMP) ? 2 : 1;
+  int per = (OP == MUL_ADD || OP == MIN_CMP || OP == CMP_CNDMASK_VCC || OP == CMP_CNDMASK_SGPR) ? 2 : 1;
   const double instr_per_wave = (double)trips * UNROLL * CHAINS * per;
   const double total = instr_per_wave * blocks * 4;
   printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"G_wave_instr_per_s\": %.1f, \"cycles_per_instr_per_simd\": %.2f, \"ms\": %.3f}\n",
@@ -94,7 +108,10 @@ void run(int waves_per_simd, float* out, unsigned long long* cyc_d) {
 int main() {
   float* out; unsigned long long* cyc;
   CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&cyc, 64));
-  for (int w : {8, 4}) {
+  for (int w : {8, 5, 4}) {
+    run<CNDMASK_SGPR>(w, out, cyc); run<CMP_CNDMASK_VCC>(w, out, cyc); run<CMP_CNDMASK_SGPR>(w, out, cyc);
+    run<CNDMASK_VCC_2SRC>(w, out, cyc); run<MAX_F32>(w, out, cyc); run<AND_B32>(w, out, cyc); run<MOV_B32>(w, out, cyc);
+    run<MED3_F32>(w, out, cyc); run<CMP_ONLY>(w, out, cyc);
     run<FMA>(w, out, cyc); run<MUL_ADD>(w, out, cyc); run<EXP>(w, out, cyc); run<RCP>(w, out, cyc);
     run<DPP_ADD>(w, out, cyc); run<PERMLANE32_SWAP>(w, out, cyc); run<CNDMASK>(w, out, cyc);
     run<LDS_B128_BCAST>(w, out, cyc); run<MIN_CMP>(w, out, cyc);

@@ -13,6 +13,7 @@ from clm_gs_amd import dp_preflight
 
 def _run(world, inject=None, timeout=90.0):
     old = os.environ.get("CLMGS_PREFLIGHT_INJECT")
+    os.environ["CLMGS_TEST_HOOKS"] = "1"  # (dp_preflight honours the injection only with this set)
     if inject:
         os.environ["CLMGS_PREFLIGHT_INJECT"] = inject
     else:

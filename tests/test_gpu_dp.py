@@ -220,7 +220,7 @@ def test_bench_falls_back_to_allreduce_when_the_preflight_fails(dev):
     collective of the pre-flight is made to fail on rank 0 (CLMGS_PREFLIGHT_INJECT): the run must still print ONE line
     with n_gpus == 2, in the plain all-reduce mode, and say why."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1", CLMGS_PREFLIGHT_INJECT="raise")
+    env.update(CLMGS_DIST_BACKEND="gloo", CLMGS_SHARE_GPU="1", CLMGS_PREFLIGHT_INJECT="raise", CLMGS_TEST_HOOKS="1")
     out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                 "--config", "small", "--prime-seconds", "0"], env=env)
     lines = [l for l in out.splitlines() if l.startswith("{")]

@@ -306,6 +306,42 @@ def test_capture_restore_resumes_training(dev, strategy, residency):
         assert _frac_differs(a.detach(), b.detach(), init, 0.02) < 0.01
 
 
+def test_restore_onto_a_model_that_is_mid_training_drops_its_waiting_steps(dev):
+    """train -> restore(old_state) -> train on the SAME model object: the deferred small-attribute steps and the
+    deferred row steps the interrupted run still had waiting belong to tensors / an optimizer that restore() replaces;
+    they must be dropped with them (not replayed onto the restored tensors, not trip the "row count changed with steps
+    waiting" assertion), and the run must continue exactly like a fresh model restored from the same state."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+
+    def one_batch(m, cams, it):
+        utils.set_cur_iter(it)
+        m.update_learning_rate(it)
+        clm_offload_train_one_batch(m, _Scene, cams, m.parameters_grad_buffer, None, None,
+                                    torch.cuda.Stream(), torch.Generator(device="cuda"))
+        torch.cuda.synchronize()
+
+    args, sc, cams = _setup("clm_offload", "hbm")
+    m = _make("clm_offload", sc, args)
+    one_batch(m, cams, 1)
+    state = m.capture()               # (capture flushes: `state` is a consistent checkpoint after batch 1)
+    one_batch(m, cams, 5)
+    one_batch(m, cams, 9)             # steps of these two batches are waiting (deferred) when restore() arrives
+    assert m.small_deferred and not m._small_def_clean()
+    m.restore(state, args)            # same object
+    assert m._small_def_clean() and m._sorted_tag is None
+    one_batch(m, cams, 5)
+    m.flush_lazy_rows()
+    m.flush_small()
+    m2 = type(m)(3)
+    m2.restore(state, args)
+    one_batch(m2, cams, 5)
+    m2.flush_lazy_rows()
+    m2.flush_small()
+    for a, b in zip(m.all_parameters(), m2.all_parameters()):
+        assert torch.equal(a.detach(), b.detach())
+
+
 def test_order_calculation_invariants(dev):
     from clm_gs_amd.strategies.base_engine import calculate_filters
     from clm_gs_amd.strategies.clm_offload.engine import order_calculation
