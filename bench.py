@@ -144,6 +144,11 @@ def parse():
                          "once when the model is built, as a loader would); random: the generator's order")
     ap.add_argument("--no-host-leg", action="store_true",
                     help="skip the second leg (the same workload with the SH rows + Adam state in pinned host memory)")
+    ap.add_argument("--host-staging", default="window", choices=["window", "batch"],
+                    help="host-resident leg: per-camera staging windows (strategies/clm_offload/host_window.py, the default) "
+                         "or the union of the batch's rows (the round-2..5 form)")
+    ap.add_argument("--no-host-staging-pair", action="store_true",
+                    help="skip the second, shorter host-resident leg with the other staging form")
     ap.add_argument("--host-steps", type=int, default=20)
     ap.add_argument("--host-warmup", type=int, default=2)
     ap.add_argument("--no-host-hint", action="store_true",
@@ -409,7 +414,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
         c.original_image = None
     gc.collect()
     torch.cuda.empty_cache()
-    args = utils.default_args(bsz=bsz, sh_residency="host")
+    args = utils.default_args(bsz=bsz, sh_residency="host", host_staging=a.host_staging)
     args.clm_offload = True
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -479,7 +484,7 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
            "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
            "late_rows_per_batch": (round(sum(_lib.STATS.get("host_late_rows", [])[-host_steps:]) / host_steps, 1)
                                    if _lib.STATS.get("host_late_rows") else None),
-           "speculative_prefetch": not a.no_host_hint,
+           "speculative_prefetch": not a.no_host_hint, "staging": a.host_staging,
            "final_flush_ms": round((dt - t_batches) * 1e3, 1),
            "value_steady": round(host_steps * bsz / t_batches, 3),
            "value_note": "value = timed batches + the flush of the deferred host row steps still waiting after the last batch "
@@ -1091,8 +1096,24 @@ def main():
             _tabs = {"sh_rows": gaussians._parameters.data, "sh_exp_avg": _st["exp_avg"], "sh_exp_avg_sq": _st["exp_avg_sq"],
                      "sh_grad_rows": gaussians.parameters_grad_buffer, "xyz": gaussians._xyz.data}
         alloc_info = _tel.tensor_alloc_info(_tabs) if _tabs else None
+        # ... and how fast THIS process streams each of them (a plain read of the whole table, best of 3, event-timed): the
+        # same table has read at different rates in different processes on one box (physical placement is the driver's), and
+        # the gather kernels' durations move with it
+        for _nm, _t in _tabs.items():
+            _flat, _best = _t.reshape(-1), None
+            for _ in range(3):
+                _e0, _e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                _e0.record()
+                _flat.sum()
+                _e1.record()
+                _e1.synchronize()
+                _ms = _e0.elapsed_time(_e1)
+                _best = _ms if _best is None else min(_best, _ms)
+            alloc_info[_nm]["read_GBps"] = round(_flat.numel() * 4 / (_best * 1e-3) / 1e9, 1)
+        _tabs = _flat = _t = _st = None  # (no reference to the tables may outlive this block: the later legs free the model)
     except Exception as e:  # reporting only
         alloc_info = {"error": f"{type(e).__name__}: {e}"}
+        _tabs = _flat = _t = _st = None
     def _finish(allreduce_leg, clean=True):
         """Everything after the timed work: the process group is left (clean=False: the watchdog of the all-reduce leg
         calls this from its own thread while the main thread may be stuck in a collective), rank 0 assembles and prints
@@ -1271,6 +1292,19 @@ def main():
                 out["host_resident"] = host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
             except Exception as e:  # reported, never fatal for the headline
                 out["host_resident"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            # ... and the other staging form beside it (a shorter leg): per-camera windows trade ~10 % of the rate for 5 GB
+            if not a.no_host_staging_pair:
+                try:
+                    import copy
+                    a2 = copy.copy(a)
+                    a2.host_staging = "batch" if a.host_staging == "window" else "window"
+                    a2.host_steps = min(a.host_steps, 10)
+                    h2 = host_resident_leg(a2, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
+                    out["host_resident_other_staging"] = {k: h2.get(k) for k in (
+                        "staging", "value", "value_steady", "ms_per_step", "steps", "peak_gpu_bytes", "late_rows_per_batch",
+                        "host_pool_busy_fraction", "link")}
+                except Exception as e:
+                    out["host_resident_other_staging"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if (not a.no_trainer_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
                 and a.config in ("rubble28m", "rubble10m", "small")):
             try:

@@ -871,6 +871,11 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
       stores, no read-modify-write over the link, no host pass), on a second side stream; they wait there,
       stamped with this batch's step, until the row is needed again.
     """
+    if getattr(args, "host_staging", "window") == "window":
+        # per-camera staging windows (host_window.py): the same link traffic from half the staging memory
+        from .host_window import train_one_batch_host_windowed
+        return train_one_batch_host_windowed(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
+                                             pipe_args, comm_stream, perm_generator, args)
     from ...fused import train_one_camera
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]

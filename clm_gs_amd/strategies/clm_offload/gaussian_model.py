@@ -585,16 +585,17 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         """Forget the rows the engine staged for a hinted batch that is not coming (model resized / flushed /
         evaluated / different cameras): they were stamped as expecting that batch's gradient, which will never
         land (clm_offload/engine.py speculative prefetch)."""
-        sp = getattr(self, "_host_spec", None)
-        self._host_spec = None
-        if sp is None:
-            return
-        sp["thread"].join()
-        ev = sp.get("event")
-        if ev is not None:
-            ev.synchronize()  # the thread's last hipMemcpyAsync into the second staging table has landed
-        if sp["n"]:
-            self._host_g_step[sp["rows_h"][:sp["n"]].long()] = 0
+        for attr in ("_host_spec", "_hwin_spec"):  # (batch-wide staging / per-camera windows: engine.py / host_window.py)
+            sp = getattr(self, attr, None)
+            setattr(self, attr, None)
+            if sp is None:
+                continue
+            sp["thread"].join()
+            ev = sp.get("event")
+            if ev is not None:
+                ev.synchronize()  # the thread's last hipMemcpyAsync into the staging table has landed
+            if sp["n"]:
+                self._host_g_step[sp["rows_h"][:sp["n"]].long()] = 0
 
     def host_rows_prepare(self, rows_host, stage_host, to_step=None, next_g_step=0, n_rows=None, sync_grads=True):
         """Bring host rows (int32 pinned/CPU row list, None = all) up to `to_step` (default: the optimizer's

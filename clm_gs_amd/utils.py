@@ -68,6 +68,8 @@ def default_args(**over):
         defer_loss_log=True,    # trainer: a batch's loss line is written once the NEXT batch is enqueued (no device drain)
         spatial_row_order=True,   # trainer: keep the rows in Z-order of (x, y) (after loading / densification)
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
+        host_staging="window",           # host-resident mode: "window" = per-camera staging tables + the rows several cameras
+                                         # share (strategies/clm_offload/host_window.py), "batch" = the union of the batch's rows
         host_speculative_prefetch=True,  # host-resident mode: stage the hinted next batch's untouched rows early
         device_side_counts=True,   # fused engine: consumers of a camera's intersection list read its length on the device
         isect_capacity_margin=1.25,  # ... from buffers sized (largest count seen at this image size) x margin

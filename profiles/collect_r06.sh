@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round-6 recipe behind profiles/r06_* (GPU box, repo root; ~25 GPU-minutes).  Parity reports come from the test suite
+# (gpurun_out/parity_fullsize.json, parity_report*.json); probes: valu_calib.hip, gather_probe.hip, raster_microbench.py.
+set -x
+R=$(pwd)
+O=$R/gpurun_out/r06c; mkdir -p $O
+N="--no-cpu-baseline --no-host-leg --no-trainer-leg --no-heavy-leg"
+# 1. the driver's command (all legs: value, value_gt_streamed, value_heavy, host_resident, trainer, cpu_baseline)
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_28m_final.log 2> $O/bench_28m_final.err
+# 2. kernel trace of the timed steps only (in situ), one pipelined batch as a timeline
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_s /tmp/pmcF /tmp/pmcW /tmp/pmcS
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --steps 8 --warmup 3 $N --no-kernel-timing --gt resident > $O/prof_s.log 2>&1
+DB=$(find /tmp/prof_s -name "*.db" | head -1)
+python $R/profiles/kernel_stats.py "$DB" 165 > $O/kernel_stats.csv
+python $R/profiles/timeline.py $DB step3 > $O/timeline_step.txt 2>&1
+python $R/profiles/timeline_streams.py $DB step3 > $O/timeline_streams.txt 2>&1
+cd $R
+# 3. the same kernels with nothing co-running
+bash $R/profiles/solo_trace.sh r06solo > /dev/null 2>&1; cp $R/gpurun_out/r4/solo_kernel_stats_r06solo.csv $O/kernel_stats_single_stream.csv
+# 4. PMC passes (separate, --kernel-trace only)
+cd /tmp
+B="python $R/bench.py --steps 2 --warmup 2 $N --no-kernel-timing --gt resident --prime-seconds 0"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -o f -- $B > $O/pmcF.log 2>&1
+python $R/profiles/pmc_summary.py $(find /tmp/pmcF -name "*counter_collection.csv" | head -1) > $O/pmc_fetch_size.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -o w -- $B > $O/pmcW.log 2>&1
+python $R/profiles/pmc_summary.py $(find /tmp/pmcW -name "*counter_collection.csv" | head -1) > $O/pmc_write_size.txt 2>&1
+echo "== SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" > $O/pmc_sq_counters.txt
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pmcS -o s -- $B --opt overlap_cameras=false > $O/pmcS.log 2>&1
+python $R/profiles/pmc_summary.py $(find /tmp/pmcS -name "*counter_collection.csv" | head -1) >> $O/pmc_sq_counters.txt 2>&1
+cd $R
+timeout 300 python bench.py --steps 10 --warmup 3 $N > $O/bench_28m_for_pmc.log 2>&1
+cp profiles/pmc_traffic.json $O/pmc_traffic_before.json
+python profiles/make_pmc_json.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt $O/pmc_sq_counters.txt "round 6 HEAD" $O/bench_28m_for_pmc.log > $O/pmc_traffic_summary.txt 2>&1
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# 5. A/B legs (same box)
+timeout 300 python bench.py --steps 10 --warmup 3 $N --opt overlap_cameras=false > $O/bench_28m_no_overlap.log 2>&1
+timeout 400 python bench.py --scene heavy --steps 10 --warmup 3 $N > $O/bench_28m_heavy.log 2>&1
+# 6. the other BASELINE.json configurations
+timeout 400 python bench.py --config rubble10m --steps 10 --warmup 3 $N > $O/bench_rubble10m_clm.log 2>&1
+timeout 300 python bench.py --config bicycle6m --strategy no_offload --steps 10 --warmup 3 $N > $O/bench_bicycle6m_no_offload.log 2>&1
+timeout 300 python bench.py --config bicycle6m --steps 10 --warmup 3 $N > $O/bench_bicycle6m_clm.log 2>&1
+timeout 400 python bench.py --config bigcity102m --steps 6 --warmup 2 $N > $O/bench_bigcity102m_1gpu.log 2>&1
+# 7. probes
+timeout 200 python profiles/raster_microbench.py > $O/raster_microbench.txt 2>&1
+timeout 200 python profiles/raster_microbench.py heavy 10 >> $O/raster_microbench.txt 2>&1
+timeout 200 python profiles/catch_up_microbench.py > $O/catch_up_microbench.txt 2>&1
+ls -la $O

@@ -24,7 +24,10 @@ FUSED = True
 def _setup(strategy, residency="hbm", sparse=False, seed=0):
     from clm_gs_amd import utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
-    args = utils.default_args(bsz=BSZ, sh_residency=residency, sparse_adam=sparse, fused_front_end=FUSED)
+    staging = {}
+    if residency == "host_batch":  # host-resident rows staged as the union of the batch (engine._train_one_batch_host)
+        residency, staging = "host", {"host_staging": "batch"}
+    args = utils.default_args(bsz=BSZ, sh_residency=residency, sparse_adam=sparse, fused_front_end=FUSED, **staging)
     setattr(args, strategy, True)
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -684,8 +687,10 @@ def test_device_side_counts_equal_exact_sizes_and_survive_overflow(dev):
     fused._CAPACITY.clear(); fused._CAP_HELD.clear()
 
 
-def test_host_speculative_prefetch_is_exact(dev):
-    """Host-resident mode with hint_next_batch: the next batch's untouched rows are brought up to date and shipped
+@pytest.mark.parametrize("staging", ["host", "host_batch"])
+def test_host_speculative_prefetch_is_exact(dev, staging):
+    """(both staging forms: per-camera windows, host_window.py, and the union of the batch)
+    Host-resident mode with hint_next_batch: the next batch's untouched rows are brought up to date and shipped
     while the present batch renders, verified against the exact selection when the batch arrives.  Four batches
     (overlapping cameras, so late / staged / wasted rows all occur) must end BIT FOR BIT where the run without
     hints ends -- also with a wrong hint (dropped: its rows are un-stamped) and with a hint that is never used
@@ -696,7 +701,7 @@ def test_host_speculative_prefetch_is_exact(dev):
     from clm_gs_amd.synthetic import nadir_cameras
     res = {}
     for mode in ("plain", "hinted", "wrong"):
-        args, sc, _ = _setup("clm_offload", "host")
+        args, sc, _ = _setup("clm_offload", staging)
         cams = nadir_cameras(5 * BSZ, N, W, H, 0.35, seed=11, device="cuda")
         g = torch.Generator().manual_seed(5)
         for c in cams:
@@ -725,8 +730,13 @@ def test_host_speculative_prefetch_is_exact(dev):
                                                            st["exp_avg"], st["exp_avg_sq"])], img.clone(), late,
                      m._host_g_step.clone(), m._host_last_step.clone())
     touched = res["plain"][3]
-    # from the second batch on only the late rows go through the feeder
-    assert res["hinted"][3][0] == touched[0] and all(a < b for a, b in zip(res["hinted"][3][1:], touched[1:])), (res["hinted"][3], touched)
+    # from the second batch on only the late rows go through the feeder (per-camera windows: the rows of the hinted batch's
+    # FIRST camera are staged early -- none when the previous batch touched them all; batch-wide staging: the whole batch's)
+    late_h = res["hinted"][3]
+    assert late_h[0] == touched[0] and all(a <= b for a, b in zip(late_h[1:], touched[1:])), (late_h, touched)
+    assert sum(late_h[1:]) < sum(touched[1:]), (late_h, touched)
+    if staging == "host_batch":
+        assert all(a < b for a, b in zip(late_h[1:], touched[1:])), (late_h, touched)
     for mode in ("hinted", "wrong"):
         assert res[mode][0] == res["plain"][0], mode
         for a, b in zip(res[mode][1], res["plain"][1]):

@@ -72,7 +72,7 @@ def _oracle_parity(tag, m, cam, W, H, rows="visible"):
     return rep
 
 
-def _build(strategy, N, W, H, bsz, vis, n_cams=None, seed=0, kind="slab", **over):
+def _build(strategy, N, W, H, bsz, vis, n_cams=None, seed=0, kind="slab", morton=False, **over):
     from clm_gs_amd import utils
     from clm_gs_amd.synthetic import nadir_cameras, perturbed_copy, synth_gaussians
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
@@ -82,6 +82,11 @@ def _build(strategy, N, W, H, bsz, vis, n_cams=None, seed=0, kind="slab", **over
     utils.set_img_size(H, W)
     utils.set_cur_iter(1)
     sc = synth_gaussians(N, seed=seed, device="cuda", kind=kind)
+    if morton:  # rows in Z-order of (x, y), as the trainer and bench.py keep them
+        order = utils.morton_order(sc["xyz"])
+        for k_ in ("xyz", "scaling", "rotation", "opacity", "shs48"):
+            sc[k_] = utils.gather_rows(sc[k_], order)
+        del order
     cams = nadir_cameras(n_cams or bsz, N, W, H, vis, seed=seed, device="cuda")
     gt = GaussianModelCLMOffload(3, only_for_rendering=True)
     t = perturbed_copy(sc)
@@ -273,7 +278,7 @@ def test_block_skipping_visibility_equals_exact_pass_after_training_at_28m(dev):
     from clm_gs_amd import utils
     from clm_gs_amd.strategies.base_engine import select_filters
     N, W, H, bsz = 28_000_000, 4608, 3456, 4
-    args, m, cams = _build("clm_offload", N, W, H, bsz, 0.10, n_cams=44)
+    args, m, cams = _build("clm_offload", N, W, H, bsz, 0.10, n_cams=44, morton=True)
     assert m.small_deferred, "the default single-GPU HBM configuration defers the small-attribute Adam"
     it = 1
     for b in range(9):

@@ -50,6 +50,13 @@ def fx():
                                                                       "naive_offload")}
 
 
+def _res(residency):
+    """"host_batch": host-resident rows staged as the union of the batch (the round-2..5 form); "host": per-camera windows."""
+    if residency == "host_batch":
+        return {"sh_residency": "host", "host_staging": "batch"}
+    return {"sh_residency": residency}
+
+
 def _t(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -188,7 +195,7 @@ def test_no_offload_three_batches_match_reference_training(dev, fx, fused):
 
 
 # ------------------------------------------------------------------ a4 / a7 / a8 / a9 / a11 / a16: clm_offload
-CLM_MODES = [("hbm", True), ("hbm", False), ("host", True)]  # the host-resident mode runs the fused front end only
+CLM_MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True)]  # the host-resident mode runs the fused front end only
 
 
 def _clm_batch(m, Scene, batch, comm, gen):
@@ -204,7 +211,7 @@ def test_clm_offload_pre_optimizer_gradients_match_reference(dev, fx, residency,
     3-batch state is checked below).  Unscaled sums over the bsz cameras, as engine.py:725-742, 789-822
     leave them."""
     d = fx["no_offload"]
-    args, m, cams, Scene, bsz = _setup(fx, "clm_offload", sh_residency=residency, fused_front_end=fused,
+    args, m, cams, Scene, bsz = _setup(fx, "clm_offload", **_res(residency), fused_front_end=fused,
                                        debug_skip_optimizer=True)
     comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
     losses, order, sparsity = _clm_batch(m, Scene, cams[:bsz], comm, gen)
@@ -244,13 +251,13 @@ def test_clm_offload_three_batches_match_reference_engine(dev, fx, residency, fu
     from clm_gs_amd import utils
     from clm_gs_amd.strategies.clm_offload import clm_offload_eval_one_cam
     d, d0 = fx["clm_offload"], fx["no_offload"]
-    args, m, cams, Scene, bsz = _setup(fx, "clm_offload", sh_residency=residency, fused_front_end=fused)
+    args, m, cams, Scene, bsz = _setup(fx, "clm_offload", **_res(residency), fused_front_end=fused)
     comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
     it = 1
     for b in range(int(d0["n_batches"])):
         utils.set_cur_iter(it)
         m.update_learning_rate(it)
-        if residency == "host":  # what a loader knows: the speculative prefetch of the host-resident engine runs
+        if residency.startswith("host"):  # what a loader knows: the speculative prefetch of the host-resident engine runs
             from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
             hint_next_batch(m, cams[(b + 1) * bsz:(b + 2) * bsz])
         losses, order, _ = _clm_batch(m, Scene, cams[b * bsz:(b + 1) * bsz], comm, gen)

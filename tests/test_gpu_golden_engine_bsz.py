@@ -50,6 +50,13 @@ def _fx(bsz):
     return _FX[bsz]
 
 
+def _res(residency):
+    """"host_batch": host-resident rows staged as the union of the batch (the round-2..5 form); "host": per-camera windows."""
+    if residency == "host_batch":
+        return {"sh_residency": "host", "host_staging": "batch"}
+    return {"sh_residency": residency}
+
+
 def _t(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -163,14 +170,14 @@ def test_bitmap_ops_on_wide_words_match_oracle(dev, bsz, dtype):
 
 
 # ------------------------------------------------------------------ a8: the batch at bsz 16 / 64
-MODES = [("hbm", True), ("hbm", False), ("host", True)]
+MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True)]
 
 
 @pytest.mark.parametrize("residency,fused", MODES)
 @pytest.mark.parametrize("bsz", [16, 64])
 def test_clm_offload_large_batch_pre_optimizer_gradients_match_reference(dev, bsz, residency, fused):
     """Sum over bsz cameras of the gradients the optimizers are about to consume == the reference engine's batch gradient."""
-    args, m, cams, Scene, d = _setup(bsz, sh_residency=residency, fused_front_end=fused, debug_skip_optimizer=True)
+    args, m, cams, Scene, d = _setup(bsz, **_res(residency), fused_front_end=fused, debug_skip_optimizer=True)
     comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
     losses, order, sparsity = _batch(m, Scene, cams[:bsz], comm, gen)
     torch.cuda.synchronize()
@@ -217,13 +224,13 @@ def test_clm_offload_large_batch_two_batches_match_reference_engine(dev, bsz, re
     micro-batches, FusedCPUAdam thread consuming bsz + 1 finish groups, torch Adam / SelectiveAdam for the GPU groups)."""
     from clm_gs_amd import utils
     pre = "sparse" if sparse else "dense"
-    args, m, cams, Scene, d = _setup(bsz, sh_residency=residency, fused_front_end=fused, sparse_adam=sparse)
+    args, m, cams, Scene, d = _setup(bsz, **_res(residency), fused_front_end=fused, sparse_adam=sparse)
     comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
     it = 1
     for b in range(int(d["n_batches"])):
         utils.set_cur_iter(it)
         m.update_learning_rate(it)
-        if residency == "host" and b + 1 < int(d["n_batches"]):
+        if residency.startswith("host") and b + 1 < int(d["n_batches"]):
             from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
             hint_next_batch(m, cams[(b + 1) * bsz:(b + 2) * bsz])
         losses, order, _ = _batch(m, Scene, cams[b * bsz:(b + 1) * bsz], comm, gen)
