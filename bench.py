@@ -636,9 +636,12 @@ def trainer_leg(a, N, W, H, bsz, cams, lr_extent, extent):
            "eval_train_l1_psnr": [float(x) for x in psnr[-1]] if psnr else None,
            "loss_first_last_batch": [[float(x) for x in first.group(1).split()] if first else None,
                                      [float(x) for x in last[-1].split()] if last else None],
-           "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items() if k != "reserved_bytes"},
+           "host_seconds_by_phase": {k: round(v, 4) for k, v in phases.items()
+                                     if k not in ("reserved_bytes", "device_mallocs_before_clock")},
            "allocator_reserved_bytes": int(phases.get("reserved_bytes", 0)),
            "device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+           "device_mallocs_inside_the_clock": (int(ms1.get("num_device_alloc", 0) - phases["device_mallocs_before_clock"])
+                                               if "device_mallocs_before_clock" in phases else None),
            "clocks": tel.summary(),
            "schedule": {"densify_at_images": list(range(100, n_img - 49, 100)), "opacity_reset_at_image": 3 * (n_img // 4),
                         "densify_grad_threshold": float(a.trainer_grad_threshold)},
@@ -831,6 +834,37 @@ def main():
     torch.cuda.empty_cache()
     comm_stream = torch.cuda.Stream()
     perm_generator = torch.Generator(device="cuda").manual_seed(1)
+
+    from clm_gs_amd import telemetry as _tel
+    # (before the warm-up steps, so that a kernel trace of the run ends with the timed region)
+    # how the caching allocator placed the row tables the gather kernels walk (one hipMalloc each, or blocks inside
+    # larger segments): clm_gs_amd/telemetry.py tensor_alloc_info
+    alloc_info = None
+    try:
+        _tabs = {}
+        if a.strategy == "clm_offload" and getattr(gaussians, "_parameters", None) is not None and gaussians._parameters.is_cuda:
+            _st = gaussians.optimizer.cpu_adam.state[gaussians._parameters]
+            _tabs = {"sh_rows": gaussians._parameters.data, "sh_exp_avg": _st["exp_avg"], "sh_exp_avg_sq": _st["exp_avg_sq"],
+                     "sh_grad_rows": gaussians.parameters_grad_buffer, "xyz": gaussians._xyz.data}
+        alloc_info = _tel.tensor_alloc_info(_tabs) if _tabs else None
+        # ... and how fast THIS process streams each of them (a plain read of the whole table, best of 3, event-timed): the
+        # same table has read at different rates in different processes on one box (physical placement is the driver's), and
+        # the gather kernels' durations move with it
+        for _nm, _t in _tabs.items():
+            _flat, _best = _t.reshape(-1), None
+            for _ in range(3):
+                _e0, _e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                _e0.record()
+                _flat.sum()
+                _e1.record()
+                _e1.synchronize()
+                _ms = _e0.elapsed_time(_e1)
+                _best = _ms if _best is None else min(_best, _ms)
+            alloc_info[_nm]["read_GBps"] = round(_flat.numel() * 4 / (_best * 1e-3) / 1e9, 1)
+        _tabs = _flat = _t = _st = None  # (no reference to the tables may outlive this block: the later legs free the model)
+    except Exception as e:  # reporting only
+        alloc_info = {"error": f"{type(e).__name__}: {e}"}
+        _tabs = _flat = _t = _st = None
 
     class _Scene:
         cameras_extent = extent
@@ -1086,34 +1120,6 @@ def main():
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
 
     dist_backend = torch.distributed.get_backend() if grouped else None
-    # how the caching allocator placed the row tables the gather kernels walk (one hipMalloc each, or blocks inside
-    # larger segments): clm_gs_amd/telemetry.py tensor_alloc_info
-    alloc_info = None
-    try:
-        _tabs = {}
-        if a.strategy == "clm_offload" and getattr(gaussians, "_parameters", None) is not None and gaussians._parameters.is_cuda:
-            _st = gaussians.optimizer.cpu_adam.state[gaussians._parameters]
-            _tabs = {"sh_rows": gaussians._parameters.data, "sh_exp_avg": _st["exp_avg"], "sh_exp_avg_sq": _st["exp_avg_sq"],
-                     "sh_grad_rows": gaussians.parameters_grad_buffer, "xyz": gaussians._xyz.data}
-        alloc_info = _tel.tensor_alloc_info(_tabs) if _tabs else None
-        # ... and how fast THIS process streams each of them (a plain read of the whole table, best of 3, event-timed): the
-        # same table has read at different rates in different processes on one box (physical placement is the driver's), and
-        # the gather kernels' durations move with it
-        for _nm, _t in _tabs.items():
-            _flat, _best = _t.reshape(-1), None
-            for _ in range(3):
-                _e0, _e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                _e0.record()
-                _flat.sum()
-                _e1.record()
-                _e1.synchronize()
-                _ms = _e0.elapsed_time(_e1)
-                _best = _ms if _best is None else min(_best, _ms)
-            alloc_info[_nm]["read_GBps"] = round(_flat.numel() * 4 / (_best * 1e-3) / 1e9, 1)
-        _tabs = _flat = _t = _st = None  # (no reference to the tables may outlive this block: the later legs free the model)
-    except Exception as e:  # reporting only
-        alloc_info = {"error": f"{type(e).__name__}: {e}"}
-        _tabs = _flat = _t = _st = None
     def _finish(allreduce_leg, clean=True):
         """Everything after the timed work: the process group is left (clean=False: the watchdog of the all-reduce leg
         calls this from its own thread while the main thread may be stuck in a collective), rank 0 assembles and prints
@@ -1178,9 +1184,10 @@ def main():
                                      "note": "instruction count from the SQ_INSTS_VALU pass in profiles/ (NOT this run), "
                                              "durations from this run; peak = plain-FMA issue rate at 8 waves/SIMD, ceiling = "
                                              "the same at the kernel's 5 waves/SIMD (profiles/r02_ilp_probe.jsonl) -- the "
-                                             "kernel's exp / rcp / DPP / permlane instructions cost 1.5-3 issue slots each: "
-                                             "weighted by those costs it needs 1.22x its instruction count in slots "
-                                             "(DESIGN.md section 3)"}
+                                             "kernel's compares / selects / v_min, DPP adds and exp / rcp cost 1.6-3 issue slots "
+                                             "each (profiles/r06_valu_calib.jsonl); it is bound by the dependent-issue chain of "
+                                             "its 5 one-wave workgroups per SIMD, not by the slot count (DESIGN.md section 3, "
+                                             "round 6)"}
                                     if valu else None),
                         "pairs_per_s": round(256.0 * I_avg / (kernels[dom]["avg_ms"] * 1e-3), 1),
                         "note": "alpha-blend kernels are ALU/LDS-bound on 256*I pixel-Gaussian pairs; "

@@ -393,6 +393,7 @@ def _stage_plan(b):
         # camera-DP: rows touched by ANY rank get their (reduced) gradient at the end of the batch;
         # only globally untouched rows may take the early zero-gradient update
         if dp.active() and not b.locality_sparse:  # (locality: the global mask is assembled from what the owners publish)
+            b.local_touched = b.touched          # this rank's cameras' rows (mask), before the OR over the ranks
             b.touched = dp.allreduce_touched(b.touched)
             b.touched_rows = None
     b.row_adam = gaussians.optimizer.cpu_adam
@@ -496,9 +497,15 @@ def _stage_exchange_head(b):
         # deferred dense Adam: rows this batch renders replay the zero-gradient steps they skipped
         # (exactly the updates the eager pass would have streamed through HBM every batch);
         # untouched rows are not visited at all.
-        if (b.pipelined and bsz >= 2 and getattr(args, "split_catch_up", True) and b.filters is not None
-                and not dp.active()):  # (all-reduce camera-DP: rows only OTHER ranks touch must consume their waiting
-            #                            gradient before this batch's sum lands on them -- the pass needs the global set)
+        if (b.pipelined and bsz >= 2 and getattr(args, "split_catch_up", True) and b.filters is not None):
+            # (all-reduce camera-DP, round 6: the rows only OTHER ranks touch must consume their waiting gradient before
+            #  this batch's sum lands on them -- they get one extra pass of their own, enqueued by _cameras_pipelined
+            #  behind the last camera's rows, i.e. underneath the tile kernels and ahead of the tail exchange)
+            b.foreign_rows = None
+            if dp.active():
+                lt = getattr(b, "local_touched", None)
+                assert lt is not None
+                b.foreign_rows = touched_rows[~lt[touched_rows.long()]]
             # CAMERA BY CAMERA (round 5; enqueued by _cameras_pipelined on the front stream, each call right before its
             # camera's projection): the first camera's chain waits for ITS rows only (0.8 ms of the 2.7 ms pass at 28 M
             # rows), the other cameras' rows are brought up to date underneath the tile kernels of the cameras before them
@@ -575,6 +582,9 @@ def _cameras_pipelined(b):
             s_front.wait_event(b.dp_ev_b0 if k == 0 else b.dp_ev_b1)
         if b.split_catch and (k or not b.first_catch_done):  # (camera 0: usually done by _stage_exchange_head)
             catch(k)
+        if b.split_catch and k == bsz - 1 and getattr(b, "foreign_rows", None) is not None and b.foreign_rows.numel():
+            with torch.cuda.stream(s_front):  # all-reduce camera-DP: the rows only other ranks touch (see _stage_exchange_head)
+                gaussians.catch_up_rows(b.foreign_rows, to_step=step - 1)
         with _lib.host_region("camera_front"):
             cur_pass = camera_front(gaussians, b.cameras[k], b.filters[k], b.params.data, 1, b.background,
                                     b.cameras[k].original_image, small_packed=b.small_pk,

@@ -294,6 +294,8 @@ def training(gaussians, scene, train_cameras, test_cameras, log_file, iterations
             _t = time.perf_counter()
             _warm_structural_ops(gaussians._xyz.device)
             _acc("warm_ops", _t)
+    if torch.cuda.is_available():  # (diagnosis: how many hipMallocs happen INSIDE the end-to-end clock -- bench.py reports it)
+        pt["device_mallocs_before_clock"] = float(torch.cuda.memory_stats().get("num_device_alloc", 0))
     timer = End2endTimer()
     timer.start()
     next_batch = None

@@ -5,6 +5,11 @@ set -x
 R=$(pwd)
 O=$R/gpurun_out/r06c; mkdir -p $O
 N="--no-cpu-baseline --no-host-leg --no-trainer-leg --no-heavy-leg"
+# 0. the FIRST process on the box: the gather ceiling + the deferred row pass alone (repeated at the very end: the first
+#    process of a box has measured slower than later ones)
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 profiles/gather_probe.hip -o /tmp/gather_probe 2>/dev/null
+timeout 300 /tmp/gather_probe > $O/gather_probe_first_process.jsonl 2>&1
+timeout 200 python profiles/catch_up_microbench.py > $O/catch_up_microbench_first_process.txt 2>&1
 # 1. the driver's command (all legs: value, value_gt_streamed, value_heavy, host_resident, trainer, cpu_baseline)
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_28m_final.log 2> $O/bench_28m_final.err
 # 2. kernel trace of the timed steps only (in situ), one pipelined batch as a timeline
@@ -45,4 +50,14 @@ timeout 400 python bench.py --config bigcity102m --steps 6 --warmup 2 $N > $O/be
 timeout 200 python profiles/raster_microbench.py > $O/raster_microbench.txt 2>&1
 timeout 200 python profiles/raster_microbench.py heavy 10 >> $O/raster_microbench.txt 2>&1
 timeout 200 python profiles/catch_up_microbench.py > $O/catch_up_microbench.txt 2>&1
+timeout 300 /tmp/gather_probe > $O/gather_probe_last_process.jsonl 2>&1
+# 8. rocprof's duration and the event-timed duration of the SAME launches (20 back-to-back launches of each tile kernel)
+cd /tmp
+rm -rf /tmp/prof_mb
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_mb -o mb -- python $R/profiles/raster_microbench.py slab 20 > $O/raster_microbench_under_rocprof.txt 2>&1
+DB=$(find /tmp/prof_mb -name "*.db" | head -1)
+python $R/profiles/kernel_stats.py "$DB" 100000 | grep -i "rasterize\|Name" >> $O/raster_microbench_under_rocprof.txt
+cd $R
+# 9. the GPU test suite
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu_final.log
 ls -la $O

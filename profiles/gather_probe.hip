@@ -97,6 +97,18 @@ int main() {
   CHECK(hipMemcpy(d_shuf, shuf_list.data(), n * 4, hipMemcpyHostToDevice));
   const double useful = (double)n * 7 * 192;
 
+  // First-process effect (round 6): the FIRST process on a freshly acquired box measured the 2 MB-aligned tables at the rate
+  // of the mis-aligned ones; does freeing and re-allocating inside that process change it?  (192 B rows, runs list)
+  for (int rep = 0; rep < 3; ++rep) {
+    const size_t tb = (size_t)N * 12 * 16;
+    float4* t[4];
+    for (int k = 0; k < 4; ++k) { CHECK(hipMalloc(&t[k], tb)); CHECK(hipMemset(t[k], 0, tb)); }
+    double med;
+    const double best = timed([&] { hipLaunchKernelGGL(gather_rows<12>, dim3(256 * 16), dim3(256), 0, 0, d_runs, n, t[0], t[1], t[2], t[3]); }, &med);
+    printf("{\"experiment\": \"alloc_free_realloc\", \"allocation_round\": %d, \"ms_min\": %.4f, \"useful_GBps_min\": %.1f, \"ptr\": \"%p\"}\n",
+           rep, best, useful / (best * 1e-3) / 1e9, (void*)t[0]);
+    for (int k = 0; k < 4; ++k) CHECK(hipFree(t[k]));
+  }
   for (int stride4 : {12, 16}) {
     const size_t tb = (size_t)N * stride4 * 16;
     for (int carved = 0; carved < 2; ++carved) {
