@@ -15,9 +15,11 @@
 //     misses the tile are compacted away with a ballot/popcount prefix (depth order kept),
 //     quadrants it misses are skipped with wave-uniform branches.  Only pairs the reference
 //     itself skips (alpha < 1/255) are dropped, so results are unchanged;
-//   * backward: each lane first sums its pixels' contributions, then one DPP wave reduction per
-//     Gaussian (row_shr + row_bcast) and ONE set of float atomics per (Gaussian, tile), issued
-//     64 Gaussians at a time by 64 lanes;
+//   * backward: each lane first sums its pixels' contributions; the nine wave-wide sums of an entry then go
+//     through LDS (eight of them, transposed: four ds_write2st64 + two ds_read_b128 + 7 adds + 3 DPP adds per
+//     lane) and one DPP chain (the ninth), and ONE 64 B partial line per (Gaussian, tile) leaves the wave
+//     (engine path: plain stores at the intersection's slot; gsplat-compatible op: float atomics), 64
+//     Gaussians at a time by 64 lanes;
 //   * blockIdx -> tile mapping is XCD-aware: each XCD's L2 sees a contiguous stripe of tiles,
 //     so neighbouring tiles' shared Gaussians hit in L2.
 #include <stdlib.h>

@@ -204,9 +204,12 @@ def _plan(w):
         need_a = max([n_p + n_first[0]] + n_first[1:])
         hb = _buffers(g, need_a, n_surv, n_late, dev)
         if spec is not None and spec["gen"] != hb["gen"]:
-            # the tables had to grow: what was staged went with the old ones -- everything is late
+            # the tables had to grow: what was staged went with the old ones -- everything is late (re-preparing a current
+            # row is the identity; the stamps of the touched rows stay right, the untouched ones are un-stamped below)
+            gone = spec["rows"]
             spec = None
-            n_p, staged, wasted, late_all, rows_by_last32, cl = group(None)
+            n_p, staged, _w, late_all, rows_by_last32, cl = group(None)
+            wasted = gone[~mark[gone]]
             n_first, n_last, n_late = [int(x) for x in cl[:bsz]], [int(x) for x in cl[bsz:2 * bsz]], int(cl[2 * bsz])
             arr, flag, cum = survivors(0, None, late_all, n_first)
             cum_h = [int(x) for x in cum.tolist()]
