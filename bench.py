@@ -416,6 +416,11 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     torch.cuda.empty_cache()
     args = utils.default_args(bsz=bsz, sh_residency="host", host_staging=a.host_staging)
     args.clm_offload = True
+    for kv in a.opt:  # (engine options of the host-resident mode given with --opt apply to this leg too)
+        k, v = kv.split("=", 1)
+        if k.startswith("host_") and hasattr(args, k):
+            cur = getattr(args, k)
+            setattr(args, k, v.lower() in ("1", "true", "yes") if isinstance(cur, bool) else type(cur)(v))
     utils.set_args(args)
     utils.set_img_size(H, W)
     scene = synth_gaussians(N, seed=0, device="cuda", kind=a.scene)
