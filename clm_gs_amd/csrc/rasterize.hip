@@ -492,8 +492,8 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       if (DBG != 2) {
 #if CLMGS_BWD_LDS_REDUCE
         // Eight of the nine wave-wide sums through LDS, transposed: lane L stores value q at red[q][L] (four
-        // ds_write2st64_b32: the two values of a pair lie 64 dwords apart); lane j = 8 q + c then loads the 8
-        // consecutive floats red[q][8c .. 8c+7] (two ds_read_b128, conflict-free), adds them (7 VALU) and three
+        // ds_write2st64_b32: the two values of a pair lie 64 dwords apart); lane j = 8 q + c then loads eight
+        // floats of red[q][.] (two ds_read_b128, conflict-free: see below), adds them (7 VALU) and three
         // row_shr DPP adds finish value q in lane 8 q + 7.  ~12 issue slots for eight sums against ~37 for the two
         // permlane-swap butterflies; the LDS instructions issue beside other waves' VALU.  The ninth sum (opacity)
         // keeps its DPP chain.  One wave per workgroup: LDS operations of a wave execute in order, the fences only
@@ -503,8 +503,10 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        const float4* rp = reinterpret_cast<const float4*>(&sm.red[lane >> 3][8 * (lane & 7)]);
-        const float4 r0 = rp[0], r1 = rp[1];
+        // (lane 8q + c takes floats [4c, 4c+4) and [32 + 4c, 32 + 4c + 4) of value q: consecutive lanes read consecutive
+        //  16 B pieces -- the [8c, 8c+8) assignment had a stride of 32 B between lanes and a 2-way bank conflict on both loads)
+        const float4* rp = reinterpret_cast<const float4*>(&sm.red[lane >> 3][4 * (lane & 7)]);
+        const float4 r0 = rp[0], r1 = rp[8];
         g_o = wave_sum_to_lane63(g_o);
         float u = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
         u = dpp_add<0x111>(u);

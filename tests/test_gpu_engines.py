@@ -746,6 +746,58 @@ def test_host_speculative_prefetch_is_exact(dev, staging):
         assert torch.equal(res[mode][4], res["plain"][4])                      # and no stamp left behind by a dropped hint
 
 
+@pytest.mark.parametrize("staging", ["host", "host_batch"])
+def test_host_staging_tables_grow_under_an_outstanding_speculation(dev, staging):
+    """The staging tables are sized from the batches seen so far; a batch whose cameras see far more rows makes them grow
+    while rows staged speculatively for it sit in the OLD tables: everything must then be treated as late, the untouched
+    speculative rows un-stamped -- and the run must end bit for bit where the run without hints ends."""
+    from clm_gs_amd import utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_train_one_batch
+    from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
+    from clm_gs_amd.synthetic import nadir_cameras
+    res = {}
+    from clm_gs_amd.synthetic import synth_gaussians
+    n, w_, h_ = 60_000, 160, 120  # (capacities are bucketed with a floor of 4 096 rows: the module's 3 000-row scene never grows)
+    for mode in ("plain", "hinted"):
+        over = {"host_staging": "batch"} if staging == "host_batch" else {}
+        args = utils.default_args(bsz=BSZ, sh_residency="host", **over)
+        args.clm_offload = True
+        utils.set_args(args)
+        utils.set_img_size(h_, w_)
+        utils.set_cur_iter(1)
+        sc = synth_gaussians(n, seed=3, device="cuda")
+        small = nadir_cameras(2 * BSZ, n, w_, h_, 0.05, seed=21, device="cuda")
+        big = nadir_cameras(BSZ, n, w_, h_, 0.6, seed=22, device="cuda")
+        g = torch.Generator().manual_seed(6)
+        for c in small + big:
+            c.original_image = (torch.rand(3, h_, w_, generator=g) * 255).to(torch.uint8).cuda()
+        batches = [small[:BSZ], big, small[BSZ:], big]
+        m = _make("clm_offload", sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        it, losses, gens = 1, [], []
+        for b, batch in enumerate(batches):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            if mode == "hinted" and b + 1 < len(batches):
+                hint_next_batch(m, batches[b + 1])
+            l, _, _ = clm_offload_train_one_batch(m, _Scene, batch, m.parameters_grad_buffer, None, None, comm, gen)
+            losses += [x.item() for x in l]
+            hb = getattr(m, "_hwin_bufs", None) or getattr(m, "_host_bufs", None)
+            gens.append(hb["gen"])
+            it += BSZ
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        res[mode] = (losses, [t.detach().clone() for t in (m._xyz, m._opacity, m._scaling, m._rotation, m._parameters,
+                                                           st["exp_avg"], st["exp_avg_sq"])],
+                     m._host_g_step.clone(), m._host_last_step.clone(), gens)
+    assert res["hinted"][4][1] > res["hinted"][4][0], res["hinted"][4]  # the tables DID grow at the big batch
+    assert res["hinted"][0] == res["plain"][0]
+    for a, b in zip(res["hinted"][1], res["plain"][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res["hinted"][2], res["plain"][2]) and torch.equal(res["hinted"][3], res["plain"][3])
+
+
 def test_deferred_small_adam_equals_eager(dev):
     """Round 5: xyz / opacity / scaling / rotation stepped per block of 256 rows, only when one of the batch's cameras
     may see the block (GaussianModelCLMOffload.small_deferred, clmgs_adam_small_deferred) == the eager dense Adam of
