@@ -154,6 +154,9 @@ __device__ __forceinline__ int special_entry(float opac, float ca, float cb, flo
 #ifndef CLMGS_FWD_WAVES
 #define CLMGS_FWD_WAVES 6
 #endif
+#ifndef CLMGS_FWD_ASM
+#define CLMGS_FWD_ASM 1
+#endif
 __global__ void __launch_bounds__(64, CLMGS_FWD_WAVES)
 rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ packed,
                      const float* __restrict__ backgrounds,
@@ -248,6 +251,32 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           const float dy = RA.y - (py0 + (float)(8 * (k >> 1)));
           const float sigma = scaled_sigma(RA.w, RB.x, RB.y, dx, dy);  // log2(e) * sigma
           const float alpha = fminf(0.999f, RA.z * __builtin_amdgcn_exp2f(-sigma));
+#if CLMGS_FWD_ASM
+          // Round 6: three compares and three selects per pass instead of five and four, and no new scalar work (compares,
+          // selects and v_min issue at half the FMA rate: profiles/r06_valu_calib.jsonl).  A finished / out-of-image pixel
+          // holds a NEGATIVE T, so its next_T < 0 fails `next_T > eps` by itself (no `T > 0` compare); the two outcomes of a
+          // hit are mask arithmetic on the compares' scalar results (s_and / s_andn2; the compiler issued v_cmp_nlt AND
+          // v_cmp_lt for `goes_on` / `!goes_on`); the selects are written as v_cndmask on those scalar masks.  Results are
+          // bit-identical to the select form below (CLMGS_FWD_ASM=0, the round-5 code).
+          const float next_T = T[k] * (1.f - alpha);
+          const unsigned long long hit_m = __builtin_amdgcn_ballot_w64(sigma >= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+          const unsigned long long go_m = __builtin_amdgcn_ballot_w64(next_T > T_EPS);
+          const unsigned long long acc_m = hit_m & go_m, stop_m = hit_m & ~go_m;
+          float vis = alpha * T[k];
+          asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(vis) : "s"(acc_m));
+          cr[k] += RB.z * vis; cg[k] += RB.w * vis; cb[k] += rblue * vis;
+          asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(last[k]) : "v"(gi_v), "s"(acc_m));
+          asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(T[k]) : "v"(next_T), "s"(acc_m));
+          if (stop_m != 0ull) {
+            // rare (a pixel stops once; finished pixels of a part-finished quadrant come by again): the sign of T is set
+            // under a narrowed exec mask -- one full-rate v_or here instead of a fourth select in every pass.  (exec is all
+            // ones around this point: 64 threads per workgroup, no divergent region open.)
+            asm volatile("s_mov_b64 exec, %1\n\tv_or_b32_e32 %0, 0x80000000, %0\n\ts_mov_b64 exec, -1" : "+v"(T[k]) : "s"(stop_m));
+            if (__builtin_amdgcn_ballot_w64(T[k] > 0.f) == 0ull) alive &= ~(1 << k);
+          }
+        }
+      }
+#else
           const bool valid = (T[k] > 0.f) && (sigma >= 0.f) && (alpha >= ALPHA_MIN);
           const float next_T = T[k] * (1.f - alpha);
           const bool goes_on = next_T > T_EPS;  // valid => alpha, T finite: one compare serves both cases
@@ -262,6 +291,7 @@ rasterize_fwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
           if (__any(term) && !__any(T[k] > 0.f)) alive &= ~(1 << k);
         }
       }
+#endif
       if (!alive) break;
     }
   }
@@ -454,7 +484,9 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
       // (g_x = a Sx + b Sy, g_y = b Sx + c Sy, g_conic = Sxx/2, Sxy, Syy/2), applied at the flush
       float g_r = 0.f, g_g = 0.f, g_b = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f,
             g_o = 0.f;
-      bool any_valid = false;
+      // OR of the passes' valid masks, kept as scalar mask arithmetic on the compares' results (a per-lane flag costs a
+      // v_mov per pass and a v_cmp at the end; measured -0.8 % slab / -1.2 % heavy, profiles/r06_raster_ab8.txt)
+      unsigned long long any_valid = 0ull;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
           if (meta & (1 << k)) {  // wave-uniform
@@ -466,10 +498,14 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
             // (scalar branches on `special`; the empty asm keeps them branches -- if-converted they are selects again)
             float alpha = oa;
             bool ok = true;
-            if (__builtin_expect(special, 0)) { asm volatile(""); alpha = fminf(0.999f, oa); ok = sigma >= 0.f; }
+            unsigned long long ok_m = ~0ull;
+            if (__builtin_expect(special, 0)) {
+              asm volatile("");
+              alpha = fminf(0.999f, oa); ok = sigma >= 0.f; ok_m = __builtin_amdgcn_ballot_w64(sigma >= 0.f);
+            }
             const bool valid = ok & (gi <= bin[k]) & (alpha >= ALPHA_MIN);
+            any_valid |= ok_m & __builtin_amdgcn_ballot_w64(gi <= bin[k]) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
             if (valid) {
-              any_valid = true;
               const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // v_rcp_f32 (1 ulp), not the 10-op IEEE divide
               T[k] *= ra;
               const float fac = alpha * T[k];
@@ -487,7 +523,7 @@ rasterize_bwd_kernel(int C, int N, int64_t n_isects, const float4* __restrict__ 
             }
           }
         }
-      if (wave_none(any_valid)) continue;
+      if (any_valid == 0ull) continue;
       if (DBG == 3) n_valid++;
       if (DBG != 2) {
 #if CLMGS_BWD_LDS_REDUCE
