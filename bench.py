@@ -149,6 +149,11 @@ def parse():
                          "or the union of the batch's rows (the round-2..5 form)")
     ap.add_argument("--no-host-staging-pair", action="store_true",
                     help="skip the second, shorter host-resident leg with the other staging form")
+    ap.add_argument("--host-budget-gb", type=float, default=0.0,
+                    help="host-resident leg: sh_hbm_budget_gb of that leg (768 B per resident row); the default run adds a "
+                         "third, shorter leg at --host-budget-leg-gb beside the budget-0 leg")
+    ap.add_argument("--host-budget-leg-gb", type=float, default=-1.0,
+                    help="budget of the extra host-resident leg (-1: half of the rows; 0: no such leg)")
     ap.add_argument("--host-steps", type=int, default=20)
     ap.add_argument("--host-warmup", type=int, default=2)
     ap.add_argument("--no-host-hint", action="store_true",
@@ -414,11 +419,12 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
         c.original_image = None
     gc.collect()
     torch.cuda.empty_cache()
-    args = utils.default_args(bsz=bsz, sh_residency="host", host_staging=a.host_staging)
+    args = utils.default_args(bsz=bsz, sh_residency="host", host_staging=a.host_staging,
+                              sh_hbm_budget_gb=float(a.host_budget_gb))
     args.clm_offload = True
     for kv in a.opt:  # (engine options of the host-resident mode given with --opt apply to this leg too)
         k, v = kv.split("=", 1)
-        if k.startswith("host_") and hasattr(args, k):
+        if (k.startswith("host_") or k == "sh_hbm_budget_gb") and hasattr(args, k):
             cur = getattr(args, k)
             setattr(args, k, v.lower() in ("1", "true", "yes") if isinstance(cur, bool) else type(cur)(v))
     utils.set_args(args)
@@ -479,14 +485,20 @@ def host_resident_leg(a, N, W, H, bsz, vis_frac, cams, lr_extent, extent):
     regions, _lib.HOST_REGIONS = _lib.HOST_REGIONS, None
     peak = torch.cuda.max_memory_allocated()
     tr = _lib.STATS.get("touched_rows", [])
-    T = sum(tr) / max(1, len(tr))
+    T_all = T = sum(tr) / max(1, len(tr))
+    K_res = g.hbm_prefix_rows()
+    if K_res:  # sh_hbm_budget_gb: rows [0, K) never cross the link and are stepped on the GPU
+        th = _lib.STATS.get("host_touched_rows", [])[-host_steps:]
+        T = sum(th) / max(1, len(th))
     link_bytes = 2 * 192.0 * T + 4.0 * T + bsz * 3.0 * H * W  # rows down + gradient rows up + row list + GT images
     vals = [float(x) for x in losses_all]
     k2 = min(2 * bsz, max(bsz, len(vals) // 2))
     out = {"value": round(host_steps * bsz / dt, 3), "unit": "img/s", "ms_per_step": round(dt / host_steps * 1e3, 2),
            "steps": host_steps, "warmup": a.host_warmup, "peak_gpu_bytes": int(peak),
            "pinned_host_bytes": int(4 * g.parameters_buffer.shape[0] * 192),
-           "touched_rows_per_batch": round(T, 1), "host_threads": n_threads,
+           "touched_rows_per_batch": round(T_all, 1), "host_touched_rows_per_batch": round(T, 1),
+           "sh_hbm_budget_gb": float(args.sh_hbm_budget_gb), "hbm_resident_rows": int(K_res),
+           "hbm_resident_bytes": int(K_res) * 768, "host_threads": n_threads,
            "late_rows_per_batch": (round(sum(_lib.STATS.get("host_late_rows", [])[-host_steps:]) / host_steps, 1)
                                    if _lib.STATS.get("host_late_rows") else None),
            "speculative_prefetch": not a.no_host_hint, "staging": a.host_staging,
@@ -1317,6 +1329,22 @@ def main():
                         "host_pool_busy_fraction", "link")}
                 except Exception as e:
                     out["host_resident_other_staging"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            # ... and the window form with an HBM budget: half of the rows (by default) resident -- rendered from and stepped
+            # in HBM -- so the link and the host pool carry the other half only
+            if a.host_budget_leg_gb != 0.0 and a.host_staging == "window" and not a.host_budget_gb:
+                try:
+                    import copy
+                    a3 = copy.copy(a)
+                    a3.host_budget_gb = a.host_budget_leg_gb if a.host_budget_leg_gb > 0 else (N // 2) * 768 / 1e9
+                    a3.host_steps = min(a.host_steps, 10)
+                    h3 = host_resident_leg(a3, N, W, H, bsz, vis_frac, cams, lr_extent, extent)
+                    out["host_resident_hbm_budget"] = {k: h3.get(k) for k in (
+                        "staging", "sh_hbm_budget_gb", "hbm_resident_rows", "hbm_resident_bytes", "value", "value_steady",
+                        "ms_per_step", "steps", "peak_gpu_bytes", "touched_rows_per_batch", "host_touched_rows_per_batch",
+                        "late_rows_per_batch", "host_pool_busy_fraction", "final_flush_ms", "host_ms_per_step", "link",
+                        "loss_first", "loss_last")}
+                except Exception as e:
+                    out["host_resident_hbm_budget"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if (not a.no_trainer_leg and world == 1 and not grouped and a.strategy == "clm_offload" and a.residency == "hbm"
                 and a.config in ("rubble28m", "rubble10m", "small")):
             try:

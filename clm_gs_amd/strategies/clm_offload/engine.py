@@ -886,6 +886,7 @@ def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buf
         from .host_window import train_one_batch_host_windowed
         return train_one_batch_host_windowed(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
                                              pipe_args, comm_stream, perm_generator, args)
+    assert not float(getattr(args, "sh_hbm_budget_gb", 0.0) or 0.0), "sh_hbm_budget_gb is built on host_staging='window'"
     from ...fused import train_one_camera
     bsz = len(batched_cameras)
     N = gaussians._xyz.shape[0]

@@ -77,6 +77,10 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def create_from_tensors(self, xyz, shs48, scaling, rotation, opacity, spatial_lr_scale=1.0):
         # new tensors replace the model (first creation, load, restore): whatever the previous optimizer still had waiting
         # belonged to the tensors that are going away -- dropped with them, never replayed onto the new ones
+        self._hbm_prefix = None  # (sh_hbm_budget_gb: the device copy of the old rows goes with them)
+        if getattr(self, "_hwin_bufs", None) is not None and self._hwin_bufs.get("K", 0):
+            torch.cuda.synchronize()
+            self._hwin_bufs = None
         self.optimizer = None
         self._small_def, self._small_def_dirty = None, False
         self._lazy_dirty, self._sorted_tag = True, None
@@ -110,6 +114,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
                 self.flush_small()
             if self.lazy_rows and getattr(self, "_lazy_dirty", False):
                 self.flush_lazy_rows()
+            if getattr(self, "_hbm_prefix", None) is not None:  # its moments belong to the optimizer that is going away
+                self.hbm_prefix_drop(writeback=True)
         self._small_def_dirty = False
         self._lazy_dirty = True
         self._mutations = getattr(self, "_mutations", 0) + 1
@@ -597,6 +603,97 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             if sp["n"]:
                 self._host_g_step[sp["rows_h"][:sp["n"]].long()] = 0
 
+    # ---------------------------------------------------- HBM-resident prefix of the host rows (sh_hbm_budget_gb)
+    # sh_residency="host" with a budget: rows [0, K) of the (Z-ordered) SH table, their two moments and their gradient rows
+    # LIVE in HBM while batches run -- 4 x 192 B per row, K = budget / 768 B -- and are stepped there by the deferred row
+    # optimizer of the HBM engine (clmgs_adam_catch_up, its own stamps); only rows >= K cross the host link and are stepped
+    # by the host pool.  The host tables stay the model's storage: every reader outside a batch goes through
+    # flush_lazy_rows() / host_rows_prepare(), which write the prefix back first (hbm_prefix_writeback), and every
+    # structural change (append / prune / permute / a new optimizer) forgets the device copy (hbm_prefix_drop) after that
+    # flush; the next batch loads it again (768 B x K over the link: ~0.2 s at 14 M rows).
+    def hbm_prefix_rows(self):
+        gb = float(getattr(self.args, "sh_hbm_budget_gb", 0.0) or 0.0)
+        if gb <= 0.0 or not self.sh_on_host:
+            return 0
+        return int(min(self._xyz.shape[0], gb * 1e9 // (4 * 48 * 4)))
+
+    def hbm_prefix_ensure(self):
+        """-> the live prefix state (dict: K, m, v, last_step, g_step, dirty, fill) or None without a budget.  A prefix
+        that is not loaded yet is created here from the host tables, which are brought up to date first; its parameter
+        and gradient rows are the first K rows of the staging tables of host_window.py, which fills them (`fill`)."""
+        K = self.hbm_prefix_rows()
+        px = getattr(self, "_hbm_prefix", None)
+        if px is not None and (px["K"] != K or px["N"] != self._xyz.shape[0]):
+            self.hbm_prefix_drop(writeback=True)
+            px = None
+        if K == 0:
+            return None
+        if px is None:
+            assert self.deferred_host_rows
+            self.flush_lazy_rows()  # every host row current, nothing waiting, no speculation outstanding
+            opt = self.optimizer.cpu_adam
+            st = opt.state[self._parameters]
+            dev = self._xyz.device
+            px = self._hbm_prefix = dict(
+                K=K, N=int(self._xyz.shape[0]), m=st["exp_avg"][:K].to(dev), v=st["exp_avg_sq"][:K].to(dev),
+                last_step=torch.full((K,), int(opt.global_step), dtype=torch.int32, device=dev),
+                g_step=torch.zeros((K,), dtype=torch.int32, device=dev), dirty=False, fill=True)
+        return px
+
+    def _hbm_prefix_tables(self):
+        hb = getattr(self, "_hwin_bufs", None)
+        px = self._hbm_prefix
+        assert hb is not None and hb.get("K", 0) == px["K"] and not px["fill"], "the prefix rows are not in the staging tables"
+        return hb["pt"][:px["K"]], hb["gt"][:px["K"]]
+
+    def hbm_prefix_catch_up(self, rows, to_step):
+        """Deferred row optimizer on prefix rows (int32 device list, None = all K): the waiting gradient of a row at its
+        own step, then the zero-gradient steps it skipped, up to `to_step`; consumed gradient rows are cleared."""
+        from ...clm_kernels import adam_catch_up
+        px = self._hbm_prefix
+        if to_step <= 0 or (rows is not None and rows.numel() == 0):
+            return
+        p, gr = self._hbm_prefix_tables()
+        opt = self.optimizer.cpu_adam
+        g = opt.param_groups[0]
+        adam_catch_up(p, px["m"], px["v"], px["last_step"], rows, opt._col_lr(p.device), g["betas"][0], g["betas"][1],
+                      g["eps"], int(to_step), g["bias_correction"], g=gr, g_step=px["g_step"],
+                      grad_scale=1.0 / float(self.args.bsz), keep_grad=False)
+
+    def hbm_prefix_writeback(self):
+        """Host tables [0, K) <- the prefix, brought up to the optimizer's current step (no-op unless a batch ran since)."""
+        px = getattr(self, "_hbm_prefix", None)
+        if px is None or not px["dirty"]:
+            return
+        K = px["K"]
+        opt = self.optimizer.cpu_adam
+        step = int(opt.global_step)
+        if not self.args.sparse_adam:
+            self.hbm_prefix_catch_up(None, step)
+        p, _ = self._hbm_prefix_tables()
+        st = opt.state[self._parameters]
+        self._parameters.data[:K].copy_(p)          # (pinned destination, blocking copies: the host pass that follows
+        st["exp_avg"][:K].copy_(px["m"])            #  reads these rows)
+        st["exp_avg_sq"][:K].copy_(px["v"])
+        self._host_last_step[:K] = step
+        self._host_g_step[:K] = 0
+        px["dirty"] = False
+
+    def hbm_prefix_drop(self, writeback=False):
+        """Forget the device copy of the prefix (structural change, new optimizer).  The callers have flushed -- which
+        wrote it back -- before they changed anything; writeback=True: do that here (the budget itself changed)."""
+        px = getattr(self, "_hbm_prefix", None)
+        if px is None:
+            return
+        if writeback:
+            self.hbm_prefix_writeback()
+        assert not px["dirty"], "the HBM-resident prefix was dropped with row steps that never reached the host tables"
+        self._hbm_prefix = None
+        hb = getattr(self, "_hwin_bufs", None)
+        if hb is not None and hb.get("K", 0):
+            torch.cuda.synchronize()  # (side-stream copies into the tables: see host_window._buffers)
+            self._hwin_bufs = None
+
     def host_rows_prepare(self, rows_host, stage_host, to_step=None, next_g_step=0, n_rows=None, sync_grads=True):
         """Bring host rows (int32 pinned/CPU row list, None = all) up to `to_step` (default: the optimizer's
         current step): waiting gradients are applied at their own step, skipped zero-gradient steps are
@@ -611,6 +708,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
             if self._host_grads_event is not None:  # the waiting gradients must have landed
                 self._host_grads_event.synchronize()
                 self._host_grads_event = None
+            self.hbm_prefix_writeback()  # (sh_hbm_budget_gb: rows [0, K) are stepped in HBM; the host copy is read next)
         opt = self.optimizer.cpu_adam
         g = opt.param_groups[0]
         p = self._parameters
@@ -633,6 +731,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
 
     def _rebind_row_state(self, n):
         """Point the row optimizer at the [:n] views after append / prune."""
+        self.hbm_prefix_drop()  # (rows moved / were added / removed: the callers flushed before they did it)
         old = self._parameters
         opt = self.optimizer.cpu_adam
         st = opt.state.pop(old, None)

@@ -46,33 +46,44 @@ class _Win:
     """State of one windowed host-resident batch, handed from stage to stage."""
 
 
-def _buffers(gaussians, need_a, need_p, need_late, dev):
+def _buffers(gaussians, need_a, need_p, need_late, dev, K=0):
     """Device tables (bucketed capacity, 8 % head room) + pinned host twins (50 %: host memory is cheap, and a pinned
     re-allocation is a hipHostMalloc of hundreds of ms).  `gen` counts device re-allocations: rows staged into an older
-    generation are gone."""
+    generation are gone.  K > 0 (sh_hbm_budget_gb): the first K rows of the parameter and of the gradient table are the
+    HBM-resident prefix of the model (slot r = row r), the P and A regions follow; a re-allocation carries them over."""
     hb = getattr(gaussians, "_hwin_bufs", None)
     N = gaussians._xyz.shape[0]
-    if hb is None or hb["N"] != N or hb["cap_a"] < need_a or hb["cap_p"] < need_p:
+    if hb is None or hb["N"] != N or hb.get("K", 0) != K or hb["cap_a"] < need_a or hb["cap_p"] < need_p:
         gen = hb["gen"] + 1 if hb else 0
-        keep = None
+        keep, old_pt, old_gt = None, None, None
         if hb is not None:
             # the tables are written by hipMemcpyAsync issued through ctypes on side streams (the caching allocator does not
             # know): drain the device before the old blocks go back to it
             torch.cuda.synchronize()
-            if hb["N"] == N:
+            same = hb["N"] == N and hb.get("K", 0) == K
+            if same:
                 keep = hb
-            cap_a = max(hb["cap_a"] if hb["N"] == N else 0, bucket_size(max(int(need_a * 1.08), 1)))
-            cap_p = max(hb["cap_p"] if hb["N"] == N else 0, bucket_size(max(int(need_p * 1.08), 1)))
+                if K:
+                    old_pt, old_gt = hb["pt"], hb["gt"]  # (alive until the prefix rows are copied over)
+            cap_a = max(hb["cap_a"] if same else 0, bucket_size(max(int(need_a * 1.08), 1)))
+            cap_p = max(hb["cap_p"] if same else 0, bucket_size(max(int(need_p * 1.08), 1)))
             for k in ("pt", "gt", "bb"):
                 hb[k] = None
         else:
             cap_a, cap_p = bucket_size(max(int(need_a * 1.08), 1)), bucket_size(max(int(need_p * 1.08), 1))
         gaussians._hwin_bufs = None
-        new = dict(N=N, gen=gen, cap_a=cap_a, cap_p=cap_p,
-                   pt=torch.empty((cap_p + cap_a, 48), device=dev), gt=torch.empty((cap_p + cap_a, 48), device=dev),
-                   bb=torch.empty((cap_a, 48), device=dev),
+        new = dict(N=N, K=K, gen=gen, cap_a=cap_a, cap_p=cap_p, bb=torch.empty((cap_a, 48), device=dev),
                    rows_h=keep["rows_h"] if keep else None, stage_h=keep["stage_h"] if keep else None,
                    spec_rows_h=keep["spec_rows_h"] if keep else None, spec_stage_h=keep["spec_stage_h"] if keep else None)
+        # one table at a time: the old one is alive only while its prefix rows are copied (transient = one table, not two)
+        new["pt"] = torch.empty((K + cap_p + cap_a, 48), device=dev)
+        if old_pt is not None:
+            new["pt"][:K].copy_(old_pt[:K])
+            old_pt = None
+        new["gt"] = torch.empty((K + cap_p + cap_a, 48), device=dev)
+        if old_gt is not None:
+            new["gt"][:K].copy_(old_gt[:K])
+            old_gt = None
         hb = gaussians._hwin_bufs = new
     if hb["rows_h"] is None or hb["rows_h"].shape[0] < need_late:
         cap_h = bucket_size(max(int(need_late * 1.5), 1))
@@ -82,16 +93,19 @@ def _buffers(gaussians, need_a, need_p, need_late, dev):
     return hb
 
 
-def _tables(gaussians, dev):
-    """Row-indexed scratch (independent of the batch): the slot every touched row lives in right now, two row masks."""
+def _tables(gaussians, dev, K=0):
+    """Row-indexed scratch (independent of the batch): the slot every touched row lives in right now, two row masks.
+    Rows of the HBM-resident prefix [0, K) live in slot r for good."""
     N = gaussians._xyz.shape[0]
     ht = getattr(gaussians, "_hwin_tabs", None)
-    if ht is None or ht["N"] != N:
-        ht = gaussians._hwin_tabs = dict(N=N, cur_slot=torch.zeros((N,), dtype=torch.int32, device=dev),
+    if ht is None or ht["N"] != N or ht.get("K", 0) != K:
+        ht = gaussians._hwin_tabs = dict(N=N, K=K, cur_slot=torch.zeros((N,), dtype=torch.int32, device=dev),
                                          scratch_slot=torch.zeros((N,), dtype=torch.int32, device=dev),
                                          mark=torch.zeros((N,), dtype=torch.bool, device=dev),
                                          in_spec=torch.zeros((N,), dtype=torch.bool, device=dev),
                                          cam0=torch.zeros((N,), dtype=torch.bool, device=dev))
+        if K:
+            ht["cur_slot"][:K] = torch.arange(K, dtype=torch.int32, device=dev)
     return ht
 
 
@@ -117,8 +131,18 @@ def _plan(w):
     g, args, dev, bsz, N, L = w.gaussians, w.args, w.dev, w.bsz, w.N, _lib.lib()
     with _lib.host_region("select_filters"):
         w.filters, touched = select_filters(w.cameras, g._xyz.detach(), g._scaling.detach(), g._rotation.detach())
+    _lib.STATS.setdefault("touched_rows", []).append(int(touched.shape[0]))
+    w.touched_all = touched
+    K = w.K
+    w.prefix_rows = None
+    if K:
+        # sh_hbm_budget_gb: rows [0, K) are resident (slot r = row r, stepped in HBM); only the rest is planned, staged and
+        # stepped on the host below.  (touched is ascending: one comparison pass, one host read of the split point)
+        n_lo = int((touched < K).sum())
+        w.prefix_rows = touched[:n_lo].to(torch.int32)
+        touched = touched[n_lo:]
     T = int(touched.shape[0])
-    _lib.STATS.setdefault("touched_rows", []).append(T)
+    _lib.STATS.setdefault("host_touched_rows", []).append(T)
     w.sparsity = [len(f) / float(N) for f in w.filters]
     w.ordered_cams = list(range(bsz))
     if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
@@ -136,7 +160,7 @@ def _plan(w):
             spec["thread"].join()
         if spec["err"]:
             raise spec["err"][0]
-    ht = _tables(g, dev)
+    ht = _tables(g, dev, K)
     mark, in_spec, cam0, cur_slot = ht["mark"], ht["in_spec"], ht["cam0"], ht["cur_slot"]
     with _lib.host_region("host_groups"):
         mark.zero_()
@@ -159,6 +183,8 @@ def _plan(w):
             late_all = torch.empty((T,), dtype=torch.int32, device=dev)
             rows_by_last32 = torch.empty((T,), dtype=torch.int32, device=dev)
             counts = torch.empty((2 * bsz + 1,), dtype=torch.int64, device=dev)
+            if T == 0:  # (every touched row is resident: nothing to stage)
+                return n_p, staged, wasted, late_all, rows_by_last32, [0] * (2 * bsz + 1)
             tb = L.clmgs_host_groups_temp_bytes(T)
             tmp = torch.empty((tb,), dtype=torch.uint8, device=dev)
             _lib.check(L.clmgs_host_groups(_lib.stream(), T, _lib.dptr(touched, torch.int64), _lib.dptr(bitmap),
@@ -202,7 +228,7 @@ def _plan(w):
         _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
         n_surv = cum_h[-1] if cum_h else 0
         need_a = max([n_p + n_first[0]] + n_first[1:])
-        hb = _buffers(g, need_a, n_surv, n_late, dev)
+        hb = _buffers(g, need_a, n_surv, n_late, dev, K)
         if spec is not None and spec["gen"] != hb["gen"]:
             # the tables had to grow: what was staged went with the old ones -- everything is late (re-preparing a current
             # row is the identity; the stamps of the touched rows stay right, the untouched ones are un-stamped below)
@@ -214,21 +240,23 @@ def _plan(w):
             arr, flag, cum = survivors(0, None, late_all, n_first)
             cum_h = [int(x) for x in cum.tolist()]
             n_surv = cum_h[-1] if cum_h else 0
-            hb = _buffers(g, max(n_first), n_surv, n_late, dev)
-        cap_p = hb["cap_p"]
-        # ---- slots.  A-region slot of every arrival: cap_p + position inside its camera's arrival block
+            hb = _buffers(g, max(n_first), n_surv, n_late, dev, K)
+        # ---- slots (table rows: [prefix 0..K | P | A]).  A-region slot of every arrival: base_a + position inside its
+        # camera's arrival block
+        base_p, base_a = K, K + hb["cap_p"]
+        w.base_a = base_a
         if n_p:
-            cur_slot[spec["rows"].long()] = cap_p + torch.arange(n_p, dtype=torch.int32, device=dev)
+            cur_slot[spec["rows"].long()] = base_a + torch.arange(n_p, dtype=torch.int32, device=dev)
         g0 = 0
         for k in range(bsz):
             if n_first[k]:
-                base = cap_p + (n_p if k == 0 else 0)
+                base = base_a + (n_p if k == 0 else 0)
                 cur_slot[late_all[g0:g0 + n_first[k]].long()] = base + torch.arange(n_first[k], dtype=torch.int32, device=dev)
             g0 += n_first[k]
         surv_pos = torch.nonzero(flag).flatten()              # (size n_surv, known: no extra synchronisation in effect)
         w.surv_rows = arr[surv_pos]
         w.surv_src = cur_slot[w.surv_rows].long()             # their A slots ...
-        w.surv_dst = torch.arange(n_surv, dtype=torch.int64, device=dev)  # ... and their P slots, in arrival order
+        w.surv_dst = base_p + torch.arange(n_surv, dtype=torch.int64, device=dev)  # ... and their P slots, in arrival order
         w.surv_cum = cum_h
         rbl = rows_by_last32.long()
         leave = cur_slot[rbl].long()
@@ -248,6 +276,8 @@ def _plan(w):
             try:
                 f_next, _ = select_filters(w.hint[:1], g._xyz.detach(), g._scaling.detach(), g._rotation.detach())
                 sr = f_next[0]
+                if K:
+                    sr = sr[sr >= K]
                 sr = sr[~mark[sr]]
                 n_s = int(sr.shape[0])
                 if 0 < n_s <= hb["cap_a"]:
@@ -386,7 +416,7 @@ def _cameras(w):
     from ...fused import train_one_camera
     from .engine import _zero_small_grads
     g, hb, bsz, N = w.gaussians, w.hb, w.bsz, w.N
-    pt, gt, bb, cap_p = hb["pt"], hb["gt"], hb["bb"], hb["cap_p"]
+    pt, gt, bb, cap_p = hb["pt"], hb["gt"], hb["bb"], w.base_a  # (cap_p below: first row of the arrival region)
     cur_slot = g._hwin_tabs["cur_slot"]
     ds, out_stream = w.default_stream, w.out_stream
     _zero_small_grads(g)
@@ -461,6 +491,47 @@ def _camera_loop(w, losses, l0, c_prev, ev_out, pt, gt, bb, cap_p, cur_slot, ds,
     return losses
 
 
+# ------------------------------------------------------------------------------------- the HBM-resident prefix (budget)
+def _prefix_head(w):
+    """Before the cameras: the resident rows this batch renders from are brought up to the previous step by the deferred
+    row optimizer of the HBM engine (their waiting gradient at its own step, then the zero-gradient steps they skipped;
+    consumed gradient rows are cleared, so the cameras accumulate into zeros).  Runs while the host pool prepares the
+    first camera's rows."""
+    px, g = w.px, w.gaussians
+    if px is None:
+        return
+    K, hb = px["K"], w.hb
+    if px["fill"]:  # first batch after a load: the rows themselves (the moments came with hbm_prefix_ensure)
+        hb["pt"][:K].copy_(g._parameters.data[:K])
+        hb["gt"][:K].zero_()
+        px["fill"] = False
+    if not w.args.sparse_adam:
+        g.hbm_prefix_catch_up(w.prefix_rows, w.step - 1)
+
+
+def _prefix_tail(w):
+    """After the cameras: the resident rows' gradient of this batch waits in the table, stamped with this step (dense Adam:
+    applied at the row's next touch / at a flush), or is applied now (sparse_adam: only touched rows ever step)."""
+    px, g = w.px, w.gaussians
+    if px is None or w.prefix_rows.numel() == 0:
+        return
+    K, hb, rows = px["K"], w.hb, w.prefix_rows
+    if w.skip_opt:  # test hook: the unscaled sums go where the host rows' gradients go, and nothing is left behind
+        idx = rows.long()
+        clm_kernels._rows("clmgs_rows_gather", w.parameters_grad_buffer[:w.N, :], hb["gt"], idx, idx, 0)
+        torch.cuda.synchronize()
+        hb["gt"].index_fill_(0, idx, 0.0)
+        return
+    px["dirty"] = True
+    if w.args.sparse_adam:
+        opt = g.optimizer.cpu_adam
+        gr = opt.param_groups[0]
+        clm_kernels.adam_rows(hb["pt"][:K], hb["gt"][:K], px["m"], px["v"], rows, opt._col_lr(w.dev), gr["betas"][0],
+                              gr["betas"][1], gr["eps"], w.step, gr["bias_correction"], 1.0 / float(w.bsz), True)
+    else:
+        utils.fill_rows(px["g_step"], rows.long(), w.step)
+
+
 def train_one_batch_host_windowed(gaussians, scene, batched_cameras, parameters_grad_buffer, background, pipe_args,
                                   comm_stream, perm_generator, args):
     """-> (losses, ordered_cams, sparsity); see the module docstring."""
@@ -484,17 +555,21 @@ def train_one_batch_host_windowed(gaussians, scene, batched_cameras, parameters_
     gaussians._next_batch_hint = None
     if w.skip_opt or not getattr(args, "host_speculative_prefetch", True) or getattr(args, "reference_camera_order", False):
         w.hint = None
+    w.px = gaussians.hbm_prefix_ensure()  # (sh_hbm_budget_gb; a first call flushes the host rows and loads the prefix)
+    w.K = w.px["K"] if w.px is not None else 0
     with torch.no_grad():
         _plan(w)
         _start_feeders(w)
+        _prefix_head(w)
         losses = _cameras(w)
+        _prefix_tail(w)
     if w.skip_opt:
         torch.cuda.synchronize()
         return losses, w.ordered_cams, w.sparsity
     visibility_mask = None
     if args.sparse_adam:
         visibility_mask = torch.zeros((w.N,), dtype=torch.bool, device=w.dev)
-        utils.fill_rows(visibility_mask, w.touched, True)
+        utils.fill_rows(visibility_mask, w.touched_all, True)
     E._gpu_adam_step(gaussians, args, visibility_mask)
     gaussians.invalidate_small_packed()
     E._mark_batch(gaussians)

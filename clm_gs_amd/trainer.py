@@ -458,8 +458,10 @@ if __name__ == "__main__":  # python -m clm_gs_amd.trainer -s <colmap dir> -m <o
     for s_ in ("clm_offload", "no_offload", "naive_offload"):
         grp.add_argument("--" + s_, action="store_true")
     ap.add_argument("--sh_residency", choices=["hbm", "host"], default="hbm")
+    ap.add_argument("--sh_hbm_budget_gb", type=float, default=0.0,
+                    help="sh_residency=host: HBM that keeps the first rows of the Z-ordered SH table resident (768 B per row)")
     a = ap.parse_args()
     strat = "no_offload" if a.no_offload else ("naive_offload" if a.naive_offload else "clm_offload")
     _, _, t = train_from_colmap(a.source_path, a.model_path, strategy=strat, iterations=a.iterations, eval=a.eval,
                                 resolution=a.resolution, images=a.images, test_iterations=tuple(a.test_iterations),
-                                bsz=a.bsz, sh_residency=a.sh_residency)
+                                bsz=a.bsz, sh_residency=a.sh_residency, sh_hbm_budget_gb=a.sh_hbm_budget_gb)

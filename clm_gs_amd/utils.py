@@ -70,6 +70,9 @@ def default_args(**over):
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
         host_staging="window",           # host-resident mode: "window" = per-camera staging tables + the rows several cameras
                                          # share (strategies/clm_offload/host_window.py), "batch" = the union of the batch's rows
+        sh_hbm_budget_gb=0.0,            # host-resident mode, window staging: this much HBM (768 B per row: parameters, two
+                                         # moments, gradient) keeps rows [0, K) of the Z-ordered SH table RESIDENT -- rendered
+                                         # from and stepped in HBM, never crossing the link (gaussian_model.hbm_prefix_*)
         host_speculative_prefetch=True,  # host-resident mode: stage the hinted next batch's untouched rows early
         device_side_counts=True,   # fused engine: consumers of a camera's intersection list read its length on the device
         isect_capacity_margin=1.25,  # ... from buffers sized (largest count seen at this image size) x margin

@@ -27,6 +27,8 @@ def _setup(strategy, residency="hbm", sparse=False, seed=0):
     staging = {}
     if residency == "host_batch":  # host-resident rows staged as the union of the batch (engine._train_one_batch_host)
         residency, staging = "host", {"host_staging": "batch"}
+    if residency == "host_budget":  # host-resident rows, about half of them (K = 1 500) kept in HBM (sh_hbm_budget_gb)
+        residency, staging = "host", {"sh_hbm_budget_gb": 1500 * 768 / 1e9 + 1e-9}
     args = utils.default_args(bsz=BSZ, sh_residency=residency, sparse_adam=sparse, fused_front_end=FUSED, **staging)
     setattr(args, strategy, True)
     utils.set_args(args)
@@ -375,7 +377,8 @@ def test_order_calculation_invariants(dev):
     assert set(fin[0].tolist()) == set(range(N)) - set().union(*sets)
 
 
-@pytest.mark.parametrize("strategy,residency", [("no_offload", "hbm"), ("clm_offload", "hbm"), ("clm_offload", "host")])
+@pytest.mark.parametrize("strategy,residency", [("no_offload", "hbm"), ("clm_offload", "hbm"), ("clm_offload", "host"),
+                                                ("clm_offload", "host_budget")])
 def test_densify_and_prune_keeps_state_aligned(dev, strategy, residency):
     r = _one_step(strategy, residency)
     m = r["model"]
@@ -536,7 +539,8 @@ def test_naive_offload_densify_and_prune(dev):
     assert naive_offload_eval_one_cam(m, _Scene, cams[0], None).shape == (3, H, W)
 
 
-@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("clm_offload", "host"), ("no_offload", "hbm")])
+@pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("clm_offload", "host"), ("clm_offload", "host_budget"),
+                                                ("no_offload", "hbm")])
 def test_spatial_sort_mid_training_is_a_pure_relabelling(dev, strategy, residency):
     """permute_rows / spatial_sort (rows along a Z-order curve of x, y) between two batches: parameters,
     both Adam moments and the densification statistics afterwards are the un-sorted run's, row for row
@@ -617,7 +621,7 @@ def test_camera_without_intersections_trains_with_zero_gradients(dev):
             assert float(q.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("residency", ["hbm", "host"])
+@pytest.mark.parametrize("residency", ["hbm", "host", "host_budget"])
 def test_reference_camera_order_reorders_and_reports_like_the_reference(dev, residency):
     """reference_camera_order=True: the batch's cameras are processed in order_calculation's TSP order (the
     reference's engine.py:135-298) and `ordered_cams` / `sparsity` / `losses` are reported in that order; the
@@ -934,3 +938,61 @@ def test_split_catch_up_equals_single_pass(dev):
     for i, (a, b) in enumerate(zip(*outs)):
         assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), i
     assert float(torch.stack([x for x in outs[0][1:2 * nb:2]]).sum()) > 0
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_host_rows_with_an_hbm_budget_end_where_the_host_rows_end(dev, sparse):
+    """sh_hbm_budget_gb: rows [0, K) of the SH table live in HBM -- rendered from there, stepped
+    there by the HBM engine's deferred row optimizer -- and only the rest goes through the host path.  Six batches with
+    hints, an evaluation (reads the host table: the prefix is written back), a densification (structure changes: the device
+    copy is dropped and loaded again) and a final flush must end where the plain host-resident run ends: the two row
+    optimizers are the same arithmetic (host: C++, device: HIP; FMA contraction may differ in the last bit)."""
+    from clm_gs_amd import _lib, utils
+    from clm_gs_amd.strategies.clm_offload import clm_offload_eval_one_cam, clm_offload_train_one_batch
+    from clm_gs_amd.strategies.clm_offload.engine import hint_next_batch
+    from clm_gs_amd.synthetic import nadir_cameras
+    res = {}
+    for mode in ("host", "host_budget"):
+        args, sc, cams = _setup("clm_offload", mode, sparse)
+        more = nadir_cameras(3 * BSZ, N, W, H, 0.35, seed=3, device="cuda")
+        g = torch.Generator().manual_seed(7)
+        for c in more:
+            c.original_image = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).cuda()
+        batches = [cams, more[:BSZ], more[BSZ:2 * BSZ], cams, more[2 * BSZ:], more[:BSZ]]
+        m = _make("clm_offload", sc, args)
+        comm, gen = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1)
+        it, losses, imgs = 1, [], []
+        for b, cs in enumerate(batches):
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            if b + 1 < len(batches) and b not in (2, 3):
+                hint_next_batch(m, batches[b + 1])
+            l, _, _ = clm_offload_train_one_batch(m, _Scene, cs, m.parameters_grad_buffer, None, None, comm, gen)
+            losses += [x.item() for x in l]
+            it += BSZ
+            if mode == "host_budget":
+                px = m._hbm_prefix
+                assert px is not None and px["dirty"] and not px["fill"] and px["K"] == 1500 == m._hwin_bufs["K"]
+                assert _lib.STATS["host_touched_rows"][-1] < _lib.STATS["touched_rows"][-1]
+            if b == 2:
+                imgs.append(clm_offload_eval_one_cam(cams[1], m, None, _Scene).clone())
+                if mode == "host_budget":
+                    assert not m._hbm_prefix["dirty"]  # written back, still loaded
+            if b == 3:
+                m.xyz_gradient_accum = torch.full_like(m.xyz_gradient_accum, 1e-3) * (torch.arange(m._xyz.shape[0], device="cuda")[:, None] % 7 == 0)
+                m.denom = torch.ones_like(m.denom)
+                m.split_generator = torch.Generator(device="cuda").manual_seed(3)
+                m.densify_and_prune(0.0002, 0.005, 30.0, None)
+                if mode == "host_budget":
+                    assert m._hbm_prefix is None  # dropped with the structure it described
+        torch.cuda.synchronize()
+        m.flush_lazy_rows()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        res[mode] = (losses, imgs, [t.detach().clone().cuda() for t in (m._xyz, m._opacity, m._parameters, st["exp_avg"], st["exp_avg_sq"])])
+    assert res["host"][2][0].shape == res["host_budget"][2][0].shape
+    for a, b in zip(res["host"][0], res["host_budget"][0]):
+        assert abs(a - b) < 2e-6
+    for a, b in zip(res["host"][1], res["host_budget"][1]):
+        assert float((a - b).abs().max()) < 1e-5
+    for a, b, name in zip(res["host"][2], res["host_budget"][2], ("xyz", "opacity", "sh", "m", "v")):
+        assert rel_l2(a, b) < 2e-6, name

@@ -54,6 +54,10 @@ def _res(residency):
     """"host_batch": host-resident rows staged as the union of the batch (the round-2..5 form); "host": per-camera windows."""
     if residency == "host_batch":
         return {"sh_residency": "host", "host_staging": "batch"}
+    if residency == "host_budget":  # ... with about half of the rows (K = 1 002) resident in HBM (sh_hbm_budget_gb)
+        return {"sh_residency": "host", "sh_hbm_budget_gb": 7.7e-4}
+    if residency == "host_budget_all":  # ... with every row resident: nothing left for the host path to stage
+        return {"sh_residency": "host", "sh_hbm_budget_gb": 1.0}
     return {"sh_residency": residency}
 
 
@@ -195,7 +199,7 @@ def test_no_offload_three_batches_match_reference_training(dev, fx, fused):
 
 
 # ------------------------------------------------------------------ a4 / a7 / a8 / a9 / a11 / a16: clm_offload
-CLM_MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True)]  # the host-resident mode runs the fused front end only
+CLM_MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True), ("host_budget", True), ("host_budget_all", True)]  # the host-resident mode runs the fused front end only
 
 
 def _clm_batch(m, Scene, batch, comm, gen):

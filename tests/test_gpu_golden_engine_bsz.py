@@ -54,6 +54,10 @@ def _res(residency):
     """"host_batch": host-resident rows staged as the union of the batch (the round-2..5 form); "host": per-camera windows."""
     if residency == "host_batch":
         return {"sh_residency": "host", "host_staging": "batch"}
+    if residency == "host_budget":  # ... with about half of the rows (K = 1 002) resident in HBM (sh_hbm_budget_gb)
+        return {"sh_residency": "host", "sh_hbm_budget_gb": 7.7e-4}
+    if residency == "host_budget_all":  # ... with every row resident: nothing left for the host path to stage
+        return {"sh_residency": "host", "sh_hbm_budget_gb": 1.0}
     return {"sh_residency": residency}
 
 
@@ -170,7 +174,7 @@ def test_bitmap_ops_on_wide_words_match_oracle(dev, bsz, dtype):
 
 
 # ------------------------------------------------------------------ a8: the batch at bsz 16 / 64
-MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True)]
+MODES = [("hbm", True), ("hbm", False), ("host", True), ("host_batch", True), ("host_budget", True), ("host_budget_all", True)]
 
 
 @pytest.mark.parametrize("residency,fused", MODES)
