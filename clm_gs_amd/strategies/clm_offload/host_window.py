@@ -55,7 +55,7 @@ def _buffers(gaussians, need_a, need_p, need_late, dev, K=0):
     N = gaussians._xyz.shape[0]
     if hb is None or hb["N"] != N or hb.get("K", 0) != K or hb["cap_a"] < need_a or hb["cap_p"] < need_p:
         gen = hb["gen"] + 1 if hb else 0
-        keep, old_pt, old_gt = None, None, None
+        keep, old_pt = None, None
         if hb is not None:
             # the tables are written by hipMemcpyAsync issued through ctypes on side streams (the caching allocator does not
             # know): drain the device before the old blocks go back to it
@@ -63,8 +63,14 @@ def _buffers(gaussians, need_a, need_p, need_late, dev, K=0):
             same = hb["N"] == N and hb.get("K", 0) == K
             if same:
                 keep = hb
-                if K:
-                    old_pt, old_gt = hb["pt"], hb["gt"]  # (alive until the prefix rows are copied over)
+                px = getattr(gaussians, "_hbm_prefix", None)
+                if K and px is not None and not px["fill"]:
+                    # the resident rows move to the new table; their waiting gradients are applied first (one pass of the
+                    # deferred row optimizer over the K rows, ~4 ms at 14 M), so the gradient table holds zeros there and
+                    # is not carried over: the only transient is the old parameter table beside the new one
+                    if not gaussians.args.sparse_adam:
+                        gaussians.hbm_prefix_catch_up(None, int(gaussians.optimizer.cpu_adam.global_step))
+                    old_pt = hb["pt"]
             cap_a = max(hb["cap_a"] if same else 0, bucket_size(max(int(need_a * 1.08), 1)))
             cap_p = max(hb["cap_p"] if same else 0, bucket_size(max(int(need_p * 1.08), 1)))
             for k in ("pt", "gt", "bb"):
@@ -75,15 +81,13 @@ def _buffers(gaussians, need_a, need_p, need_late, dev, K=0):
         new = dict(N=N, K=K, gen=gen, cap_a=cap_a, cap_p=cap_p, bb=torch.empty((cap_a, 48), device=dev),
                    rows_h=keep["rows_h"] if keep else None, stage_h=keep["stage_h"] if keep else None,
                    spec_rows_h=keep["spec_rows_h"] if keep else None, spec_stage_h=keep["spec_stage_h"] if keep else None)
-        # one table at a time: the old one is alive only while its prefix rows are copied (transient = one table, not two)
         new["pt"] = torch.empty((K + cap_p + cap_a, 48), device=dev)
         if old_pt is not None:
             new["pt"][:K].copy_(old_pt[:K])
             old_pt = None
         new["gt"] = torch.empty((K + cap_p + cap_a, 48), device=dev)
-        if old_gt is not None:
-            new["gt"][:K].copy_(old_gt[:K])
-            old_gt = None
+        if K:
+            new["gt"][:K].zero_()
         hb = gaussians._hwin_bufs = new
     if hb["rows_h"] is None or hb["rows_h"].shape[0] < need_late:
         cap_h = bucket_size(max(int(need_late * 1.5), 1))

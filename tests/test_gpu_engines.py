@@ -750,7 +750,7 @@ def test_host_speculative_prefetch_is_exact(dev, staging):
         assert torch.equal(res[mode][4], res["plain"][4])                      # and no stamp left behind by a dropped hint
 
 
-@pytest.mark.parametrize("staging", ["host", "host_batch"])
+@pytest.mark.parametrize("staging", ["host", "host_batch", "host_budget"])
 def test_host_staging_tables_grow_under_an_outstanding_speculation(dev, staging):
     """The staging tables are sized from the batches seen so far; a batch whose cameras see far more rows makes them grow
     while rows staged speculatively for it sit in the OLD tables: everything must then be treated as late, the untouched
@@ -764,6 +764,8 @@ def test_host_staging_tables_grow_under_an_outstanding_speculation(dev, staging)
     n, w_, h_ = 60_000, 160, 120  # (capacities are bucketed with a floor of 4 096 rows: the module's 3 000-row scene never grows)
     for mode in ("plain", "hinted"):
         over = {"host_staging": "batch"} if staging == "host_batch" else {}
+        if staging == "host_budget":  # half of the rows resident in HBM: the re-allocation carries them to the new tables
+            over = {"sh_hbm_budget_gb": 30_000 * 768 / 1e9 + 1e-9}
         args = utils.default_args(bsz=BSZ, sh_residency="host", **over)
         args.clm_offload = True
         utils.set_args(args)
@@ -800,6 +802,28 @@ def test_host_staging_tables_grow_under_an_outstanding_speculation(dev, staging)
     for a, b in zip(res["hinted"][1], res["plain"][1]):
         assert torch.equal(a, b)
     assert torch.equal(res["hinted"][2], res["plain"][2]) and torch.equal(res["hinted"][3], res["plain"][3])
+    if staging == "host_budget":  # ... and where the run without a budget ends (same arithmetic on the other processor)
+        res["budget"] = res["hinted"]
+        args = utils.default_args(bsz=BSZ, sh_residency="host")
+        args.clm_offload = True
+        utils.set_args(args)
+        m = _make("clm_offload", synth_gaussians(n, seed=3, device="cuda"), args)
+        small = nadir_cameras(2 * BSZ, n, w_, h_, 0.05, seed=21, device="cuda")
+        big = nadir_cameras(BSZ, n, w_, h_, 0.6, seed=22, device="cuda")
+        g = torch.Generator().manual_seed(6)
+        for c in small + big:
+            c.original_image = (torch.rand(3, h_, w_, generator=g) * 255).to(torch.uint8).cuda()
+        comm, gen, it = torch.cuda.Stream(), torch.Generator(device="cuda").manual_seed(1), 1
+        for batch in [small[:BSZ], big, small[BSZ:], big]:
+            utils.set_cur_iter(it)
+            m.update_learning_rate(it)
+            clm_offload_train_one_batch(m, _Scene, batch, m.parameters_grad_buffer, None, None, comm, gen)
+            it += BSZ
+        m.flush_lazy_rows()
+        torch.cuda.synchronize()
+        st = m.optimizer.cpu_adam.state[m._parameters]
+        for a, b, name in zip(res["budget"][1][4:], (m._parameters, st["exp_avg"], st["exp_avg_sq"]), ("sh", "m", "v")):
+            assert rel_l2(a.cuda(), b.detach().cuda()) < 2e-6, name
 
 
 def test_deferred_small_adam_equals_eager(dev):
