@@ -58,6 +58,18 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_mb -o mb -- python $R/
 DB=$(find /tmp/prof_mb -name "*.db" | head -1)
 python $R/profiles/kernel_stats.py "$DB" 100000 | grep -i "rasterize\|Name" >> $O/raster_microbench_under_rocprof.txt
 cd $R
+# 8b. SQ counters of the two tile kernels on the microbench (one camera of the bench scene), four separate --pmc passes
+cd /tmp
+echo "# rocprofv3 --kernel-trace --pmc <4 counters per pass> -- python profiles/raster_microbench.py slab 5; per launch (mean, median)" > $O/pmc_sq_tile_kernels.txt
+i=0
+for SET in "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
+           "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU" \
+           "SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD"; do
+  i=$((i+1)); rm -rf /tmp/pmcT$i
+  timeout 200 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmcT$i -o t -- python $R/profiles/raster_microbench.py slab 5 > $O/pmcT$i.log 2>&1
+  python $R/profiles/pmc_summary.py $(find /tmp/pmcT$i -name "*counter_collection.csv" | head -1) | grep rasterize >> $O/pmc_sq_tile_kernels.txt 2>&1
+done
+cd $R
 # 9. the GPU test suite
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu_final.log
 ls -la $O
