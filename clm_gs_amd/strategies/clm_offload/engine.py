@@ -10,12 +10,13 @@ Two residency modes for the [N,48] SH rows and their optimizer state (see gaussi
   the fused front end; the SH-row optimizer is DEFERRED (a row's step of batch b is applied, with the
   zero-gradient steps it skipped, the next time the row is rendered / evaluated / saved: clmgs_adam_catch_up);
   the cameras of a batch run as a software pipeline over three streams by kernel type.
-* host-resident (`_train_one_batch_host`, the offloading configuration of the metric).  Pinned host rows; the
-  union of the batch's touched rows is staged once per direction: a feeder thread drives the host pool
-  (deferred host row optimizer + copy into pinned staging) and ships 48 MB chunks with hipMemcpyAsync on a side
-  stream, grouped by the camera that uses a row first; gradient rows go home as zero-copy stores after the
-  camera that uses a row last.  No retention sets, no signal flags, no host Adam thread: see the function's
-  docstring for what replaced them and why.
+* host-resident (`_train_one_batch_host`, the offloading configuration of the metric).  Pinned host rows; every
+  touched row is staged once per direction: helper threads drive the host pool (deferred host row optimizer + copy
+  into pinned staging) and ship 48 MB chunks with hipMemcpyAsync on a side stream, grouped by the camera that uses
+  a row first; gradient rows go home as zero-copy stores after the camera that uses a row last.  Two staging forms,
+  each its own module of four stage functions: per-camera windows (`host_window.py`, the default; `sh_hbm_budget_gb`
+  keeps a prefix of the rows resident and stepped in HBM) and the union of the batch (`host_batch.py`).  No retention
+  sets, no signal flags, no host Adam thread: the modules' docstrings say what replaced them and why.
 
 Camera order: both modes process the cameras in the order given (the batch gradient does not depend on it and
 every touched row crosses the host link once per direction whatever the order).  `order_calculation` -- the
@@ -23,11 +24,8 @@ reference's TSP order + last-use groups + retention-set sizes (engine.py:135-298
 reference-compatible ordering entry and is what `reference_camera_order=True` runs: the cameras are then
 processed, and `ordered_cams` / `sparsity` reported, in that order, as the reference does.
 """
-import ctypes
 import math
 import os
-import threading
-import time
 
 import torch
 
@@ -853,298 +851,16 @@ def _drop_speculation(gaussians):
 
 def _train_one_batch_host(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
                           pipe_args, comm_stream, perm_generator, args):
-    """Host-resident SH rows + Adam state (sh_residency="host"): what the reference's retention pipeline
-    and cpu-adam thread do (clm_offload/engine.py:494-508, 622-641, 789-825, 301-335), re-shaped around
-    what this machine's host link and host cores reward.
-
-    * Every row the batch touches crosses the link ONCE per direction (the minimum the H / D / G retention
-      sets aim at, reached without camera re-ordering): the union of the batch's filters is staged, grouped
-      by the camera that uses a row FIRST (host -> GPU) and LAST (GPU -> host), so camera k renders as soon
-      as its own new rows have arrived while the rows only later cameras need are still being prepared,
-      and a row's gradient leaves right after the last camera that contributes to it.
-    * Host -> GPU: a feeder thread drives the host thread pool, which brings the touched rows up to date
-      (DEFERRED row optimizer: the gradient a row received in an earlier batch is applied, and the
-      zero-gradient Adam steps it has skipped since are replayed, only now -- one read and one write of
-      p / m / v per touched row and batch, where the dense reference optimizer streams all N rows every
-      batch) and copies them into a contiguous pinned staging buffer, chunk by chunk; each finished chunk
-      goes to the GPU with a hipMemcpyAsync on the side stream (SDMA engine: no compute unit is taken from
-      the renderer) while the pool works on the next chunk.
-    * SPECULATIVE PREFETCH (hint_next_batch): the host pool is busy for the first ~60 % of a batch and the link
-      for less; the rows of the NEXT batch that the present one does not touch (their state is final until
-      then) are prepared and shipped in that idle time into the second staging table.  When the next batch
-      arrives, its exact selection is compared with what was staged: only the LATE rows (touched by both
-      batches: their gradient had to come home first -- plus the few a position update moved into view) go
-      through the feeder at batch time, so the first camera waits for a third of its rows instead of all.
-    * The cameras render from / accumulate into GPU staging tables ([T,48] parameters and gradients, row
-      -> slot through an index the fused front end follows).
-    * GPU -> host: zero-copy scatter STORES of the gradient rows into the pinned gradient table (plain
-      stores, no read-modify-write over the link, no host pass), on a second side stream; they wait there,
-      stamped with this batch's step, until the row is needed again.
-    """
+    """Host-resident SH rows + Adam state (sh_residency="host"), in one of two staging forms, each a module of four stage
+    functions (plan -> feeders -> cameras -> the small attributes' optimizer step): per-camera staging windows
+    (host_window.py, the default; optionally with an HBM budget that keeps a prefix of the rows resident) or the union of the
+    batch's rows (host_batch.py, rounds 2-5's form)."""
     if getattr(args, "host_staging", "window") == "window":
-        # per-camera staging windows (host_window.py): the same link traffic from half the staging memory
-        from .host_window import train_one_batch_host_windowed
-        return train_one_batch_host_windowed(gaussians, scene, batched_cameras, parameters_grad_buffer, background,
-                                             pipe_args, comm_stream, perm_generator, args)
-    assert not float(getattr(args, "sh_hbm_budget_gb", 0.0) or 0.0), "sh_hbm_budget_gb is built on host_staging='window'"
-    from ...fused import train_one_camera
-    bsz = len(batched_cameras)
-    N = gaussians._xyz.shape[0]
-    dev = gaussians._xyz.device
-    assert not dp.active(), "camera-DP is built for sh_residency='hbm' (every rank holds a full replica)"
-    assert gaussians.deferred_host_rows
-    assert getattr(args, "fused_front_end", True), "the host-resident mode runs the fused front end"
-    assert args.lr_scale_mode == "sqrt", "Overlap CPUAdam only supports sqrt lr scaling"
-    assert not args.stop_update_param, "Overlap CPUAdam does not support stop_update_param"
-    L = _lib.lib()
-    skip_opt = getattr(args, "debug_skip_optimizer", False)  # test hook, see _train_one_batch_hbm
-    default_stream = torch.cuda.current_stream()
-    if getattr(gaussians, "_host_out_stream", None) is None:
-        gaussians._host_out_stream = torch.cuda.Stream()
-    out_stream = gaussians._host_out_stream
-    hint = getattr(gaussians, "_next_batch_hint", None)
-    gaussians._next_batch_hint = None
-    if skip_opt or not getattr(args, "host_speculative_prefetch", True):
-        hint = None
-    with torch.no_grad():
-        with _lib.host_region("select_filters"):
-            filters, touched_rows = select_filters(batched_cameras, gaussians._xyz.detach(),
-                                                   gaussians._scaling.detach(), gaussians._rotation.detach())
-        T = int(touched_rows.shape[0])
-        _lib.STATS.setdefault("touched_rows", []).append(T)
-        sparsity = [len(f) / float(N) for f in filters]
-        ordered_cams = list(range(bsz))
-        if getattr(args, "reference_camera_order", False):  # the reference's TSP order (engine.py:135-298)
-            _, batched_cameras, filters, sparsity, ordered_cams = order_calculation(
-                list(filters), list(batched_cameras), N, bsz, perm_generator, args)[:5]
-        # ---- what was staged for this batch while the previous one rendered
-        spec = getattr(gaussians, "_host_spec", None)
-        gen0 = (getattr(gaussians, "_host_bufs", None) or {}).get("gen")
-        if spec is not None and (spec["key"] != tuple(sorted(id(c) for c in batched_cameras)) or spec["N"] != N
-                                 or spec["gen"] != gen0):
-            _drop_speculation(gaussians)
-            spec = None
-        gaussians._host_spec = None
-        n_p = 0
-        if spec is not None:
-            with _lib.host_region("spec_join"):
-                spec["thread"].join()
-            if spec["err"]:
-                raise spec["err"][0]
-            n_p = spec["n"]
-        ht = _host_tables(gaussians, dev)
-        slot_of, mark, in_spec = ht["slot_of"], ht["mark"], ht["in_spec"]
-        with _lib.host_region("host_groups"):
-            mark.zero_()
-            utils.fill_rows(mark, touched_rows, True)          # rows this batch touches
-            wasted = touched_rows[:0]
-            staged_mask = None
-            if spec is not None and n_p:
-                P = spec["rows"]                                 # staged rows, slot k = P[k]
-                wasted = P[~mark[P]]                             # staged but not touched: no gradient will land
-                in_spec.zero_()
-                utils.fill_rows(in_spec, P, True)
-                staged_mask = in_spec
-            # ---- ONE library call (clmgs_host_groups) groups the rows: the rows still to be staged ("late": not in
-            # the speculative block) by the camera that uses them FIRST (slot order), all touched rows by the camera
-            # that uses them LAST (hand-back order), slot_of[] of the late rows, and the 2 bsz + 1 group sizes on the
-            # device -- two stable one-digit radix sorts.  Rounds 2-3 did this with ~60 torch index ops (float64 log2 of
-            # the bitmap words, two 64-bit sorts, bincounts, boolean selections): 24 ms of a 114 ms batch during which
-            # the GPU did little else.
-            bitmap = _encode_bitmap(filters, N, bsz)                     # MSB = camera 0
-            late_all = torch.empty((T,), dtype=torch.int32, device=dev)
-            rows_by_last32 = torch.empty((T,), dtype=torch.int32, device=dev)
-            counts = torch.empty((2 * bsz + 1,), dtype=torch.int64, device=dev)
-            tb = L.clmgs_host_groups_temp_bytes(T)
-            tmp = torch.empty((tb,), dtype=torch.uint8, device=dev)
-            _t0 = time.perf_counter()
-            # (slot_of of the late rows needs slot0 = n_p, which is only final once the staging tables are known not to
-            #  have been re-allocated: n_p is re-checked below and the call repeated in that rare case)
-            def group(slot0, staged):
-                _lib.check(L.clmgs_host_groups(_lib.stream(), T, _lib.dptr(touched_rows, torch.int64), _lib.dptr(bitmap),
-                                               bitmap.element_size(), bsz, _lib.dptr(staged.view(torch.uint8), None, True)
-                                               if staged is not None else None, int(slot0), _lib.dptr(late_all),
-                                               _lib.dptr(rows_by_last32), _lib.dptr(slot_of), _lib.dptr(counts),
-                                               _lib.dptr(tmp), tb))
-            group(n_p, staged_mask)
-            cl = counts.tolist()                                          # one host read: the group sizes
-            _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
-            n_late = int(cl[2 * bsz])
-            hb = _host_buffers(gaussians, n_p + n_late, dev)
-            if spec is not None and spec["gen"] != hb["gen"]:
-                # the staging tables had to grow: what was staged went with the old ones -- everything is late
-                # (re-preparing a current row is the identity; the stamps of the touched rows stay right)
-                n_p, spec = 0, None
-                group(0, None)
-                cl = counts.tolist()
-                n_late = int(cl[2 * bsz])
-            if spec is not None and n_p:
-                slot_of[spec["rows"]] = torch.arange(n_p, dtype=torch.int32, device=dev)
-            sh_stage = hb["sh_stage"][hb["cur"]]
-            T_slots = n_p + n_late
-            _lib.STATS.setdefault("host_late_rows", []).append(n_late)
-            g_stage = hb["g_stage"][:T_slots]
-            rows32 = late_all[:n_late]                                   # slot n_p + k holds row rows32[k]
-            late_sorted = rows32
-            rows_h, stage_h = hb["rows_h"][:n_late], hb["stage_h"][:n_late]
-            if n_late:
-                _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(rows_h), ctypes_ptr(rows32), n_late * 4, 2))
-            sh_index = [slot_of[f] for f in filters]
-            rows_by_last = rows_by_last32.to(torch.int64)
-            slots_by_last = slot_of[rows_by_last]
-            # ---- the NEXT batch's rows on the positions current now; what this batch touches cannot be staged early
-            spec_rows = None
-            t_next = None
-            if hint is not None:
-                try:
-                    _, t_next = select_filters(hint, gaussians._xyz.detach(), gaussians._scaling.detach(),
-                                               gaussians._rotation.detach())
-                except AssertionError:  # a hinted camera sees nothing yet: that batch will complain itself
-                    t_next = None
-            if t_next is not None:
-                spec_rows = t_next[~mark[t_next]]
-                n_s = int(spec_rows.shape[0])
-                del t_next
-                if n_s and n_s <= hb["cap"]:
-                    _host_spec_buffers(hb, dev)
-                    _lib.check(L.clmgs_memcpy_async(_lib.stream(), ctypes_ptr(hb["spec_rows_h"][:n_s]),
-                                                    ctypes_ptr(spec_rows.to(torch.int32)), n_s * 4, 2))
-                else:
-                    spec_rows = None
-            _t0 = time.perf_counter()
-            wasted_h = wasted.cpu() if wasted.numel() else None
-            _lib.STATS["host_wait_s"] += time.perf_counter() - _t0
-        n_first, n_last = cl[:bsz], cl[bsz:2 * bsz]
-        if wasted_h is not None:  # staged for this batch but not touched by it: they expect no gradient after all
-            gaussians._host_g_step[wasted_h] = 0
-        prev = gaussians._host_grads_event
-        if prev is not None:  # the previous batch's scatter still reads g_stage
-            default_stream.wait_event(prev)
-        g_stage.zero_()
-        row_adam = gaussians.optimizer.cpu_adam
-        step = row_adam.global_step + 1
-        comm_stream.wait_stream(default_stream)
-        cs = ctypes.c_void_p(comm_stream.cuda_stream)
-        # ---- feeder: prepare + stage + hipMemcpyAsync chunk by chunk, one event per first-use group
-        ready = [threading.Event() for _ in range(bsz)]
-        ev_group = [None] * bsz
-        err = []
-
-        def feeder():
-            try:
-                if prev is not None:  # gradients of the previous batch must have landed before any row is stepped
-                    prev.synchronize()
-                k0 = 0
-                for i in range(bsz):
-                    k1 = k0 + n_first[i]
-                    for c0 in range(k0, k1, _HOST_CHUNK_ROWS):
-                        c1 = min(k1, c0 + _HOST_CHUNK_ROWS)
-                        _tp = time.perf_counter()
-                        gaussians.host_rows_prepare(rows_h[c0:c1], stage_h[c0:c1], to_step=step - 1,
-                                                    next_g_step=0 if skip_opt else step, sync_grads=False)
-                        _lib.STATS["host_prepare_s"] = _lib.STATS.get("host_prepare_s", 0.0) + time.perf_counter() - _tp
-                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(sh_stage[n_p + c0:n_p + c1]),
-                                                        ctypes_ptr(stage_h[c0:c1]), (c1 - c0) * 192, 1))
-                    ev = torch.cuda.Event()
-                    ev.record(comm_stream)
-                    ev_group[i] = ev
-                    ready[i].set()
-                    k0 = k1
-            except BaseException as e:  # surface in the main thread
-                err.append(e)
-                for r in ready:
-                    r.set()
-
-        if prev is not None:
-            gaussians._host_grads_event = None  # consumed by the feeder above
-        worker = threading.Thread(target=feeder, name="clmgs-host-feeder")
-        worker.start()
-        # ---- speculation for the next batch: after this batch's late rows, in the pool's idle time
-        new_spec = None
-        if spec_rows is not None:
-            nb = 1 - hb["cur"]
-            n_s = int(spec_rows.shape[0])
-            s_rows_h, s_stage_h, s_dst = hb["spec_rows_h"][:n_s], hb["spec_stage_h"][:n_s], hb["sh_stage"][nb]
-            ev_list = torch.cuda.Event()
-            ev_list.record(default_stream)   # the row list has reached pinned memory once this has passed
-            spec_err, spec_done = [], torch.cuda.Event()
-
-            def speculate():
-                try:
-                    worker.join()            # after this batch's own rows
-                    ev_list.synchronize()
-                    for c0 in range(0, n_s, _HOST_CHUNK_ROWS):
-                        c1 = min(n_s, c0 + _HOST_CHUNK_ROWS)
-                        _tp = time.perf_counter()
-                        gaussians.host_rows_prepare(s_rows_h[c0:c1], s_stage_h[c0:c1], to_step=step,
-                                                    next_g_step=step + 1, sync_grads=False)
-                        _lib.STATS["host_prepare_s"] = _lib.STATS.get("host_prepare_s", 0.0) + time.perf_counter() - _tp
-                        _lib.check(L.clmgs_memcpy_async(cs, ctypes_ptr(s_dst[c0:c1]), ctypes_ptr(s_stage_h[c0:c1]),
-                                                        (c1 - c0) * 192, 1))
-                    spec_done.record(comm_stream)
-                except BaseException as e:
-                    spec_err.append(e)
-
-            th = threading.Thread(target=speculate, name="clmgs-host-speculate")
-            new_spec = dict(key=tuple(sorted(id(c) for c in hint)), N=N, rows=spec_rows, n=n_s, buf=nb, thread=th,
-                            gen=hb["gen"], event=spec_done, err=spec_err, rows_h=hb["spec_rows_h"])
-        # ---- render: one camera after the other (the mode is bound by the host side, not by the GPU: the
-        # camera pipeline of the HBM mode would only add its per-camera buffers to the peak)
-        _zero_small_grads(gaussians)
-        if spec is not None:
-            default_stream.wait_event(spec["event"])  # the staged block has landed
-        if new_spec is not None:
-            new_spec["thread"].start()
-        losses = []
-        l0 = 0
-        for i in range(bsz):
-            with _lib.host_region("wait_rows"):
-                ready[i].wait()
-            if err:
-                worker.join()
-                raise err[0]
-            default_stream.wait_event(ev_group[i])
-            losses.append(train_one_camera(gaussians, batched_cameras[i], filters[i], sh_stage, 1, g_stage,
-                                           background, batched_cameras[i].original_image, sh_index=sh_index[i]))
-            # rows whose LAST camera this was: their gradient rows go home now (plain stores, side stream)
-            l1 = l0 + n_last[i]
-            if l1 > l0:
-                out_stream.wait_stream(default_stream)
-                with torch.cuda.stream(out_stream):
-                    # (launch width: the kernel is bound by the link -- 51 GB/s of stores -- and its stalled waves take
-                    # wave slots from the render kernels next to it (preprocess_fwd 0.3 -> 4.7 ms in the trace), but
-                    # narrowing it to the reference's grid_size_H = 32 / 128 / 512 workgroups measured 101.3 / 100.6 /
-                    # 101.1 ms per batch against 99.1 at full width: the batch is bound by the link either way)
-                    clm_kernels._rows("clmgs_rows_gather", parameters_grad_buffer[:N, :], g_stage,
-                                      rows_by_last[l0:l1], slots_by_last[l0:l1].to(torch.int64),
-                                      int(getattr(args, "host_scatter_grid", 0)))
-            l0 = l1
-        worker.join()
-        ev_g = torch.cuda.Event()
-        ev_g.record(out_stream)
-        gaussians._host_grads_event = ev_g
-        gaussians._host_keep = (rows32, sh_index, touched_rows, filters, rows_by_last, slots_by_last, late_sorted)
-        if new_spec is not None:
-            hb["cur"] = new_spec["buf"]      # the next batch renders from the table its staged rows are landing in
-            gaussians._host_spec = new_spec
-    if skip_opt:
-        torch.cuda.synchronize()
-        return losses, ordered_cams, sparsity
-    visibility_mask = None
-    if args.sparse_adam:
-        visibility_mask = torch.zeros((N,), dtype=torch.bool, device=dev)
-        utils.fill_rows(visibility_mask, touched_rows, True)
-    _gpu_adam_step(gaussians, args, visibility_mask)
-    gaussians.invalidate_small_packed()
-    _mark_batch(gaussians)
-    row_adam.global_step = step
-    row_adam.state[gaussians._parameters]["step"] = step
-    return losses, ordered_cams, sparsity
-
-
-def ctypes_ptr(t):
-    import ctypes as _c
-    return _c.c_void_p(t.data_ptr())
+        from .host_window import train_one_batch_host_windowed as run
+    else:
+        from .host_batch import train_one_batch_host_batched as run
+    return run(gaussians, scene, batched_cameras, parameters_grad_buffer, background, pipe_args, comm_stream,
+               perm_generator, args)
 
 
 def clm_offload_train_one_batch(gaussians, scene, batched_cameras, parameters_grad_buffer,

@@ -2,7 +2,7 @@
 
 The reference's offloading pipeline keeps, per micro-batch, only what that camera needs on the GPU and retains the rows the
 next camera shares with it (retention sets H / D / G, strategies/clm_offload/engine.py:566-636; 13.0 GB of GPU memory at
-28 M Gaussians, release_scripts/rubble4k_README.md:113).  `engine._train_one_batch_host` (host_staging="batch") stages the
+28 M Gaussians, release_scripts/rubble4k_README.md:113).  `host_batch.py` (host_staging="batch") stages the
 UNION of a batch's rows instead -- three [T, 48] tables, 6.6 GB at 28 M.  This module keeps that mode's properties
 
   * every touched row crosses the host link ONCE per direction and batch (parameters in before the first camera that

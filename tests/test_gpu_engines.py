@@ -25,7 +25,7 @@ def _setup(strategy, residency="hbm", sparse=False, seed=0):
     from clm_gs_amd import utils
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
     staging = {}
-    if residency == "host_batch":  # host-resident rows staged as the union of the batch (engine._train_one_batch_host)
+    if residency == "host_batch":  # host-resident rows staged as the union of the batch (host_batch.py)
         residency, staging = "host", {"host_staging": "batch"}
     if residency == "host_budget":  # host-resident rows, about half of them (K = 1 500) kept in HBM (sh_hbm_budget_gb)
         residency, staging = "host", {"sh_hbm_budget_gb": 1500 * 768 / 1e9 + 1e-9}
