@@ -29,15 +29,18 @@ def _parse_like_log2csv(text):
 
 
 @pytest.mark.parametrize("strategy,residency", [("clm_offload", "hbm"), ("no_offload", "hbm"), ("clm_offload", "host"),
-                                                ("naive_offload", "hbm")])
+                                                ("clm_offload", "host_budget"), ("naive_offload", "hbm")])
 def test_training_loop_improves_psnr_and_logs(dev, strategy, residency):
     from clm_gs_amd import trainer, utils
     from clm_gs_amd.strategies.clm_offload import GaussianModelCLMOffload, clm_offload_eval_one_cam
     from clm_gs_amd.strategies.no_offload import GaussianModelNoOffload
     from clm_gs_amd.synthetic import nadir_cameras, synth_gaussians
     N, W, H, bsz = 20000, 160, 128, 4
-    args = utils.default_args(bsz=bsz, sh_residency=residency, densify_from_iter=100, densification_interval=100,
-                              densify_until_iter=300, densify_grad_threshold=0.00005)
+    budget = {}
+    if residency == "host_budget":  # host-resident rows, 12 000 of them kept and stepped in HBM (sh_hbm_budget_gb): the
+        residency, budget = "host", {"sh_hbm_budget_gb": 12000 * 768 / 1e9 + 1e-9}  # evaluations write them back, the
+    args = utils.default_args(bsz=bsz, sh_residency=residency, densify_from_iter=100, densification_interval=100,  # densifications reload them
+                              densify_until_iter=300, densify_grad_threshold=0.00005, **budget)
     setattr(args, strategy, True)
     utils.set_args(args)
     utils.set_img_size(H, W)
@@ -84,6 +87,8 @@ def test_training_loop_improves_psnr_and_logs(dev, strategy, residency):
     assert model.active_sh_degree == 0  # the first ramp step is at image 1000 (train.py:253-254)
     if residency == "host":
         assert m["pinned_cpu_memory_gb"] > 0
+    if budget:
+        assert model._hbm_prefix is not None and model._hbm_prefix["K"] == 12000 and not model._hbm_prefix["dirty"]
 
 
 def test_longer_pipelined_run_with_densification_is_stable(dev):
