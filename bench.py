@@ -878,10 +878,25 @@ def main():
                 _ms = _e0.elapsed_time(_e1)
                 _best = _ms if _best is None else min(_best, _ms)
             alloc_info[_nm]["read_GBps"] = round(_flat.numel() * 4 / (_best * 1e-3) / 1e9, 1)
+        # ... and the rate of a row GATHER from each row table (what the deferred row pass and the projection kernels do to
+        # them; clm_gs_amd/placement.py): this is the figure that moves with the physical placement
+        from clm_gs_amd import placement as _pl
+        _rows48 = {k: v for k, v in _tabs.items() if v.dim() == 2 and v.shape[1] == 48}
+        if _rows48:
+            _cap = min(int(v.shape[0]) for v in _rows48.values())
+            _idx = _pl._probe_index(_cap, torch.device("cuda"))
+            _scr = torch.empty((_idx.numel(), 48), device="cuda")
+            for _nm, _t in _rows48.items():
+                alloc_info[_nm]["gather_GBps"] = round(_pl.gather_rate(_t, _idx, _scr), 1)
+                alloc_info[_nm]["gather_in_place_GBps"] = round(_pl.gather_rate(_t, _idx, _scr, in_place=True), 1)
+            _idx = _scr = None
+        if _pl.probe_log():
+            alloc_info["placement_probe"] = _pl.probe_log()
+        _rows48 = None
         _tabs = _flat = _t = _st = None  # (no reference to the tables may outlive this block: the later legs free the model)
     except Exception as e:  # reporting only
         alloc_info = {"error": f"{type(e).__name__}: {e}"}
-        _tabs = _flat = _t = _st = None
+        _tabs = _flat = _t = _st = _rows48 = _idx = _scr = None
 
     class _Scene:
         cameras_extent = extent

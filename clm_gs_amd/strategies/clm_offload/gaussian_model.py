@@ -53,9 +53,13 @@ class GaussianModelCLMOffload(BaseGaussianModel):
     def sh_on_host(self):
         return getattr(self.args, "sh_residency", "hbm") == "host"
 
-    def _alloc_rows(self, capacity):
+    def _alloc_rows(self, capacity, name=None):
         if self.sh_on_host:
             return pinned_empty((capacity, 48))
+        n_cand = int(getattr(self.args, "placement_candidates", 1) or 1)
+        if n_cand > 1:  # tables of >= 1 GB: the best-placed of a few allocations by a gather probe (placement.py)
+            from ...placement import alloc_rows_placed
+            return alloc_rows_placed(capacity, 48, n_cand, name)
         return torch.empty((capacity, 48), dtype=torch.float32, device="cuda")
 
     def _capacity_for(self, n):
@@ -89,9 +93,9 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         self.spatial_lr_scale = spatial_lr_scale
         n = xyz.shape[0]
         cap = self._capacity_for(n)
-        self.parameters_buffer = self._alloc_rows(cap)
+        self.parameters_buffer = self._alloc_rows(cap, "parameters")
         if not self.only_for_rendering:
-            self.parameters_grad_buffer = self._alloc_rows(cap)
+            self.parameters_grad_buffer = self._alloc_rows(cap, "gradients")
             self.parameters_grad_buffer.zero_()
         self.parameters_buffer[:n].copy_(shs48.reshape(n, 48).float())
         self._xyz = nn.Parameter(xyz.float().cuda().contiguous().requires_grad_(True))
@@ -158,8 +162,8 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         if self._mom_sharded:
             lo, hi = dp.owner_range(n)
             self._mom_lo, m_n, m_cap = lo, hi - lo, self._moment_capacity(cap)
-        self._exp_avg_buffer = self._alloc_rows(m_cap).zero_()
-        self._exp_avg_sq_buffer = self._alloc_rows(m_cap).zero_()
+        self._exp_avg_buffer = self._alloc_rows(m_cap, "exp_avg").zero_()
+        self._exp_avg_sq_buffer = self._alloc_rows(m_cap, "exp_avg_sq").zero_()
         self.optimizer = UnifiedAdam(
             l, [3, 45], [training_args.feature_lr, training_args.feature_lr / 20.0], lr=0.0,
             bias_correction=True, betas=(0.9, 0.999), eps=1e-15, fused=True, sparse=a.sparse_adam,
@@ -838,7 +842,7 @@ class GaussianModelCLMOffload(BaseGaussianModel):
         n = self._parameters.shape[0]
         for attr in self._full_row_buffers():
             old = getattr(self, attr)
-            new = self._alloc_rows(new_cap)
+            new = self._alloc_rows(new_cap, attr)
             new[:n].copy_(old[:n])
             if attr != "parameters_buffer":
                 new[n:].zero_()

@@ -70,6 +70,8 @@ def default_args(**over):
         first_touch_grads=True,  # fused HBM engine: SH gradient rows stored on first touch, never cleared
         host_staging="window",           # host-resident mode: "window" = per-camera staging tables + the rows several cameras
                                          # share (strategies/clm_offload/host_window.py), "batch" = the union of the batch's rows
+        placement_candidates=1,          # HBM row tables of >= 1 GB: keep the best-placed of this many allocations, judged by a
+                                         # gather probe at set-up time (clm_gs_amd/placement.py); 1 = take what comes
         sh_hbm_budget_gb=0.0,            # host-resident mode, window staging: this much HBM (768 B per row: parameters, two
                                          # moments, gradient) keeps rows [0, K) of the Z-ordered SH table RESIDENT -- rendered
                                          # from and stepped in HBM, never crossing the link (gaussian_model.hbm_prefix_*)
