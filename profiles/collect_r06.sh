@@ -46,6 +46,8 @@ timeout 400 python bench.py --config rubble10m --steps 10 --warmup 3 $N > $O/ben
 timeout 300 python bench.py --config bicycle6m --strategy no_offload --steps 10 --warmup 3 $N > $O/bench_bicycle6m_no_offload.log 2>&1
 timeout 300 python bench.py --config bicycle6m --steps 10 --warmup 3 $N > $O/bench_bicycle6m_clm.log 2>&1
 timeout 400 python bench.py --config bigcity102m --steps 6 --warmup 2 $N > $O/bench_bigcity102m_1gpu.log 2>&1
+timeout 900 python bench.py --config bigcity102m --bsz 64 --steps 4 --warmup 2 $N > $O/bench_bigcity102m_bsz64_1gpu.log 2>&1
+bash profiles/host_budget_curve.sh > /dev/null 2>&1; cp gpurun_out/r06/host_budget_curve.jsonl $O/host_budget_curve.jsonl
 # 7. probes
 timeout 200 python profiles/raster_microbench.py > $O/raster_microbench.txt 2>&1
 timeout 200 python profiles/raster_microbench.py heavy 10 >> $O/raster_microbench.txt 2>&1
