@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_s /tmp/pmcF /tmp/pmcW /tmp/pmcS
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o st -- python $R/bench.py --steps 8 --warmup 3 $N --no-kernel-timing --gt resident > $O/prof_s.log 2>&1
 DB=$(find /tmp/prof_s -name "*.db" | head -1)
-python $R/profiles/kernel_stats.py "$DB" 165 > $O/kernel_stats.csv
+python $R/profiles/kernel_stats.py "$DB" 160 "adam_catch_up48_kernel<int>" > $O/kernel_stats.csv  # the 8 timed steps, up to the final flush
 python $R/profiles/timeline.py $DB step3 > $O/timeline_step.txt 2>&1
 python $R/profiles/timeline_streams.py $DB step3 > $O/timeline_streams.txt 2>&1
 cd $R
